@@ -1,0 +1,512 @@
+"""Flat compiled model: the constants the stepping kernels consume.
+
+The reference builds an MJCF document and lets MuJoCo's compiler turn it into an
+``MjModel`` (``src/flygym/compose/base.py:21-27``).  Here the same inputs — rigging
+table, meshes, joint/actuator/contact settings chosen through the ``Fly`` / ``World``
+API — are compiled by :func:`compile_world` into a dictionary of float64 / int32
+arrays (a :class:`CompiledModel`) that serialises to one binary blob read by both the
+C oracle (``oracle/nmf_oracle.c``) and the HIP library (``flygym_amd/csrc``).
+
+Compile-time semantics restated from MuJoCo's documented compiler behaviour
+(parameters cited to the reference):
+
+* ``boundmass=1e-6`` / ``boundinertia=1e-12`` lower clamps, ``angle=radian``
+  (``assets/model/mujoco_globals.yaml:1-7``);
+* every body has one geom with explicit ``mass`` (``fly.py:603-611``): inertia is the
+  shape's unit-density inertia scaled to that mass;
+* bodies without joints are rigidly merged into their moving ancestor for the
+  dynamics ("static fusing"); the 69 named segment poses are kept as constant
+  offsets so the observation surface is unchanged;
+* ``body_invweight0`` (used by the contact regulariser) is evaluated per *named
+  segment* at ``qpos0`` (all hinge angles 0, root at the spawn pose).
+"""
+
+from __future__ import annotations
+
+import hashlib
+import struct
+from pathlib import Path
+
+import numpy as np
+
+from . import rigid
+from .mesh import MeshData, capsule_from_inertia_box, capsule_inertia, mirror_y
+
+__all__ = ["CompiledModel", "compile_world", "ASSET_PACK"]
+
+ASSET_PACK = Path(__file__).resolve().parents[1] / "assets" / "nmf_assets.npz"
+
+GEOM_CAPSULE, GEOM_HULL = 0, 1
+ACT_POSITION, ACT_ADHESION, ACT_MOTOR = 0, 1, 2
+
+_MAGIC = b"NMFMODEL"
+_VERSION = 3
+_DT = {np.dtype(np.float64): 0, np.dtype(np.int32): 1}
+
+
+class CompiledModel(dict):
+    """``dict[str, np.ndarray]`` with (de)serialisation; keys are the blob entry names."""
+
+    meta: dict
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.meta = {}
+
+    # sizes ---------------------------------------------------------------
+    @property
+    def nb(self): return int(self["body_parent"].shape[0])
+    @property
+    def nv(self): return int(self["dof_body"].shape[0])
+    @property
+    def nq(self): return self.nv + 1
+    @property
+    def nu(self): return int(self["act_type"].shape[0])
+    @property
+    def ng(self): return int(self["geom_body"].shape[0])
+    @property
+    def nseg(self): return int(self["seg_body"].shape[0])
+    @property
+    def nsite(self): return int(self["site_body"].shape[0])
+
+    # blob ----------------------------------------------------------------
+    def to_blob(self) -> bytes:
+        names = sorted(self.keys())
+        head = struct.calcsize("<8sII")
+        ent = struct.calcsize("<32sII4qqq")
+        off = head + ent * len(names)
+        off = (off + 63) // 64 * 64
+        table, chunks = [], []
+        for n in names:
+            a = np.ascontiguousarray(self[n])
+            if a.dtype not in _DT:
+                a = a.astype(np.float64 if a.dtype.kind == "f" else np.int32)
+            shape = list(a.shape) + [0] * (4 - a.ndim)
+            table.append(struct.pack("<32sII4qqq", n.encode(), _DT[a.dtype], a.ndim, *shape, off, a.nbytes))
+            chunks.append((off, a.tobytes()))
+            off = (off + a.nbytes + 63) // 64 * 64
+        buf = bytearray(off)
+        buf[0:head] = struct.pack("<8sII", _MAGIC, _VERSION, len(names))
+        for i, t in enumerate(table):
+            buf[head + i * ent: head + (i + 1) * ent] = t
+        for o, b in chunks:
+            buf[o:o + len(b)] = b
+        return bytes(buf)
+
+    @classmethod
+    def from_blob(cls, blob: bytes) -> "CompiledModel":
+        magic, ver, n = struct.unpack_from("<8sII", blob, 0)
+        if magic != _MAGIC or ver != _VERSION:
+            raise ValueError("not an NMFMODEL v%d blob" % _VERSION)
+        head = struct.calcsize("<8sII")
+        ent = struct.calcsize("<32sII4qqq")
+        out = cls()
+        for i in range(n):
+            name, dt, nd, s0, s1, s2, s3, off, nbytes = struct.unpack_from("<32sII4qqq", blob, head + i * ent)
+            dtype = np.float64 if dt == 0 else np.int32
+            shape = (s0, s1, s2, s3)[:nd]
+            out[name.rstrip(b"\0").decode()] = np.frombuffer(blob, dtype=dtype, count=int(np.prod(shape, dtype=np.int64)), offset=off).reshape(shape).copy()
+        return out
+
+    def save(self, path):
+        Path(path).write_bytes(self.to_blob())
+
+    @classmethod
+    def load(cls, path):
+        return cls.from_blob(Path(path).read_bytes())
+
+    def digest(self) -> str:
+        return hashlib.sha256(self.to_blob()).hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------
+# asset access
+# ----------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def load_asset_pack(path=None):
+    path = Path(path or ASSET_PACK)
+    if path not in _pack_cache:
+        if not path.exists():
+            raise FileNotFoundError(
+                f"asset pack {path} missing: run scripts/build_asset_pack.py against a flygym asset directory"
+            )
+        _pack_cache[path] = dict(np.load(path, allow_pickle=False))
+    return _pack_cache[path]
+
+
+def mesh_for_segment(pack, seg_name: str, mesh_type: str, mirror_left2right=True) -> MeshData:
+    """Mesh constants for a segment, with the reference's fallback and mirroring rules
+    (``fly.py:514-543``): right-side segments reuse the left mesh under y → −y; a mesh
+    absent from ``mesh_type`` falls back to ``fullsize``."""
+    src = seg_name
+    flip = False
+    if mirror_left2right and seg_name[0] == "r":
+        src, flip = "l" + seg_name[1:], True
+    for mt in (mesh_type, "fullsize"):
+        key = f"mesh/{mt}/{src}"
+        if key + "/props" in pack:
+            p = pack[key + "/props"]
+            md = MeshData(
+                volume=float(p[0]), hull_volume=float(p[1]), n_vertices=int(p[2]), n_faces=int(p[3]),
+                com=p[4:7].copy(), inertia=p[7:16].reshape(3, 3).copy(),
+                hull_vertices=pack[key + "/hull_v"].copy(), hull_faces=pack[key + "/hull_f"].copy(),
+            )
+            return mirror_y(md) if flip else md
+    raise FileNotFoundError(f"Mesh file not found for segment {seg_name}")
+
+
+# ----------------------------------------------------------------------------
+# compile
+# ----------------------------------------------------------------------------
+def _segment_inertial(md: MeshData, mass: float, as_capsule: bool, boundinertia: float):
+    """(ipos, principal rotation, principal moments, capsule(r, half)|None) in segment frame."""
+    w, R = md.principal()
+    cap = None
+    if as_capsule:
+        r, half = capsule_from_inertia_box(md)
+        moments = capsule_inertia(r, half, mass)
+        cap = (r, half)
+    else:
+        moments = mass * w / md.volume
+    moments = np.maximum(moments, boundinertia)
+    return md.com.copy(), R, moments, cap
+
+
+def compile_world(world) -> CompiledModel:
+    """Compile a ``flygym_amd.compose`` world holding exactly one fly."""
+    if len(world.fly_lookup) != 1:
+        raise ValueError("the MI355X engine steps exactly one fly per world (batch = many worlds)")
+    fly = next(iter(world.fly_lookup.values()))
+    pack = load_asset_pack(fly.asset_pack_path)
+    opt = fly.mujoco_globals
+    boundmass = float(opt["compiler"].get("boundmass", 0.0))
+    boundinertia = float(opt["compiler"].get("boundinertia", 0.0))
+
+    seg_names = [s.name for s in fly.get_bodysegs_order()]
+    seg_index = {n: i for i, n in enumerate(seg_names)}
+    ns = len(seg_names)
+    rig_idx = {str(n): i for i, n in enumerate(pack["rigging_names"])}
+
+    seg_parent = np.full(ns, -1, dtype=np.int64)
+    for parent, child in fly.segment_edges():
+        seg_parent[seg_index[child]] = seg_index[parent]
+
+    seg_pos = np.zeros((ns, 3))
+    seg_quat = np.zeros((ns, 4))
+    seg_mass = np.zeros(ns)
+    seg_ipos = np.zeros((ns, 3))
+    seg_imat = np.zeros((ns, 3, 3))        # inertia about COM, segment frame
+    seg_geomR = np.zeros((ns, 3, 3))       # geom (principal) frame in segment frame
+    seg_capsule = [None] * ns
+    seg_mesh = [None] * ns
+    for i, n in enumerate(seg_names):
+        r = rig_idx[n]
+        seg_pos[i] = pack["rigging_pos"][r]
+        seg_quat[i] = rigid.quat_normalize(pack["rigging_quat"][r])
+        seg_mass[i] = max(float(pack["rigging_mass"][r]), boundmass)
+        md = mesh_for_segment(pack, n, fly.mesh_type.value, fly.mirror_left2right)
+        ipos, R, moments, cap = _segment_inertial(md, seg_mass[i], fly.segment_is_capsule(n), boundinertia)
+        seg_ipos[i], seg_geomR[i] = ipos, R
+        seg_imat[i] = R @ np.diag(moments) @ R.T
+        seg_capsule[i], seg_mesh[i] = cap, md
+
+    # ---- dofs per segment, in skeleton order --------------------------------
+    jointdofs = fly.get_jointdofs_order()
+    seg_dofs: dict[int, list] = {}
+    for d in jointdofs:
+        seg_dofs.setdefault(seg_index[d.child.name], []).append(d)
+
+    # ---- dynamic bodies: attach body (free joint) + every segment with hinges --
+    # body 0 is the attachment frame created by spawn_site.attach(...).add("freejoint")
+    # (world.py:274-277); the root segment hangs off it at its rigging pose.
+    dyn_of_seg = np.full(ns, -1, dtype=np.int64)
+    seg_off_pos = np.zeros((ns, 3))             # pose of the segment frame in its dyn body frame
+    seg_off_mat = np.zeros((ns, 3, 3))
+    body_parent, body_pos, body_quat, body_seg = [-1], [np.zeros(3)], [np.array([1.0, 0, 0, 0])], [-1]
+    order = list(range(ns))  # seg order is already parent-before-child (DFS)
+    for s in order:
+        p = seg_parent[s]
+        Rs = rigid.quat_to_mat(seg_quat[s])
+        if p < 0:
+            par_body, par_pos, par_mat = 0, np.zeros(3), np.eye(3)
+        else:
+            par_body, par_pos, par_mat = dyn_of_seg[p], seg_off_pos[p], seg_off_mat[p]
+        pos_in_parbody = par_pos + par_mat @ seg_pos[s]
+        mat_in_parbody = par_mat @ Rs
+        if s in seg_dofs:
+            dyn_of_seg[s] = len(body_parent)
+            body_parent.append(int(par_body))
+            body_pos.append(pos_in_parbody)
+            body_quat.append(rigid.mat_to_quat(mat_in_parbody))
+            body_seg.append(s)
+            seg_off_pos[s], seg_off_mat[s] = np.zeros(3), np.eye(3)
+        else:
+            dyn_of_seg[s] = par_body
+            seg_off_pos[s], seg_off_mat[s] = pos_in_parbody, mat_in_parbody
+    nb = len(body_parent)
+
+    # ---- fused inertias ----------------------------------------------------
+    body_mass = np.zeros(nb)
+    body_mc = np.zeros((nb, 3))
+    body_I0 = np.zeros((nb, 3, 3))  # about the dyn body origin
+    # the attachment body itself: massless in MJCF → boundmass / boundinertia
+    body_mass[0] += boundmass
+    body_I0[0] += np.eye(3) * boundinertia
+    for s in range(ns):
+        b = dyn_of_seg[s]
+        c = seg_off_pos[s] + seg_off_mat[s] @ seg_ipos[s]
+        Ic = seg_off_mat[s] @ seg_imat[s] @ seg_off_mat[s].T
+        m = seg_mass[s]
+        body_mass[b] += m
+        body_mc[b] += m * c
+        body_I0[b] += Ic + m * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+    body_ipos = body_mc / body_mass[:, None]
+    body_inertia = np.zeros((nb, 6))
+    for b in range(nb):
+        c = body_ipos[b]
+        Ic = body_I0[b] - body_mass[b] * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+        body_inertia[b] = rigid.mat_to_sym6(Ic)
+
+    # ---- dof tables ----------------------------------------------------------
+    nv = 6 + len(jointdofs)
+    dof_body = np.zeros(nv, dtype=np.int32)
+    dof_parent = np.full(nv, -1, dtype=np.int32)
+    dof_axis = np.zeros((nv, 3))
+    dof_armature = np.zeros(nv)
+    dof_damping = np.zeros(nv)
+    dof_stiffness = np.zeros(nv)
+    dof_springref = np.zeros(nv)
+    body_dofadr = np.zeros(nb, dtype=np.int32)
+    body_dofnum = np.zeros(nb, dtype=np.int32)
+    body_dofnum[0] = 6
+    for i in range(6):
+        dof_parent[i] = i - 1
+    dof_axis[3:6] = np.eye(3)
+    dof_index = {}
+    last_dof_of_body = {0: 5}
+    adr = 6
+    for b in range(1, nb):
+        s = body_seg[b]
+        body_dofadr[b] = adr
+        prev = last_dof_of_body[body_parent[b]]
+        for d in seg_dofs[s]:
+            jp = fly.joint_params[d]
+            dof_body[adr] = b
+            dof_parent[adr] = prev
+            dof_axis[adr] = jp["axis"]
+            dof_armature[adr] = jp["armature"]
+            dof_damping[adr] = jp["damping"]
+            dof_stiffness[adr] = jp["stiffness"]
+            dof_springref[adr] = jp["springref"]
+            dof_index[d] = adr
+            prev = adr
+            adr += 1
+        body_dofnum[b] = adr - body_dofadr[b]
+        last_dof_of_body[b] = prev
+    # the compose layer iterates jointdofs in DFS order, bodies were created in the same
+    # order, so dof addresses follow fly.get_jointdofs_order() exactly:
+    assert [dof_index[d] for d in jointdofs] == list(range(6, nv))
+
+    m = CompiledModel()
+    m["opt_timestep"] = np.array([float(opt["option"]["timestep"])])
+    m["opt_gravity"] = np.array(opt["option"]["gravity"], dtype=np.float64)
+    m["opt_solver"] = np.array([int(opt["option"].get("iterations", 100)), int(world.noslip_iterations)], dtype=np.int32)
+    m["opt_tolerance"] = np.array([1e-8])
+    m["body_parent"] = np.array(body_parent, dtype=np.int32)
+    m["body_pos"] = np.array(body_pos)
+    m["body_quat"] = np.array(body_quat)
+    m["body_mass"] = body_mass
+    m["body_ipos"] = body_ipos
+    m["body_inertia"] = body_inertia
+    m["body_dofadr"] = body_dofadr
+    m["body_dofnum"] = body_dofnum
+    m["dof_body"] = dof_body
+    m["dof_parent"] = dof_parent
+    m["dof_axis"] = dof_axis
+    m["dof_armature"] = dof_armature
+    m["dof_damping"] = dof_damping
+    m["dof_stiffness"] = dof_stiffness
+    m["dof_springref"] = dof_springref
+    m["seg_body"] = dyn_of_seg.astype(np.int32)
+    m["seg_pos"] = seg_off_pos
+    m["seg_quat"] = np.array([rigid.mat_to_quat(seg_off_mat[s]) for s in range(ns)])
+
+    # ---- sites ---------------------------------------------------------------
+    site_segs = [seg_index[j.child.name] for j in fly.get_sites_order()]
+    m["site_body"] = np.array([dyn_of_seg[s] for s in site_segs], dtype=np.int32).reshape(-1)
+    m["site_pos"] = np.array([seg_off_pos[s] for s in site_segs]).reshape(-1, 3)
+
+    # ---- actuators (MJCF order: in the order they were added) -----------------
+    act_type, act_trn, act_gain, act_bias, act_frc, act_ctrl, act_lim = [], [], [], [], [], [], []
+    for a in fly.actuators:
+        if a["kind"] == "adhesion":
+            act_type.append(ACT_ADHESION)
+            act_trn.append(int(dyn_of_seg[seg_index[a["segment"]]]))
+            act_gain.append(a["gain"])
+            act_bias.append([0.0, 0.0])
+        else:
+            act_type.append(ACT_POSITION if a["kind"] == "position" else ACT_MOTOR)
+            act_trn.append(dof_index[a["jointdof"]])
+            kp, kv = a.get("kp", 1.0), a.get("kv", 0.0)
+            if a["kind"] == "position":
+                act_gain.append(kp)
+                act_bias.append([-kp, -kv])
+            else:
+                act_gain.append(a.get("gear", 1.0))
+                act_bias.append([0.0, 0.0])
+        act_frc.append(a["forcerange"])
+        act_ctrl.append(a["ctrlrange"])
+        act_lim.append([int(a["forcelimited"]), int(a["ctrllimited"])])
+    nu = len(act_type)
+    m["act_type"] = np.array(act_type, dtype=np.int32).reshape(nu)
+    m["act_trn"] = np.array(act_trn, dtype=np.int32).reshape(nu)
+    m["act_gain"] = np.array(act_gain, dtype=np.float64).reshape(nu)
+    m["act_bias"] = np.array(act_bias, dtype=np.float64).reshape(nu, 2)
+    m["act_forcerange"] = np.array(act_frc, dtype=np.float64).reshape(nu, 2)
+    m["act_ctrlrange"] = np.array(act_ctrl, dtype=np.float64).reshape(nu, 2)
+    m["act_limited"] = np.array(act_lim, dtype=np.int32).reshape(nu, 2)
+
+    # ---- keyframe "neutral" (fly.py:658-678, world.py:151-207) ----------------
+    qpos = np.zeros(nv + 1)
+    qpos[0:3] = world.spawn_position
+    qpos[3:7] = rigid.quat_normalize(world.spawn_quat)
+    for d, ang in fly.jointdof_to_neutralangle.items():
+        qpos[dof_index[d] + 1] = ang
+    m["key_qpos"] = qpos
+    m["key_ctrl"] = np.array([a["neutral"] for a in fly.actuators], dtype=np.float64).reshape(nu)
+    qpos0 = np.zeros(nv + 1)
+    qpos0[0:7] = qpos[0:7]
+    m["qpos0"] = qpos0
+
+    # ---- contact geoms ---------------------------------------------------------
+    cps = world.ground_contact_params
+    contact_segs = [seg_index[s.name] for s in world.bodysegs_with_ground_contact]
+    g_body, g_seg, g_type, g_p0, g_p1, g_rad, g_hadr, g_hnum, g_bs = [], [], [], [], [], [], [], [], []
+    hull_chunks, hadr = [], 0
+    for s in contact_segs:
+        md = seg_mesh[s]
+        T_pos, T_mat = seg_off_pos[s], seg_off_mat[s]
+        g_body.append(int(dyn_of_seg[s]))
+        g_seg.append(s)
+        if seg_capsule[s] is not None:
+            r, half = seg_capsule[s]
+            zax = seg_geomR[s][:, 2]
+            c = seg_ipos[s]
+            p0 = T_pos + T_mat @ (c - zax * half)
+            p1 = T_pos + T_mat @ (c + zax * half)
+            g_type.append(GEOM_CAPSULE)
+            g_p0.append(p0); g_p1.append(p1); g_rad.append(r)
+            g_hadr.append(0); g_hnum.append(0)
+            g_bs.append([*(0.5 * (p0 + p1)), half + r])
+        else:
+            hv = (T_mat @ md.hull_vertices.T).T + T_pos
+            g_type.append(GEOM_HULL)
+            g_p0.append(np.zeros(3)); g_p1.append(np.zeros(3)); g_rad.append(0.0)
+            g_hadr.append(hadr); g_hnum.append(len(hv))
+            hull_chunks.append(hv)
+            hadr += len(hv)
+            centre = 0.5 * (hv.min(axis=0) + hv.max(axis=0))
+            g_bs.append([*centre, float(np.linalg.norm(hv - centre, axis=1).max())])
+    ng = len(contact_segs)
+    m["geom_body"] = np.array(g_body, dtype=np.int32).reshape(ng)
+    m["geom_seg"] = np.array(g_seg, dtype=np.int32).reshape(ng)
+    m["geom_type"] = np.array(g_type, dtype=np.int32).reshape(ng)
+    m["geom_p0"] = np.array(g_p0, dtype=np.float64).reshape(ng, 3)
+    m["geom_p1"] = np.array(g_p1, dtype=np.float64).reshape(ng, 3)
+    m["geom_radius"] = np.array(g_rad, dtype=np.float64).reshape(ng)
+    m["geom_hulladr"] = np.array(g_hadr, dtype=np.int32).reshape(ng)
+    m["geom_hullnum"] = np.array(g_hnum, dtype=np.int32).reshape(ng)
+    m["geom_bsphere"] = np.array(g_bs, dtype=np.float64).reshape(ng, 4)
+    m["hull_vert"] = np.concatenate(hull_chunks, axis=0) if hull_chunks else np.zeros((0, 3))
+    fr = cps.get_friction_tuple()
+    sr = cps.get_solref_tuple()
+    si = _solimp5(cps.get_solimp_tuple())
+    m["pair_friction"] = np.tile(np.array(fr, dtype=np.float64), (ng, 1)).reshape(ng, 5)
+    m["pair_solref"] = np.tile(np.array(sr, dtype=np.float64), (ng, 1)).reshape(ng, 2)
+    m["pair_solimp"] = np.tile(si, (ng, 1)).reshape(ng, 5)
+    m["pair_margin"] = np.full(ng, float(cps.margin))
+    m["hull_skin"] = np.array([1e-3])
+
+    # leg contact sensors (world.py:311-331): geoms of a leg whose segment is at or
+    # below the most proximal contacting segment feed that leg's sensor
+    from ..anatomy import LEGS
+    g_sensor = np.full(ng, -1, dtype=np.int32)
+    if world.add_ground_contact_sensors:
+        for gi, s in enumerate(contact_segs):
+            pos = seg_names[s].split("_")[0]
+            if pos in LEGS:
+                g_sensor[gi] = LEGS.index(pos)
+    m["geom_sensor"] = g_sensor
+    m["n_sensor"] = np.array([6 if world.add_ground_contact_sensors else 0], dtype=np.int32)
+
+    # adhesion: actuator index per leg order (simulation.py:387-404)
+    m["plane"] = np.array([0.0, 0.0, 1.0, 0.0])  # ground plane n·x = d  (world.py:251-261)
+
+    # ---- invweight0 at qpos0 ---------------------------------------------------
+    M0 = rigid.mass_matrix_from_jacobians(m, qpos0)
+    m["stat_meaninertia"] = np.array([float(np.mean(np.diag(M0)))])
+    Minv = np.linalg.inv(M0)
+    xpos, xmat, xquat = rigid.forward_kinematics(m, qpos0)
+    axis, anchor = rigid.dof_axes_world(m, qpos0, xpos, xmat, xquat)
+    seg_invw = np.zeros((ns, 2))
+    for s in range(ns):
+        b = int(dyn_of_seg[s])
+        com = xpos[b] + xmat[b] @ (seg_off_pos[s] + seg_off_mat[s] @ seg_ipos[s])
+        J = rigid.point_jacobian(m, b, com, axis, anchor)
+        A = J @ Minv @ J.T
+        seg_invw[s] = [np.trace(A[0:3, 0:3]) / 3.0, np.trace(A[3:6, 3:6]) / 3.0]
+    m["seg_invweight0"] = seg_invw
+    m["geom_invweight0"] = seg_invw[contact_segs, 0].reshape(ng) if ng else np.zeros(0)
+
+    # structure summary for the star-of-chains fast path
+    m["star"] = _star_structure(m)
+    m.meta = {
+        "seg_names": seg_names,
+        "dof_names": [d.name for d in jointdofs],
+        "actuator_names": [a["name"] for a in fly.actuators],
+        "fly_name": fly.name,
+    }
+    return m
+
+
+def _solimp5(t):
+    """MJCF fills the values given and keeps the defaults for the rest
+    (default solimp = 0.9 0.95 0.001 0.5 2); the reference passes FOUR numbers
+    (``compose/physics.py:103-111``) so its midpoint/sharpness land in width/midpoint.
+    The engine then clamps: d0,dmax,midpoint to [1e-4, 0.9999], width ≥ 0, power ≥ 1."""
+    full = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
+    full[: len(t)] = t
+    lo, hi = 1e-4, 0.9999
+    full[0] = min(max(full[0], lo), hi)
+    full[1] = min(max(full[1], lo), hi)
+    full[2] = max(full[2], 0.0)
+    full[3] = min(max(full[3], lo), hi)
+    full[4] = max(full[4], 1.0)
+    return full
+
+
+def _star_structure(m) -> np.ndarray:
+    """[is_star, n_chain, chain_dofs, chain_bodies] — 1 if every non-root body lies on one of
+    ``n_chain`` equal serial chains hanging off the root (the HIP fast path's layout)."""
+    nb = m["body_parent"].shape[0]
+    parent = m["body_parent"]
+    children = {b: [] for b in range(nb)}
+    for b in range(1, nb):
+        children[int(parent[b])].append(b)
+    chains = []
+    ok = True
+    for c in children[0]:
+        chain = [c]
+        while len(children[chain[-1]]) == 1:
+            chain.append(children[chain[-1]][0])
+        if children[chain[-1]]:
+            ok = False
+        chains.append(chain)
+    lens = {len(c) for c in chains}
+    dofs = {int(sum(m["body_dofnum"][b] for b in c)) for c in chains}
+    contiguous = all(c == list(range(c[0], c[0] + len(c))) for c in chains)
+    if ok and len(lens) == 1 and len(dofs) == 1 and contiguous and chains:
+        return np.array([1, len(chains), dofs.pop(), lens.pop()], dtype=np.int32)
+    return np.array([0, len(chains), 0, 0], dtype=np.int32)

@@ -1,0 +1,115 @@
+"""ctypes binding of the CPU oracle (``oracle/nmf_oracle.c``).  TEST INFRASTRUCTURE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import
+this module; nothing under ``flygym_amd/`` does.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+
+
+def build(force: bool = False) -> None:
+    libs = [HERE / "libnmf_oracle_f64.so", HERE / "libnmf_oracle_f32.so"]
+    src = HERE / "nmf_oracle.c"
+    if force or any((not l.exists()) or l.stat().st_mtime < src.stat().st_mtime for l in libs):
+        subprocess.run(["make", "-C", str(HERE), "-s", "-B"], check=True, stderr=subprocess.DEVNULL)
+
+
+_libs = {}
+
+
+def _lib(precision: str):
+    if precision not in _libs:
+        path = HERE / f"libnmf_oracle_{precision}.so"
+        if not path.exists():
+            build()
+        lib = ctypes.CDLL(str(path))
+        sfx = "_" + precision
+        for name, res, args in [
+            ("nmfo_model_create", ctypes.c_void_p, [ctypes.c_char_p, ctypes.c_int64]),
+            ("nmfo_model_dims", None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+            ("nmfo_data_create", ctypes.c_void_p, [ctypes.c_void_p]),
+            ("nmfo_forward", None, [ctypes.c_void_p, ctypes.c_void_p]),
+            ("nmfo_step", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+            ("nmfo_reset", None, [ctypes.c_void_p, ctypes.c_void_p]),
+            ("nmfo_ptr", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+            ("nmfo_ints", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+        ]:
+            fn = getattr(lib, name + sfx)
+            fn.restype, fn.argtypes = res, args
+        _libs[precision] = lib
+    return _libs[precision]
+
+
+class Oracle:
+    """One world stepped on the CPU.  ``precision`` is ``"f64"`` or ``"f32"``."""
+
+    def __init__(self, model_blob: bytes, precision: str = "f64"):
+        self.precision = precision
+        self.dtype = np.float64 if precision == "f64" else np.float32
+        self._lib = _lib(precision)
+        self._sfx = "_" + precision
+        self._blob = bytes(model_blob)
+        self._m = self._call("nmfo_model_create", self._blob, len(self._blob))
+        if not self._m:
+            raise ValueError("bad model blob")
+        dims = (ctypes.c_int * 10)()
+        self._call("nmfo_model_dims", self._m, dims)
+        (self.nq, self.nv, self.nu, self.nb, self.nseg, self.ng, self.nsite, self.maxcon,
+         self.nsensor, _) = list(dims)
+        self._d = self._call("nmfo_data_create", self._m)
+        self.reset()
+
+    def _call(self, name, *args):
+        return getattr(self._lib, name + self._sfx)(*args)
+
+    def clone_data(self) -> "Oracle":
+        other = Oracle(self._blob, self.precision)
+        for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+            other.arr(k)[:] = self.arr(k)
+        other.arr("time")[:] = self.arr("time")
+        return other
+
+    def arr(self, name: str) -> np.ndarray:
+        """Writable view of an engine array (flat)."""
+        n = ctypes.c_int(0)
+        p = self._call("nmfo_ptr", self._m, self._d, name.encode(), ctypes.byref(n))
+        if not p and n.value == 0:
+            if name in ("con_dist", "con_pos", "efc_force", "efc_aref", "efc_D", "J", "site_xpos"):
+                return np.zeros(0, dtype=self.dtype)
+            raise KeyError(name)
+        ctype = ctypes.c_double if self.precision == "f64" else ctypes.c_float
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctype)), shape=(n.value,))
+
+    def ints(self):
+        out = (ctypes.c_int * 4)()
+        geoms = (ctypes.c_int * self.maxcon)()
+        self._call("nmfo_ints", self._m, self._d, out, geoms)
+        ncon = out[0]
+        return dict(ncon=ncon, nefc=out[1], overflow=out[2], solver_iter=out[3], con_geom=list(geoms)[:ncon])
+
+    def reset(self):
+        self._call("nmfo_reset", self._m, self._d)
+
+    def forward(self):
+        self._call("nmfo_forward", self._m, self._d)
+
+    def step(self, n: int = 1):
+        self._call("nmfo_step", self._m, self._d, int(n))
+
+    # convenience ----------------------------------------------------------
+    @property
+    def qpos(self): return self.arr("qpos")
+    @property
+    def qvel(self): return self.arr("qvel")
+    @property
+    def ctrl(self): return self.arr("ctrl")
+    @property
+    def time(self): return float(self.arr("time")[0])
