@@ -1,0 +1,19 @@
+"""flygym_amd — MI355X-native batched NeuroMechFly stepping engine.
+
+Drop-in for the physics hot path of NeLy-EPFL/flygym (``Simulation`` / ``GPUSimulation`` ``step()``):
+hand-written HIP kernels for gfx950 behind the reference's Python surface.
+"""
+
+from . import anatomy, compose
+from .models import make_model
+
+__all__ = ["anatomy", "compose", "make_model", "HIPSimulation"]
+__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    if name == "HIPSimulation":
+        from .simulation import HIPSimulation
+
+        return HIPSimulation
+    raise AttributeError(name)

@@ -1,0 +1,91 @@
+"""ctypes binding of the C ABI in ``include/nmf.h`` (``libnmf_hip.so``).
+
+The product path has no CPU fallback: if the HIP library is missing or no MI355X is visible,
+loading / batch creation raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libnmf_hip.so"
+CSRC = PKG / "csrc"
+INCLUDE = PKG.parent / "include"
+
+FIELDS = dict(
+    qpos=0, qvel=1, ctrl=2, qacc_warmstart=3, seg_xpos=4, seg_xquat=5, site_xpos=6,
+    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11,
+)
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_device.h", INCLUDE / "nmf.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    cmd = [
+        "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(LIB_PATH),
+    ]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise NativeError("hipcc failed:\n" + res.stderr[-4000:])
+    if verbose:
+        print(res.stderr)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the MI355X engine has no CPU fallback)"
+            )
+        L = ctypes.CDLL(str(LIB_PATH))
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        sig = {
+            "nmf_last_error": (ctypes.c_char_p, []),
+            "nmf_model_create": (vp, [ctypes.c_char_p, ctypes.c_size_t]),
+            "nmf_model_destroy": (None, [vp]),
+            "nmf_model_dims": (ci, [vp, ctypes.POINTER(ctypes.c_int32)]),
+            "nmf_batch_create": (vp, [vp, ci, ci]),
+            "nmf_batch_destroy": (None, [vp]),
+            "nmf_batch_n_worlds": (ci, [vp]),
+            "nmf_reset": (ci, [vp, vp]),
+            "nmf_step": (ci, [vp, ci, vp]),
+            "nmf_step_replay": (ci, [vp, vp, ci, ci, vp, ci, ci, vp]),
+            "nmf_field_ptr": (vp, [vp, ci, ctypes.POINTER(ctypes.c_int32)]),
+            "nmf_gather": (ci, [vp, ci, vp, ci, ci, vp, vp]),
+            "nmf_scatter": (ci, [vp, ci, vp, ci, vp, vp]),
+            "nmf_step_count": (ctypes.c_int64, [vp]),
+            "nmf_time_launches": (ctypes.c_double, [vp, vp, ci, ci, vp, ci, ci, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NativeError(lib().nmf_last_error().decode() or "libnmf_hip call failed")
+
+
+def exported_symbols() -> list[str]:
+    """Names declared in include/nmf.h (used by the CPU-side ABI test)."""
+    import re
+
+    text = (INCLUDE / "nmf.h").read_text()
+    return sorted(set(re.findall(r"\b(nmf_[a-z_]+)\s*\(", text)))

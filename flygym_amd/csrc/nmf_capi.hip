@@ -1,0 +1,315 @@
+// nmf_capi.hip — host side of libnmf_hip.so: the C ABI declared in include/nmf.h.
+//
+// Owns device memory for the model constants and the per-world state, launches the fused step
+// kernel (nmf_step.hip) and the gather/scatter kernels.  No torch types, no host sync on the
+// stepping path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nmf.h"
+#include "nmf_step.hip"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& msg) { g_err = msg; return -1; }
+
+#define HIP_OK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct BlobEntry {
+  char name[32];
+  uint32_t dtype, ndim;
+  int64_t shape[4];
+  int64_t offset, nbytes;
+};
+
+struct HostArray {
+  std::vector<float> f;
+  std::vector<int32_t> i;
+  bool is_int = false;
+  int64_t count = 0;
+};
+
+}  // namespace
+
+struct nmf_model {
+  std::vector<uint8_t> blob;
+  std::vector<std::pair<std::string, HostArray>> arrays;
+  int nq = 0, nv = 0, nu = 0, nb = 0, nseg = 0, ng = 0, nsite = 0, nsensor = 0, max_iter = 100;
+  int star[4] = {0, 0, 0, 0};
+  const HostArray* find(const char* name) const {
+    for (auto& kv : arrays) if (kv.first == name) return &kv.second;
+    return nullptr;
+  }
+};
+
+struct nmf_batch {
+  const nmf_model* model = nullptr;
+  int n_worlds = 0, device = 0, topo = 0;
+  nmf::DevModel dm{};
+  nmf::DevState st{};
+  std::vector<void*> allocs;
+  float* fields[NMF_FIELD_COUNT] = {};
+  int widths[NMF_FIELD_COUNT] = {};
+  int64_t steps = 0;
+};
+
+extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
+
+extern "C" nmf_model* nmf_model_create(const void* blob, size_t nbytes) {
+  g_err.clear();
+  if (!blob || nbytes < 16 || memcmp(blob, "NMFMODEL", 8) != 0) { fail("nmf_model_create: not an NMFMODEL blob"); return nullptr; }
+  auto* m = new nmf_model();
+  m->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + nbytes);
+  uint32_t version, n;
+  memcpy(&version, m->blob.data() + 8, 4);
+  memcpy(&n, m->blob.data() + 12, 4);
+  if (version != 3) { delete m; fail("nmf_model_create: unsupported blob version"); return nullptr; }
+  const BlobEntry* e = (const BlobEntry*)(m->blob.data() + 16);
+  for (uint32_t k = 0; k < n; ++k) {
+    HostArray a;
+    int64_t c = 1;
+    for (uint32_t d = 0; d < e[k].ndim; ++d) c *= e[k].shape[d];
+    a.count = c;
+    if ((size_t)(e[k].offset + e[k].nbytes) > nbytes) { delete m; fail("nmf_model_create: truncated blob"); return nullptr; }
+    if (e[k].dtype == 0) {
+      const double* src = (const double*)(m->blob.data() + e[k].offset);
+      a.f.resize((size_t)c);
+      for (int64_t i = 0; i < c; ++i) a.f[(size_t)i] = (float)src[i];
+    } else {
+      a.is_int = true;
+      a.i.resize((size_t)c);
+      memcpy(a.i.data(), m->blob.data() + e[k].offset, sizeof(int32_t) * (size_t)c);
+    }
+    char nm[33];
+    memcpy(nm, e[k].name, 32); nm[32] = 0;
+    m->arrays.emplace_back(std::string(nm), std::move(a));
+  }
+  auto need = [&](const char* nm) -> const HostArray* {
+    const HostArray* a = m->find(nm);
+    if (!a) fail(std::string("nmf_model_create: blob lacks entry ") + nm);
+    return a;
+  };
+  const HostArray *bp = need("body_parent"), *db = need("dof_body"), *at = need("act_type"), *sb = need("seg_body"),
+                  *gb = need("geom_body"), *si = need("site_body"), *ns = need("n_sensor"), *os = need("opt_solver"),
+                  *star = need("star");
+  if (!bp || !db || !at || !sb || !gb || !si || !ns || !os || !star) { delete m; return nullptr; }
+  m->nb = (int)bp->count; m->nv = (int)db->count; m->nq = m->nv + 1; m->nu = (int)at->count;
+  m->nseg = (int)sb->count; m->ng = (int)gb->count; m->nsite = (int)si->count;
+  m->nsensor = ns->i[0]; m->max_iter = os->i[0];
+  for (int k = 0; k < 4; ++k) m->star[k] = star->i[(size_t)k];
+  return m;
+}
+
+extern "C" void nmf_model_destroy(nmf_model* model) { delete model; }
+
+extern "C" int nmf_model_dims(const nmf_model* m, int32_t out[10]) {
+  if (!m) return fail("nmf_model_dims: null model");
+  out[0] = m->nq; out[1] = m->nv; out[2] = m->nu; out[3] = m->nb; out[4] = m->nseg; out[5] = m->ng;
+  out[6] = m->nsite; out[7] = nmf::kMaxCon; out[8] = 96; out[9] = m->star[0];
+  return 0;
+}
+
+namespace {
+
+template <class T>
+int upload(nmf_batch* b, const std::vector<T>& host, const T** dev) {
+  void* p = nullptr;
+  size_t bytes = sizeof(T) * (host.empty() ? 1 : host.size());
+  HIP_OK(hipMalloc(&p, bytes));
+  b->allocs.push_back(p);
+  if (!host.empty()) HIP_OK(hipMemcpy(p, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+  *dev = (const T*)p;
+  return 0;
+}
+
+int upload_f(nmf_batch* b, const char* name, const float** dev) {
+  const HostArray* a = b->model->find(name);
+  if (!a || a->is_int) return fail(std::string("model lacks float entry ") + name);
+  return upload(b, a->f, dev);
+}
+int upload_i(nmf_batch* b, const char* name, const int** dev) {
+  const HostArray* a = b->model->find(name);
+  if (!a || !a->is_int) return fail(std::string("model lacks int entry ") + name);
+  return upload(b, a->i, dev);
+}
+
+int alloc_field(nmf_batch* b, int field, int width, float** out) {
+  void* p = nullptr;
+  size_t bytes = sizeof(float) * (size_t)b->n_worlds * (size_t)(width > 0 ? width : 1);
+  HIP_OK(hipMalloc(&p, bytes));
+  HIP_OK(hipMemset(p, 0, bytes));
+  b->allocs.push_back(p);
+  b->fields[field] = (float*)p;
+  b->widths[field] = width;
+  *out = (float*)p;
+  return 0;
+}
+
+int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
+  dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
+  if (b->topo == 0)
+    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopo>), grid, block, 0, stream, b->dm, b->st, rp, n_steps, mode);
+  else
+    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopoActive>), grid, block, 0, stream, b->dm, b->st, rp, n_steps, mode);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device) {
+  g_err.clear();
+  if (!model) { fail("nmf_batch_create: null model"); return nullptr; }
+  if (n_worlds <= 0) { fail("nmf_batch_create: n_worlds must be positive"); return nullptr; }
+  int topo = -1;
+  if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 11 && model->star[3] == 8) topo = 0;
+  if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 7 && model->star[3] == 4) topo = 1;
+  if (topo < 0) { fail("nmf_batch_create: the HIP engine supports the LEGS_ONLY (6x8 bodies, 6x11 dofs) and LEGS_ACTIVE_ONLY (6x4, 6x7) skeletons"); return nullptr; }
+  if (model->ng > nmf::kWave) { fail("nmf_batch_create: more than 64 contact geoms"); return nullptr; }
+  if (model->nu > nmf::kMaxCtrl) { fail("nmf_batch_create: more than 48 actuators"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
+  auto* b = new nmf_batch();
+  b->model = model; b->n_worlds = n_worlds; b->device = device; b->topo = topo;
+  nmf::DevModel& d = b->dm;
+  d.nb = model->nb; d.nv = model->nv; d.nq = model->nq; d.nu = model->nu; d.ng = model->ng;
+  d.nseg = model->nseg; d.nsite = model->nsite; d.nsensor = model->nsensor; d.max_iter = model->max_iter;
+  auto scalar = [&](const char* nm, int k) { const HostArray* a = model->find(nm); return a && !a->is_int && (int)a->f.size() > k ? a->f[(size_t)k] : 0.f; };
+  d.timestep = scalar("opt_timestep", 0); d.tolerance = scalar("opt_tolerance", 0);
+  d.hull_skin = scalar("hull_skin", 0); d.meaninertia = scalar("stat_meaninertia", 0);
+  for (int k = 0; k < 3; ++k) d.gravity[k] = scalar("opt_gravity", k);
+  for (int k = 0; k < 4; ++k) d.plane[k] = scalar("plane", k);
+  int rc = 0;
+#define UF(n) rc |= upload_f(b, #n, &d.n)
+#define UI(n) rc |= upload_i(b, #n, &d.n)
+  UF(body_pos); UF(body_quat); UF(body_mass); UF(body_ipos); UF(body_inertia);
+  UI(body_dofadr); UI(body_dofnum); UI(dof_body);
+  UF(dof_axis); UF(dof_armature); UF(dof_damping); UF(dof_stiffness); UF(dof_springref);
+  UI(seg_body); UF(seg_pos); UF(seg_quat); UI(site_body); UF(site_pos);
+  UI(act_type); UI(act_trn); UI(act_limited); UF(act_gain); UF(act_bias); UF(act_forcerange); UF(act_ctrlrange);
+  UF(key_qpos); UF(key_ctrl);
+  UI(geom_body); UI(geom_type); UI(geom_hulladr); UI(geom_hullnum); UI(geom_sensor);
+  UF(geom_p0); UF(geom_p1); UF(geom_radius); UF(geom_bsphere); UF(geom_invweight0); UF(hull_vert);
+  UF(pair_friction); UF(pair_solref); UF(pair_solimp); UF(pair_margin);
+#undef UF
+#undef UI
+  nmf::DevState& st = b->st;
+  st.n_worlds = n_worlds;
+  rc |= alloc_field(b, NMF_QPOS, model->nq, &st.qpos);
+  rc |= alloc_field(b, NMF_QVEL, model->nv, &st.qvel);
+  rc |= alloc_field(b, NMF_CTRL, model->nu, &st.ctrl);
+  rc |= alloc_field(b, NMF_QACC_WARMSTART, model->nv, &st.qacc_ws);
+  rc |= alloc_field(b, NMF_SEG_XPOS, model->nseg * 3, &st.seg_xpos);
+  rc |= alloc_field(b, NMF_SEG_XQUAT, model->nseg * 4, &st.seg_xquat);
+  rc |= alloc_field(b, NMF_SITE_XPOS, model->nsite * 3, &st.site_xpos);
+  rc |= alloc_field(b, NMF_ACTUATOR_FORCE, model->nu, &st.actuator_force);
+  rc |= alloc_field(b, NMF_SENSORDATA, 96, &st.sensordata);
+  rc |= alloc_field(b, NMF_TIME, 1, &st.time);
+  rc |= alloc_field(b, NMF_STATS, 4, &st.stats);
+  rc |= alloc_field(b, NMF_QACC, model->nv, &st.qacc);
+  if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
+    std::string keep = g_err.empty() ? std::string("nmf_batch_create: device initialisation failed") : g_err;
+    nmf_batch_destroy(b);
+    g_err = keep;
+    return nullptr;
+  }
+  return b;
+}
+
+extern "C" void nmf_batch_destroy(nmf_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* p : b->allocs) (void)hipFree(p);
+  delete b;
+}
+
+extern "C" int nmf_batch_n_worlds(const nmf_batch* b) { return b ? b->n_worlds : 0; }
+
+extern "C" int nmf_reset(nmf_batch* b, void* stream) {
+  if (!b) return fail("nmf_reset: null batch");
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
+  b->steps = 0;
+  return launch(b, rp, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int nmf_step(nmf_batch* b, int n_steps, void* stream) {
+  if (!b) return fail("nmf_step: null batch");
+  if (n_steps <= 0) return fail("nmf_step: n_steps must be positive");
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
+  b->steps += n_steps;
+  return launch(b, rp, n_steps, 0, (hipStream_t)stream);
+}
+
+extern "C" int nmf_step_replay(nmf_batch* b, const float* table_dev, int table_steps, int n_act,
+                               const int32_t* act_ids_dev, int start, int n_steps, void* stream) {
+  if (!b) return fail("nmf_step_replay: null batch");
+  if (n_steps <= 0) return fail("nmf_step_replay: n_steps must be positive");
+  if (!table_dev || !act_ids_dev || table_steps <= 0 || n_act <= 0 || n_act > b->model->nu)
+    return fail("nmf_step_replay: bad replay table arguments");
+  nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps};
+  b->steps += n_steps;
+  return launch(b, rp, n_steps, 0, (hipStream_t)stream);
+}
+
+extern "C" float* nmf_field_ptr(nmf_batch* b, int field, int32_t* width) {
+  if (!b || field < 0 || field >= NMF_FIELD_COUNT) { fail("nmf_field_ptr: bad field"); return nullptr; }
+  if (width) *width = b->widths[field];
+  return b->fields[field];
+}
+
+extern "C" int nmf_gather(nmf_batch* b, int field, const int32_t* ids_dev, int n_ids, int group, float* dst_dev, void* stream) {
+  if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_gather: bad field");
+  if (n_ids <= 0) return 0;
+  if (group < 1 || !ids_dev || !dst_dev) return fail("nmf_gather: bad arguments");
+  size_t total = (size_t)b->n_worlds * n_ids * group;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nmf::nmf_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
+                     b->widths[field], ids_dev, n_ids, group, dst_dev, b->n_worlds);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nmf_scatter(nmf_batch* b, int field, const int32_t* ids_dev, int n_ids, const float* src_dev, void* stream) {
+  if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_scatter: bad field");
+  if (n_ids <= 0) return 0;
+  if (!ids_dev || !src_dev) return fail("nmf_scatter: bad arguments");
+  size_t total = (size_t)b->n_worlds * n_ids;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nmf::nmf_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
+                     b->widths[field], ids_dev, n_ids, src_dev, b->n_worlds);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t nmf_step_count(const nmf_batch* b) { return b ? b->steps : 0; }
+
+extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int table_steps, int n_act,
+                                    const int32_t* act_ids_dev, int n_steps, int reps, void* stream) {
+  if (!b || reps <= 0 || n_steps <= 0) { fail("nmf_time_launches: bad arguments"); return -1.0; }
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { fail("hipEventCreate failed"); return -1.0; }
+  (void)hipEventRecord(e0, s);
+  int start = 0;
+  for (int r = 0; r < reps; ++r) {
+    int rc = table_dev ? nmf_step_replay(b, table_dev, table_steps, n_act, act_ids_dev, start, n_steps, stream)
+                       : nmf_step(b, n_steps, stream);
+    if (rc != 0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return -1.0; }
+    start += n_steps;
+  }
+  (void)hipEventRecord(e1, s);
+  if (hipEventSynchronize(e1) != hipSuccess) { fail("hipEventSynchronize failed"); return -1.0; }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (double)ms / reps;
+}

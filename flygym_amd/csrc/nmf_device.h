@@ -1,0 +1,200 @@
+// nmf_device.h — device-side data structures and small math for the gfx950 stepping kernels.
+//
+// One wavefront (64 lanes) owns one fly for a whole launch: the fly's state and every
+// intermediate quantity live in LDS; model constants are read-only and shared by all flies
+// (L2 resident).  The per-step pipeline restates MuJoCo's documented mj_step for the model the
+// reference builds (see oracle/nmf_oracle.c for the stage list and the reference citations).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmf {
+
+constexpr int kWave = 64;
+constexpr int kMaxCon = 64;      // contacts per fly kept by the engine (overflow is flagged)
+constexpr int kMaxCtrl = 48;
+constexpr float kMinVal = 1e-15f;
+
+enum { GEOM_CAPSULE = 0, GEOM_HULL = 1 };
+enum { ACT_POSITION = 0, ACT_ADHESION = 1, ACT_MOTOR = 2 };
+
+// Star-of-chains topology: one free root body + NLEG serial chains of NBL bodies / NDL hinges.
+template <int NLEG_, int NBL_, int NDL_>
+struct Topo {
+  static constexpr int NLEG = NLEG_, NBL = NBL_, NDL = NDL_;
+  static constexpr int NB = 1 + NLEG_ * NBL_;
+  static constexpr int NV = 6 + NLEG_ * NDL_;
+  static constexpr int NQ = NV + 1;
+};
+
+struct DevModel {
+  int nb, nv, nq, nu, ng, nseg, nsite, nsensor, max_iter;
+  float timestep, tolerance, hull_skin, meaninertia;
+  float gravity[3];
+  float plane[4];
+  const float *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
+  const int *body_dofadr, *body_dofnum, *dof_body;
+  const float *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
+  const int* seg_body;
+  const float *seg_pos, *seg_quat;
+  const int* site_body;
+  const float* site_pos;
+  const int *act_type, *act_trn, *act_limited;
+  const float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
+  const float *key_qpos, *key_ctrl;
+  const int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
+  const float *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
+  const float *pair_friction, *pair_solref, *pair_solimp, *pair_margin;
+};
+
+struct DevState {
+  int n_worlds;
+  float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
+      *sensordata, *time, *stats, *qacc;
+};
+
+struct ReplayArgs {
+  const float* table;   // [n_worlds][table_steps][n_act] or nullptr
+  const int* act_ids;   // [n_act]
+  int table_steps, n_act, start;
+};
+
+// ---------------------------------------------------------------- small math
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 mat_vec(const float* m, V3 v) {
+  return V3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+            m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+__device__ __forceinline__ V3 matT_vec(const float* m, V3 v) {
+  return V3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+            m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
+
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ Q4 ldq(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void stq(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qnorm(Q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < kMinVal) return Q4{1.f, 0.f, 0.f, 0.f};
+  float s = 1.0f / n;
+  return Q4{q.w * s, q.x * s, q.y * s, q.z * s};
+}
+__device__ __forceinline__ V3 qrot_conj(Q4 q, V3 v) {  // rotate v by q^-1 (q unit)
+  V3 u = v3(-q.x, -q.y, -q.z);
+  V3 t = 2.0f * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+__device__ __forceinline__ void qmat(float* m, Q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+
+// spatial 6-vectors: motion (w; v) and force (n; f), world axes, about the root origin
+struct SV { V3 a, l; };  // angular part, linear part
+__device__ __forceinline__ SV ldsv(const float* p) { return SV{ld3(p), ld3(p + 3)}; }
+__device__ __forceinline__ void stsv(float* p, SV s) { st3(p, s.a); st3(p + 3, s.l); }
+__device__ __forceinline__ SV operator+(SV x, SV y) { return SV{x.a + y.a, x.l + y.l}; }
+__device__ __forceinline__ SV operator-(SV x, SV y) { return SV{x.a - y.a, x.l - y.l}; }
+__device__ __forceinline__ SV operator*(float s, SV x) { return SV{s * x.a, s * x.l}; }
+__device__ __forceinline__ float dot(SV x, SV y) { return dot(x.a, y.a) + dot(x.l, y.l); }
+__device__ __forceinline__ SV cross_motion(SV a, SV b) {
+  return SV{cross(a.a, b.a), cross(a.a, b.l) + cross(a.l, b.a)};
+}
+__device__ __forceinline__ SV cross_force(SV v, SV f) {
+  return SV{cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)};
+}
+// rigid-body spatial inertia about the reference point: m, h = m c, I sym6 (xx yy zz xy xz yz)
+__device__ __forceinline__ SV inert_mul(const float* I, SV v) {
+  V3 h = ld3(I + 1);
+  V3 Iw = v3(I[4] * v.a.x + I[7] * v.a.y + I[8] * v.a.z, I[7] * v.a.x + I[5] * v.a.y + I[9] * v.a.z,
+             I[8] * v.a.x + I[9] * v.a.y + I[6] * v.a.z);
+  return SV{Iw + cross(h, v.l), I[0] * v.l - cross(h, v.a)};
+}
+
+// symmetric 6x6 in 21 floats, upper triangle row-major
+__device__ __host__ constexpr int sym_idx(int i, int j) {
+  return i <= j ? i * 6 - i * (i - 1) / 2 + (j - i) : j * 6 - j * (j - 1) / 2 + (i - j);
+}
+struct Sym6 {
+  float v[21];
+  __device__ __forceinline__ float get(int i, int j) const { return v[sym_idx(i, j)]; }
+};
+__device__ __forceinline__ void sym6_zero(Sym6& A) {
+#pragma unroll
+  for (int i = 0; i < 21; i++) A.v[i] = 0.f;
+}
+__device__ __forceinline__ void sym6_mul(const Sym6& A, const float* s, float* out) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc += A.v[sym_idx(i, j)] * s[j];
+    out[i] = acc;
+  }
+}
+// A += c * l lᵀ
+__device__ __forceinline__ void sym6_rank1(Sym6& A, const float* l, float c) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float ci = c * l[i];
+#pragma unroll
+    for (int j = i; j < 6; j++) A.v[sym_idx(i, j)] += ci * l[j];
+  }
+}
+// A += c * (l mᵀ + m lᵀ)
+__device__ __forceinline__ void sym6_rank2(Sym6& A, const float* l, const float* m, float c) {
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) A.v[sym_idx(i, j)] += c * (l[i] * m[j] + m[i] * l[j]);
+}
+// A += rigid-body inertia (m, h, I) as a 6x6 in (w; v) ordering
+__device__ __forceinline__ void sym6_add_inertia(Sym6& A, const float* I) {
+  A.v[sym_idx(0, 0)] += I[4]; A.v[sym_idx(1, 1)] += I[5]; A.v[sym_idx(2, 2)] += I[6];
+  A.v[sym_idx(0, 1)] += I[7]; A.v[sym_idx(0, 2)] += I[8]; A.v[sym_idx(1, 2)] += I[9];
+  float hx = I[1], hy = I[2], hz = I[3];
+  // block(0:3, 3:6) = [h]x
+  A.v[sym_idx(0, 4)] += -hz; A.v[sym_idx(0, 5)] += hy;
+  A.v[sym_idx(1, 3)] += hz;  A.v[sym_idx(1, 5)] += -hx;
+  A.v[sym_idx(2, 3)] += -hy; A.v[sym_idx(2, 4)] += hx;
+  A.v[sym_idx(3, 3)] += I[0]; A.v[sym_idx(4, 4)] += I[0]; A.v[sym_idx(5, 5)] += I[0];
+}
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ void wave_argmin(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+}  // namespace nmf

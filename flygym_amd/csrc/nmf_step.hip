@@ -1,0 +1,885 @@
+// nmf_step.hip — the fused per-step physics kernel (gfx950, one wavefront per fly).
+//
+// Reference path replaced: mujoco_warp.step(m, d), the single call behind
+// flygym.warp.GPUSimulation.step (reference src/flygym/warp/simulation.py:260-263), which the
+// reference runs as ~100 Warp/CUDA kernel launches per step with constraint buffers in HBM
+// (njmax = nconmax = 500 per world, :54-55).  Here the whole step — and any number of
+// consecutive steps — is ONE launch; nothing but the fly's state (qpos, qvel, ctrl,
+// warm-start) crosses HBM.
+//
+// Algorithmic design (MI355X-first, not a translation of MuJoCo's data flow):
+//   * all spatial quantities are expressed in world axes about the root-body origin, so no
+//     per-link frame changes are needed along a leg;
+//   * no mass matrix and no constraint Jacobian are ever formed.  J·x is the velocity of the
+//     contact point under body twists, Jᵀf is a wrench pushed down the chain, and every linear
+//     solve (M⁻¹, (M + JᵀDJ)⁻¹ in the Newton solver, (M + hB)⁻¹ in the Euler step) is an O(n)
+//     articulated-body sweep whose 6x6 articulated inertias absorb the active contact rows
+//     (D·l lᵀ with l = [r x d; d]) — algebraically identical to factorising the nv x nv matrix
+//     (124 kFLOP dense) at ~7 kFLOP, all in registers/LDS;
+//   * the constraint problem, its Newton iterations and exact line search follow the oracle
+//     (oracle/nmf_oracle.c) step for step, so results agree to float rounding.
+#include "nmf_device.h"
+
+namespace nmf {
+
+#define WSYNC() __syncthreads()
+
+template <class TP>
+struct __align__(16) FlyLds {
+  float qpos[TP::NQ + 3];
+  float qvel[TP::NV], qacc_ws[TP::NV], qacc[TP::NV], qacc_smooth[TP::NV], qfrc_smooth[TP::NV],
+      qfrc_con[TP::NV];
+  float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
+  float aba_u[TP::NV], aba_invD[TP::NV], aba_U[TP::NV][6];
+  float ctrl[kMaxCtrl], act_force[kMaxCtrl];
+  float xpos[TP::NB][3], xquat[TP::NB][4], xmat[TP::NB][9];
+  float S[TP::NV][6];
+  float Ib[TP::NB][10];
+  float vel[TP::NB][6], T[TP::NB][6], W[TP::NB][6];
+  float legIA[TP::NLEG][21], legpA[TP::NLEG][6];
+  float c_r[kMaxCon][3], c_dist[kMaxCon], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];
+  int c_geom[kMaxCon], c_body[kMaxCon], c_act[kMaxCon];
+  int body_cstart[TP::NB + 1];
+  float sens[96];
+  int ncon, overflow, iters;
+};
+
+struct Frame { V3 n, t1, t2; };
+
+__device__ __forceinline__ Frame make_frame(V3 n) {
+  V3 t = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
+  float dn = dot(t, n);
+  V3 t1 = t - dn * n;
+  float l = sqrtf(dot(t1, t1));
+  t1 = (1.0f / l) * t1;
+  return Frame{n, t1, cross(n, t1)};
+}
+
+// ------------------------------------------------------------------ kinematics
+template <class TP>
+__device__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
+  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.aba_U[0][0]);
+  float(*relq)[4] = reinterpret_cast<float(*)[4]>(&s.W[0][0]);
+  float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.T[0][0]);
+  for (int j = 6 + lane; j < TP::NV; j += kWave) {
+    float sn, cs;
+    sincosf(0.5f * s.qpos[j + 1], &sn, &cs);
+    jq[j][0] = cs; jq[j][1] = m.dof_axis[3 * j] * sn; jq[j][2] = m.dof_axis[3 * j + 1] * sn;
+    jq[j][3] = m.dof_axis[3 * j + 2] * sn;
+  }
+  if (lane == 0) {
+    Q4 q = qnorm(ldq(&s.qpos[3]));
+    st3(s.xpos[0], ld3(&s.qpos[0]));
+    stq(s.xquat[0], q);
+    qmat(s.xmat[0], q);
+  }
+  WSYNC();
+  for (int b = 1 + lane; b < TP::NB; b += kWave) {
+    int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
+    for (int j = adr + num - 1; j >= adr; --j) {
+      st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
+      P = qmul(ldq(jq[j]), P);
+    }
+    stq(relq[b], qmul(ldq(&m.body_quat[4 * b]), P));
+  }
+  WSYNC();
+  if (lane < TP::NLEG) {
+    for (int l = 0; l < TP::NBL; ++l) {
+      int b = 1 + lane * TP::NBL + l, p = l == 0 ? 0 : b - 1;
+      V3 off = mat_vec(s.xmat[p], ld3(&m.body_pos[3 * b]));
+      st3(s.xpos[b], ld3(s.xpos[p]) + off);
+      Q4 q = qnorm(qmul(ldq(s.xquat[p]), ldq(relq[b])));
+      stq(s.xquat[b], q);
+      qmat(s.xmat[b], q);
+    }
+  }
+  WSYNC();
+  for (int j = lane; j < TP::NV; j += kWave) {
+    SV S;
+    if (j < 3) {
+      S.a = v3(0.f, 0.f, 0.f);
+      S.l = v3(j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f);
+    } else if (j < 6) {
+      int c = j - 3;
+      S.a = v3(s.xmat[0][c], s.xmat[0][3 + c], s.xmat[0][6 + c]);
+      S.l = v3(0.f, 0.f, 0.f);
+    } else {
+      int b = m.dof_body[j];
+      V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
+      V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
+      S.a = a;
+      S.l = cross(a, r);
+    }
+    stsv(s.S[j], S);
+  }
+  WSYNC();
+}
+
+template <class TP>
+__device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
+  for (int b = lane; b < TP::NB; b += kWave) {
+    const float* R = s.xmat[b];
+    const float* q = &m.body_inertia[6 * b];
+    float Il[9] = {q[0], q[3], q[4], q[3], q[1], q[5], q[4], q[5], q[2]};
+    float Tm[9], Iw[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * Il[j] + R[3 * i + 1] * Il[3 + j] + R[3 * i + 2] * Il[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Iw[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
+    V3 c = mat_vec(R, ld3(&m.body_ipos[3 * b])) + (ld3(s.xpos[b]) - ld3(s.xpos[0]));
+    float ms = m.body_mass[b], cc = dot(c, c);
+    float* I = s.Ib[b];
+    I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
+    I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
+    I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
+  }
+  WSYNC();
+}
+
+// ------------------------------------------------------------------ collision (geom vs ground plane)
+template <class TP>
+__device__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
+  const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
+  const float pd = m.plane[3];
+  const V3 o = ld3(s.xpos[0]);
+  bool near = false;
+  if (lane < m.ng) {
+    int b = m.geom_body[lane];
+    V3 cw = mat_vec(s.xmat[b], ld3(&m.geom_bsphere[4 * lane]));
+    float dc = dot(n, cw) + dot(n, ld3(s.xpos[b])) - pd;
+    near = dc - m.geom_bsphere[4 * lane + 3] <= m.pair_margin[lane];
+  }
+  unsigned long long mask = __ballot(near);
+  int ncon = 0, overflow = 0;
+  while (mask) {
+    int g = __ffsll((long long)mask) - 1;
+    mask &= mask - 1;
+    int b = m.geom_body[g];
+    const float* R = s.xmat[b];
+    V3 xp = ld3(s.xpos[b]);
+    float margin = m.pair_margin[g];
+    if (m.geom_type[g] == GEOM_CAPSULE) {
+      bool valid = false; float dist = 0.f; V3 ps = v3(0, 0, 0);
+      if (lane < 2) {
+        const float* pl = (lane == 0 ? m.geom_p0 : m.geom_p1) + 3 * g;
+        V3 pw = mat_vec(R, ld3(pl)) + xp;
+        float r = m.geom_radius[g];
+        dist = dot(n, pw) - pd - r;
+        valid = dist <= margin;
+        ps = pw - r * n;
+      }
+      unsigned long long vm = __ballot(valid);
+      int slot = ncon + __popcll(vm & ((1ull << lane) - 1ull));
+      if (valid) {
+        if (slot < kMaxCon) {
+          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_dist[slot] = dist;
+          st3(s.c_r[slot], (ps - (0.5f * dist) * n) - o);
+        } else overflow = 1;
+      }
+      ncon += __popcll(vm);
+    } else {
+      V3 nb = matT_vec(R, n);
+      float c0 = dot(n, xp) - pd;
+      const float* V = m.hull_vert + 3 * m.geom_hulladr[g];
+      int nvv = m.geom_hullnum[g];
+      float best = INFINITY; int bi = 0x7fffffff;
+      for (int i = lane; i < nvv; i += kWave) {
+        float di = dot(nb, ld3(V + 3 * i)) + c0;
+        if (di < best) { best = di; bi = i; }
+      }
+      wave_argmin(best, bi);
+      float dmin = best; int ia = bi;
+      if (!(dmin <= margin)) continue;
+      float thr = fminf(dmin + m.hull_skin, margin);
+      int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
+      V3 va = ld3(V + 3 * ia);
+      // b: farthest candidate from a
+      best = -INFINITY; bi = 0x7fffffff;
+      for (int i = lane; i < nvv; i += kWave) {
+        V3 vi = ld3(V + 3 * i);
+        float di = dot(nb, vi) + c0;
+        if (di > thr) continue;
+        V3 e = vi - va; float sc = dot(e, e);
+        if (sc > best) { best = sc; bi = i; }
+      }
+      wave_argmax(best, bi);
+      if (best > 1e-10f) {
+        s1 = bi; nsel = 2;
+        V3 ab = ld3(V + 3 * bi) - va;
+        float lab2 = dot(ab, ab);
+        best = -INFINITY; bi = 0x7fffffff; float side = 0.f;
+        for (int i = lane; i < nvv; i += kWave) {
+          V3 vi = ld3(V + 3 * i);
+          float di = dot(nb, vi) + c0;
+          if (di > thr) continue;
+          V3 cr = cross(vi - va, ab); float sc = dot(cr, cr);
+          if (sc > best) { best = sc; bi = i; }
+        }
+        wave_argmax(best, bi);
+        if (best > 1e-10f * lab2) {
+          s2 = bi; nsel = 3;
+          side = dot(cross(ld3(V + 3 * bi) - va, ab), nb);
+          float sg = side > 0.f ? -1.f : 1.f;
+          best = -INFINITY; bi = 0x7fffffff;
+          for (int i = lane; i < nvv; i += kWave) {
+            V3 vi = ld3(V + 3 * i);
+            float di = dot(nb, vi) + c0;
+            if (di > thr) continue;
+            float sc = sg * dot(cross(vi - va, ab), nb);
+            if (sc > best) { best = sc; bi = i; }
+          }
+          wave_argmax(best, bi);
+          if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
+        }
+      }
+      if (lane < nsel) {
+        int slot = ncon + lane;
+        int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
+        if (slot < kMaxCon) {
+          V3 v = ld3(V + 3 * vi);
+          float dist = dot(nb, v) + c0;
+          V3 pw = mat_vec(R, v) + xp;
+          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_dist[slot] = dist;
+          st3(s.c_r[slot], (pw - (0.5f * dist) * n) - o);
+        } else overflow = 1;
+      }
+      ncon += nsel;
+    }
+  }
+  overflow = __any(overflow) ? 1 : 0;
+  if (ncon > kMaxCon) { ncon = kMaxCon; overflow = 1; }
+  if (lane == 0) { s.ncon = ncon; s.overflow = overflow; }
+  WSYNC();
+  for (int b = lane; b <= TP::NB; b += kWave) {
+    int cnt = 0;
+    for (int c = 0; c < ncon; ++c) cnt += s.c_body[c] < b ? 1 : 0;
+    s.body_cstart[b] = cnt;
+  }
+  WSYNC();
+}
+
+// ------------------------------------------------------------------ chain sweeps
+// T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
+template <class TP>
+__device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+  if (lane < TP::NLEG) {
+    SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t = t + x[j] * ldsv(s.S[j]);
+    if (lane == 0) stsv(T[0], t);
+    for (int l = 0; l < TP::NBL; ++l) {
+      int b = 1 + lane * TP::NBL + l;
+      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      for (int j = adr; j < adr + num; ++j) t = t + x[j] * ldsv(s.S[j]);
+      stsv(T[b], t);
+    }
+  }
+  WSYNC();
+}
+
+// W[b] <- sum of W over the subtree of b (in place), then out[j] = S_j · W[body(j)]
+template <class TP>
+__device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const DevModel& m, int lane) {
+  if (lane < TP::NLEG) {
+    SV acc = SV{v3(0, 0, 0), v3(0, 0, 0)};
+    for (int l = TP::NBL - 1; l >= 0; --l) {
+      int b = 1 + lane * TP::NBL + l;
+      acc = acc + ldsv(W[b]);
+      stsv(W[b], acc);
+    }
+  }
+  WSYNC();
+  if (lane < 6) {
+    float acc = W[0][lane];
+#pragma unroll
+    for (int k = 0; k < TP::NLEG; ++k) acc += W[1 + k * TP::NBL][lane];
+    W[0][lane] = acc;
+  }
+  WSYNC();
+  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]]));
+  WSYNC();
+}
+
+// y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x)
+template <class TP>
+__device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m, int lane) {
+  sweep_twists(s, x, s.T, m, lane);
+  for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
+  WSYNC();
+  sweep_project(s, s.W, y, m, lane);
+  for (int j = lane; j < TP::NV; j += kWave) y[j] += m.dof_armature[j] * x[j];
+  WSYNC();
+}
+
+// contact row directions l = [r x d; d]
+__device__ __forceinline__ void contact_l(V3 r, V3 d, float* l) {
+  V3 c = cross(r, d);
+  l[0] = c.x; l[1] = c.y; l[2] = c.z; l[3] = d.x; l[4] = d.y; l[5] = d.z;
+}
+
+template <class TP>
+__device__ __forceinline__ void add_contact_K(Sym6& IA, const FlyLds<TP>& s, int c, const Frame& fr) {
+  int act = s.c_act[c];
+  if (!act) return;
+  V3 r = ld3(s.c_r[c]);
+  float D = s.c_D[c], mu = s.c_mu[c];
+  float ln[6], l1[6], l2[6];
+  contact_l(r, fr.n, ln); contact_l(r, fr.t1, l1); contact_l(r, fr.t2, l2);
+  float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+  sym6_rank1(IA, ln, D * (a0 + a1 + a2 + a3));
+  if (a0 + a1 > 0.f) { sym6_rank1(IA, l1, D * mu * mu * (a0 + a1)); }
+  if (a0 != a1) sym6_rank2(IA, ln, l1, D * mu * (a0 - a1));
+  if (a2 + a3 > 0.f) { sym6_rank1(IA, l2, D * mu * mu * (a2 + a3)); }
+  if (a2 != a3) sym6_rank2(IA, ln, l2, D * mu * (a2 - a3));
+}
+
+// Articulated-body solve of (CRBA(I_b [+ K_b]) + diag(delta)) x = tau.
+// delta_j = armature_j + hdamp * damping_j.  Leaves T = twists(x).
+template <class TP>
+__device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK, float hdamp,
+                          const Frame& fr, const DevModel& m, int lane) {
+  if (lane < TP::NLEG) {
+    Sym6 IA; sym6_zero(IA);
+    float pA[6] = {0, 0, 0, 0, 0, 0};
+    for (int l = TP::NBL - 1; l >= 0; --l) {
+      int b = 1 + lane * TP::NBL + l;
+      sym6_add_inertia(IA, s.Ib[b]);
+      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K(IA, s, c, fr);
+      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      for (int j = adr + num - 1; j >= adr; --j) {
+        float sj[6], U[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
+        sym6_mul(IA, sj, U);
+        float D = m.dof_armature[j] + hdamp * m.dof_damping[j], sp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
+        float invD = 1.0f / D, u = tau[j] - sp;
+        s.aba_u[j] = u; s.aba_invD[j] = invD;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s.aba_U[j][i] = U[i];
+        sym6_rank1(IA, U, -invD);
+        float k = u * invD;
+#pragma unroll
+        for (int i = 0; i < 6; i++) pA[i] += U[i] * k;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 21; i++) s.legIA[lane][i] = IA.v[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s.legpA[lane][i] = pA[i];
+  }
+  WSYNC();
+  if (lane == 0) {
+    Sym6 IA; sym6_zero(IA);
+    float pA[6] = {0, 0, 0, 0, 0, 0};
+    sym6_add_inertia(IA, s.Ib[0]);
+    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K(IA, s, c, fr);
+    for (int k = 0; k < TP::NLEG; ++k) {
+#pragma unroll
+      for (int i = 0; i < 21; i++) IA.v[i] += s.legIA[k][i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) pA[i] += s.legpA[k][i];
+    }
+    // 6x6 system in root coordinates: A = Srᵀ IA Sr, rhs = tau_r − Srᵀ pA
+    float A[6][6], rhs[6], F[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      float si[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) si[k] = s.S[i][k];
+      sym6_mul(IA, si, F[i]);
+      float sp = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) sp += si[k] * pA[k];
+      rhs[i] = tau[i] - sp;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc += s.S[j][k] * F[i][k];
+        A[i][j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < 6; i++) A[i][i] += m.dof_armature[i] + hdamp * m.dof_damping[i];
+    // Cholesky A = L Lᵀ (lower, in place), then two triangular solves
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      float d = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+      d = sqrtf(d);
+      A[j][j] = d;
+      float inv = 1.0f / d;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        float v = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= A[i][k] * A[j][k];
+        A[i][j] = v * inv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      float v = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) v -= A[i][k] * rhs[k];
+      rhs[i] = v / A[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      float v = rhs[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) v -= A[k][i] * rhs[k];
+      rhs[i] = v / A[i][i];
+    }
+    SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
+#pragma unroll
+    for (int i = 0; i < 6; i++) { x[i] = rhs[i]; t = t + rhs[i] * ldsv(s.S[i]); }
+    stsv(s.T[0], t);
+  }
+  WSYNC();
+  if (lane < TP::NLEG) {
+    SV a = ldsv(s.T[0]);
+    for (int l = 0; l < TP::NBL; ++l) {
+      int b = 1 + lane * TP::NBL + l;
+      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      for (int j = adr; j < adr + num; ++j) {
+        float xj = (s.aba_u[j] - dot(ldsv(s.aba_U[j]), a)) * s.aba_invD[j];
+        x[j] = xj;
+        a = a + xj * ldsv(s.S[j]);
+      }
+      stsv(s.T[b], a);
+    }
+  }
+  WSYNC();
+}
+
+// ------------------------------------------------------------------ contact rows held in registers
+struct ContactRegs {
+  bool on;
+  V3 r;
+  int body, geom;
+  float dist, mu, D, K, B, imp, margin;
+  float aref[4], jar[4], jv[4];
+};
+
+__device__ __forceinline__ float impedance(const float* si, float r) {
+  float d0 = si[0], dmax = si[1], width = si[2], mid = si[3], power = si[4];
+  if (d0 == dmax || width <= kMinVal) return 0.5f * (d0 + dmax);
+  float x = fabsf(r) / width, y;
+  if (x >= 1.f) y = 1.f;
+  else if (x <= 0.f) y = 0.f;
+  else if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return d0 + y * (dmax - d0);
+}
+
+// rows k = 0..3 :  n + mu t1, n − mu t1, n + mu t2, n − mu t2   applied to the body twist at r
+__device__ __forceinline__ void rows_of_twist(const ContactRegs& c, const Frame& fr, SV t, float* out) {
+  V3 vp = t.l + cross(t.a, c.r);
+  float jn = dot(fr.n, vp), j1 = c.mu * dot(fr.t1, vp), j2 = c.mu * dot(fr.t2, vp);
+  out[0] = jn + j1; out[1] = jn - j1; out[2] = jn + j2; out[3] = jn - j2;
+}
+
+template <class TP>
+__device__ float constraint_cost(const ContactRegs& c) {
+  float v = 0.f;
+  if (c.on) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) v += 0.5f * c.D * c.jar[k] * c.jar[k];
+  }
+  return wave_sum(v);
+}
+
+// W[b] = − Σ_{contacts c on b} Σ_k f_k l_k   (deterministic order), f_k = −D jar_k on active rows
+template <class TP>
+__device__ void contact_wrenches(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign, int lane) {
+  if (c.on) {
+    float f[4]; int act = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { f[k] = c.jar[k] < 0.f ? -c.D * c.jar[k] : 0.f; act |= (c.jar[k] < 0.f ? 1 : 0) << k; }
+    float fn = f[0] + f[1] + f[2] + f[3], f1 = c.mu * (f[0] - f[1]), f2 = c.mu * (f[2] - f[3]);
+    V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
+    SV w = SV{cross(c.r, F), F};
+    stsv(s.c_w[lane], sign * w);
+    s.c_act[lane] = act;
+  }
+  for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], SV{v3(0, 0, 0), v3(0, 0, 0)});
+  WSYNC();
+  if (lane < 6) {
+    int ncon = s.ncon;
+    for (int cc = 0; cc < ncon; ++cc) s.W[s.c_body[cc]][lane] += s.c_w[cc][lane];
+  }
+  WSYNC();
+}
+
+// ------------------------------------------------------------------ the step
+template <class TP>
+__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
+  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  stage_kinematics(s, m, lane);
+  stage_inertia(s, m, lane);
+  stage_collision(s, m, lane);
+  const int ncon = s.ncon;
+
+  // ---- contact parameters (lane c owns contact c)
+  ContactRegs c;
+  c.on = lane < ncon;
+  if (c.on) {
+    c.r = ld3(s.c_r[lane]); c.body = s.c_body[lane]; c.geom = s.c_geom[lane]; c.dist = s.c_dist[lane];
+    int g = c.geom;
+    c.mu = m.pair_friction[5 * g];
+    c.margin = m.pair_margin[g];
+    const float* solref = &m.pair_solref[2 * g];
+    const float* solimp = &m.pair_solimp[5 * g];
+    float r = c.dist - c.margin;
+    c.imp = impedance(solimp, r);
+    float tran = m.geom_invweight0[g];
+    float diagA = tran + c.mu * c.mu * tran;
+    float Rn = fmaxf((1.f - c.imp) * diagA / c.imp, kMinVal);
+    float Rpy = fmaxf(2.f * c.mu * c.mu * Rn, kMinVal);
+    c.D = 1.0f / Rpy;
+    float tc = solref[0], dr = solref[1];
+    if (tc > 0.f) {
+      tc = fmaxf(tc, 2.f * m.timestep);
+      float dmax = solimp[1];
+      c.K = 1.0f / (dmax * dmax * tc * tc * dr * dr);
+      c.B = 2.0f / (dmax * tc);
+    } else { c.K = -tc / (solimp[1] * solimp[1]); c.B = -dr / solimp[1]; }
+    s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_act[lane] = 0;
+  }
+
+  // ---- velocities and bias wrenches (serial per leg), W[b] = −(I a_bias + v x* I v)
+  if (lane < TP::NLEG) {
+    SV v = SV{v3(0, 0, 0), v3(0, 0, 0)};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v = v + s.qvel[j] * ldsv(s.S[j]);
+    SV vt = v;
+    SV a = SV{v3(0, 0, 0), v3(-m.gravity[0], -m.gravity[1], -m.gravity[2])};
+#pragma unroll
+    for (int j = 3; j < 6; ++j) {
+      SV Sj = ldsv(s.S[j]);
+      a = a + s.qvel[j] * cross_motion(vt, Sj);
+      v = v + s.qvel[j] * Sj;
+    }
+    if (lane == 0) { stsv(s.vel[0], v); stsv(s.T[0], a); }
+    for (int l = 0; l < TP::NBL; ++l) {
+      int b = 1 + lane * TP::NBL + l;
+      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      for (int j = adr; j < adr + num; ++j) {
+        SV Sj = ldsv(s.S[j]);
+        float qd = s.qvel[j];
+        a = a + qd * cross_motion(v, Sj);
+        v = v + qd * Sj;
+      }
+      stsv(s.vel[b], v); stsv(s.T[b], a);
+    }
+  }
+  WSYNC();
+  for (int b = lane; b < TP::NB; b += kWave) {
+    SV v = ldsv(s.vel[b]);
+    SV f = inert_mul(s.Ib[b], ldsv(s.T[b])) + cross_force(v, inert_mul(s.Ib[b], v));
+    stsv(s.W[b], -1.0f * f);
+  }
+  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = 0.f;  // direct actuator forces
+  WSYNC();
+  // ---- actuation
+  for (int u = lane; u < m.nu; u += kWave) {
+    float ctrl = s.ctrl[u];
+    if (m.act_limited[2 * u + 1]) ctrl = fminf(fmaxf(ctrl, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
+    float f;
+    if (m.act_type[u] == ACT_ADHESION) {
+      f = m.act_gain[u] * ctrl;
+      int body = m.act_trn[u];
+      int c0 = s.body_cstart[body], c1 = s.body_cstart[body + 1];
+      if (c1 > c0) {
+        float k = -f / (float)(c1 - c0);
+        SV acc = ldsv(s.W[body]);
+        for (int cc = c0; cc < c1; ++cc) {
+          V3 r = ld3(s.c_r[cc]);
+          acc = acc + k * SV{cross(r, fr.n), fr.n};
+        }
+        stsv(s.W[body], acc);
+      }
+    } else {
+      int j = m.act_trn[u];
+      f = m.act_gain[u] * ctrl + m.act_bias[2 * u] * s.qpos[j + 1] + m.act_bias[2 * u + 1] * s.qvel[j];
+      if (m.act_limited[2 * u]) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
+      s.vA[j] += f;
+    }
+    s.act_force[u] = f;
+  }
+  WSYNC();
+  sweep_project(s, s.W, s.qfrc_smooth, m, lane);
+  for (int j = lane; j < TP::NV; j += kWave) {
+    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - m.dof_damping[j] * s.qvel[j];
+    s.qfrc_smooth[j] += passive + s.vA[j];
+  }
+  WSYNC();
+  // ---- unconstrained acceleration
+  aba_solve(s, s.qfrc_smooth, s.qacc_smooth, false, 0.f, fr, m, lane);
+
+  // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
+  int iters = 0;
+  if (ncon == 0) {
+    for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.qfrc_con[j] = 0.f; }
+    WSYNC();
+  } else {
+    float* Ma = s.vC; float* grad = s.vA; float* search = s.vB; float* Mv = s.vD;
+    // reference acceleration from the velocity twists
+    if (c.on) {
+      float vel[4];
+      rows_of_twist(c, fr, ldsv(s.vel[c.body]), vel);
+      float r = c.dist - c.margin;
+#pragma unroll
+      for (int k = 0; k < 4; k++) c.aref[k] = -c.B * vel[k] - c.K * c.imp * r;
+    }
+    // candidate 1: warm start
+    mul_M(s, s.qacc_ws, Ma, m, lane);
+    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
+#pragma unroll
+      for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
+    float g = 0.f;
+    for (int j = lane; j < TP::NV; j += kWave) g += 0.5f * (s.qacc_ws[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
+    float cost = wave_sum(g) + constraint_cost<TP>(c);
+    // candidate 2: unconstrained acceleration
+    sweep_twists(s, s.qacc_smooth, s.T, m, lane);
+    ContactRegs c2 = c;
+    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c2.jar);
+#pragma unroll
+      for (int k = 0; k < 4; k++) c2.jar[k] -= c.aref[k]; }
+    float cost_sm = constraint_cost<TP>(c2);
+    if (cost_sm < cost) {
+      cost = cost_sm;
+#pragma unroll
+      for (int k = 0; k < 4; k++) c.jar[k] = c2.jar[k];
+      for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Ma[j] = s.qfrc_smooth[j]; }
+    } else {
+      for (int j = lane; j < TP::NV; j += kWave) s.qacc[j] = s.qacc_ws[j];
+    }
+    WSYNC();
+    const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
+    for (int iter = 0; iter < m.max_iter; ++iter) {
+      // gradient = Ma − qfrc_smooth − Jᵀ f
+      contact_wrenches(s, c, fr, -1.0f, lane);
+      sweep_project(s, s.W, grad, m, lane);
+      float gn = 0.f;
+      for (int j = lane; j < TP::NV; j += kWave) {
+        float gj = grad[j] + Ma[j] - s.qfrc_smooth[j];
+        grad[j] = -gj;   // store the right-hand side of the Newton system
+        gn += gj * gj;
+      }
+      gn = wave_sum(gn);
+      WSYNC();
+      if (scale * sqrtf(gn) < m.tolerance) break;
+      aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
+      if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
+      mul_M(s, search, Mv, m, lane);
+      float g1 = 0.f, g2 = 0.f;
+      for (int j = lane; j < TP::NV; j += kWave) { g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * Mv[j]; }
+      g1 = wave_sum(g1); g2 = wave_sum(g2);
+      // exact line search
+      float alpha = 0.f, lo = 0.f, hi = -1.f;
+      for (int ls = 0; ls < 30; ++ls) {
+        float d1 = 0.f, d2 = 0.f;
+        if (c.on) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float x = c.jar[k] + alpha * c.jv[k];
+            if (x < 0.f) { d1 += c.D * x * c.jv[k]; d2 += c.D * c.jv[k] * c.jv[k]; }
+          }
+        }
+        d1 = wave_sum(d1) + g1 + alpha * g2;
+        d2 = wave_sum(d2) + g2;
+        if (d2 <= 0.f || d1 == 0.f) break;
+        if (d1 < 0.f) lo = alpha; else hi = alpha;
+        float next = alpha - d1 / d2;
+        if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
+        float change = fabsf(next - alpha);
+        alpha = next;
+        if (change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
+      }
+      if (alpha <= 0.f) break;
+      for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] += alpha * search[j]; Ma[j] += alpha * Mv[j]; }
+      if (c.on) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) c.jar[k] += alpha * c.jv[k];
+      }
+      WSYNC();
+      float gq = 0.f;
+      for (int j = lane; j < TP::NV; j += kWave) gq += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
+      float newcost = wave_sum(gq) + constraint_cost<TP>(c);
+      iters = iter + 1;
+      float improvement = cost - newcost;
+      cost = newcost;
+      if (scale * improvement < m.tolerance) break;
+    }
+    // constraint forces
+    contact_wrenches(s, c, fr, 1.0f, lane);
+    sweep_project(s, s.W, s.qfrc_con, m, lane);
+  }
+  if (lane == 0) s.iters = iters;
+
+  // ---- contact sensors (oracle contact_sensors): c_w holds the world-frame contact wrenches about o
+  for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
+  WSYNC();
+  if (m.nsensor && lane < 6 && ncon > 0) {
+    float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
+    for (int cc = 0; cc < ncon; ++cc) {
+      if (m.geom_sensor[s.c_geom[cc]] != lane) continue;
+      V3 f = ld3(&s.c_w[cc][3]);
+      float fn = dot(f, fr.n);
+      V3 p = ld3(s.c_r[cc]);
+      wsum += fn; pc = pc + fn * p; pm = pm + p; cnt++;
+    }
+    if (cnt) {
+      pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
+      for (int cc = 0; cc < ncon; ++cc) {
+        if (m.geom_sensor[s.c_geom[cc]] != lane) continue;
+        V3 f = ld3(&s.c_w[cc][3]);
+        F = F + f;
+        Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
+      }
+      float* out = &s.sens[16 * lane];
+      V3 o = ld3(s.xpos[0]);
+      out[0] = (float)cnt; st3(out + 1, F); st3(out + 4, Tq); st3(out + 7, pc + o); st3(out + 10, fr.n); st3(out + 13, fr.t1);
+    }
+  }
+  WSYNC();
+}
+
+template <class TP>
+__device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane) {
+  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  const float h = m.timestep;
+  for (int j = lane; j < TP::NV; j += kWave) { s.qacc_ws[j] = s.qacc[j]; s.vA[j] = s.qfrc_smooth[j] + s.qfrc_con[j]; }
+  WSYNC();
+  aba_solve(s, s.vA, s.vB, false, h, fr, m, lane);
+  for (int j = lane; j < TP::NV; j += kWave) s.qvel[j] += h * s.vB[j];
+  WSYNC();
+  if (lane == 0) {
+    for (int k = 0; k < 3; k++) s.qpos[k] += h * s.qvel[k];
+    V3 w = ld3(&s.qvel[3]);
+    float wn = sqrtf(dot(w, w));
+    Q4 q = ldq(&s.qpos[3]);
+    if (wn > kMinVal) {
+      float sn, cs;
+      sincosf(0.5f * h * wn, &sn, &cs);
+      V3 ax = (sn / wn) * w;
+      q = qmul(q, Q4{cs, ax.x, ax.y, ax.z});
+    }
+    stq(&s.qpos[3], qnorm(q));
+  }
+  for (int j = 6 + lane; j < TP::NV; j += kWave) s.qpos[j + 1] += h * s.qvel[j];
+  WSYNC();
+}
+
+template <class TP>
+__device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time) {
+  for (int i = lane; i < TP::NQ; i += kWave) st.qpos[(size_t)w * TP::NQ + i] = s.qpos[i];
+  for (int i = lane; i < TP::NV; i += kWave) {
+    st.qvel[(size_t)w * TP::NV + i] = s.qvel[i];
+    st.qacc_ws[(size_t)w * TP::NV + i] = s.qacc_ws[i];
+    st.qacc[(size_t)w * TP::NV + i] = s.qacc[i];
+  }
+  for (int i = lane; i < m.nu; i += kWave) {
+    st.ctrl[(size_t)w * m.nu + i] = s.ctrl[i];
+    st.actuator_force[(size_t)w * m.nu + i] = s.act_force[i];
+  }
+  for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = s.sens[i];
+  for (int sg = lane; sg < m.nseg; sg += kWave) {
+    int b = m.seg_body[sg];
+    V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.seg_pos[3 * sg]));
+    Q4 q = qnorm(qmul(ldq(s.xquat[b]), ldq(&m.seg_quat[4 * sg])));
+    st3(&st.seg_xpos[((size_t)w * m.nseg + sg) * 3], p);
+    stq(&st.seg_xquat[((size_t)w * m.nseg + sg) * 4], q);
+  }
+  for (int sg = lane; sg < m.nsite; sg += kWave) {
+    int b = m.site_body[sg];
+    V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.site_pos[3 * sg]));
+    st3(&st.site_xpos[((size_t)w * m.nsite + sg) * 3], p);
+  }
+  if (lane == 0) {
+    st.time[w] = time;
+    st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
+    st.stats[4 * w + 3] = (float)(4 * s.ncon);
+  }
+}
+
+// mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
+template <class TP>
+__global__ void __launch_bounds__(kWave) nmf_step_kernel(DevModel m, DevState st, ReplayArgs rp, int n_steps, int mode) {
+  __shared__ FlyLds<TP> s;
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if (w >= st.n_worlds) return;
+  float time;
+  if (mode == 1) {
+    for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = m.key_qpos[i];
+    for (int i = lane; i < TP::NV; i += kWave) { s.qvel[i] = 0.f; s.qacc_ws[i] = 0.f; s.qacc[i] = 0.f; }
+    for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; s.act_force[i] = 0.f; }
+    for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
+    if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
+    time = 0.f;
+    WSYNC();
+    stage_kinematics(s, m, lane);
+  } else {
+    for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = st.qpos[(size_t)w * TP::NQ + i];
+    for (int i = lane; i < TP::NV; i += kWave) {
+      s.qvel[i] = st.qvel[(size_t)w * TP::NV + i];
+      s.qacc_ws[i] = st.qacc_ws[(size_t)w * TP::NV + i];
+    }
+    for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = st.ctrl[(size_t)w * m.nu + i];
+    time = st.time[w];
+    WSYNC();
+    for (int step = 0; step < n_steps; ++step) {
+      if (rp.table) {
+        int row = (rp.start + step) % rp.table_steps;
+        const float* src = rp.table + ((size_t)w * rp.table_steps + row) * rp.n_act;
+        for (int a = lane; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
+        WSYNC();
+      }
+      physics_forward(s, m, lane);
+      physics_integrate(s, m, lane);
+      time += m.timestep;
+    }
+  }
+  write_outputs(s, m, st, w, lane, time);
+}
+
+// Indexed gather / scatter in caller order (replaces the reference's Warp kernels,
+// src/flygym/warp/utils.py:29-127).
+__global__ void nmf_gather_kernel(const float* __restrict__ src, int width, const int* __restrict__ ids,
+                                  int n_ids, int group, float* __restrict__ dst, int n_worlds) {
+  int per = n_ids * group;
+  size_t total = (size_t)n_worlds * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int w = (int)(i / per), k = (int)(i % per);
+    dst[i] = src[(size_t)w * width + (size_t)ids[k / group] * group + (k % group)];
+  }
+}
+__global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const int* __restrict__ ids, int n_ids,
+                                   const float* __restrict__ src, int n_worlds) {
+  size_t total = (size_t)n_worlds * n_ids;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int w = (int)(i / n_ids), k = (int)(i % n_ids);
+    dstf[(size_t)w * width + ids[k]] = src[i];
+  }
+}
+
+using FlyTopo = Topo<6, 8, 11>;      // LEGS_ONLY skeleton: 49 bodies, 72 dofs
+using FlyTopoActive = Topo<6, 4, 7>; // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
+
+template __global__ void nmf_step_kernel<FlyTopo>(DevModel, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoActive>(DevModel, DevState, ReplayArgs, int, int);
+
+}  // namespace nmf

@@ -1,0 +1,278 @@
+"""``HIPSimulation`` — the batched MI355X simulation, drop-in for the reference's
+``flygym.warp.GPUSimulation`` (reference ``src/flygym/warp/simulation.py:28-453``; method
+contracts from ``src/flygym/simulation.py:16-480``).
+
+Same method names, argument orders, batch-leading shapes and fly-ordered columns.  State queries
+return ``torch`` tensors on the GPU (the reference returns ``wp.array``); control inputs accept
+numpy arrays or torch tensors.  All physics runs in ``libnmf_hip.so`` (hand-written HIP for
+gfx950); there is no CPU path here.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import warnings
+from time import perf_counter_ns
+
+import numpy as np
+
+from . import _native
+from .compose.fly import ActuatorType
+from .compose.world import BaseWorld
+
+__all__ = ["HIPSimulation"]
+
+
+class HIPSimulation:
+    """Runs ``n_worlds`` copies of one world in lock-step on one MI355X.
+
+    Args:
+        world: a configured :class:`~flygym_amd.compose.BaseWorld` with one fly.
+        n_worlds: number of parallel worlds on this GPU.
+        max_constraints, max_contacts: accepted for signature compatibility with
+            ``GPUSimulation`` (``warp/simulation.py:50-56``).  The engine keeps up to 64 contacts
+            (256 constraint rows) per world in registers/LDS; overflow is reported through
+            :meth:`get_solver_stats` instead of being silently dropped.
+        device: CUDA/HIP device index (one process per GPU for multi-GPU runs).
+    """
+
+    def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
+                 max_contacts: int = 500, device: int | None = None) -> None:
+        import torch
+
+        if len(world.fly_lookup) == 0:
+            raise ValueError("The world must contain at least one fly.")
+        self._strip_unsupported_options(world)
+        self.world = world
+        self.n_worlds = int(n_worlds)
+        self.max_constraints = max_constraints
+        self.max_contacts = max_contacts
+        self.renderer = None
+        if not torch.cuda.is_available():
+            raise _native.NativeError("HIPSimulation needs a visible MI355X (torch.cuda.is_available() is False)")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._torch = torch
+        self._lib = _native.lib()
+
+        self.model = world.compile()
+        blob = self.model.to_blob()
+        self._model_h = self._lib.nmf_model_create(blob, len(blob))
+        if not self._model_h:
+            raise _native.NativeError(self._lib.nmf_last_error().decode())
+        with torch.cuda.device(self.device):
+            self._batch_h = self._lib.nmf_batch_create(self._model_h, self.n_worlds, self.device_index)
+        if not self._batch_h:
+            raise _native.NativeError(self._lib.nmf_last_error().decode())
+        self._views = {}
+        self._build_index_maps()
+        self._curr_step = 0
+        self._frames_rendered = 0
+        self._total_physics_time_ns = 0
+        self._total_render_time_ns = 0
+
+    # ---- lifecycle -----------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_batch_h", None):
+                self._lib.nmf_batch_destroy(self._batch_h)
+                self._batch_h = None
+            if getattr(self, "_model_h", None):
+                self._lib.nmf_model_destroy(self._model_h)
+                self._model_h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _strip_unsupported_options(world: BaseWorld) -> bool:
+        """The batched reference path runs without the noslip post-pass
+        (``warp/simulation.py:427-448``); so does this engine."""
+        if world.noslip_iterations > 0:
+            warnings.warn(
+                "The batched engine does not run noslip iterations. Changing "
+                f"option/noslip_iterations from {world.noslip_iterations} to 0."
+            )
+            world.noslip_iterations = 0
+            world._compiled = None
+            return True
+        return False
+
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ids(self, arr):
+        return self._torch.as_tensor(np.asarray(arr, dtype=np.int32), device=self.device)
+
+    def _build_index_maps(self):
+        m = self.model
+        self._ids_by_fly = {}
+        for fly_name, fly in self.world.fly_lookup.items():
+            nd = len(fly.get_jointdofs_order())
+            maps = dict(
+                qpos=self._ids(np.arange(7, 7 + nd)),
+                qvel=self._ids(np.arange(6, 6 + nd)),
+                bodies=self._ids(np.arange(m.nseg)),
+                sites=self._ids(np.arange(m.nsite)),
+                adhesion=self._ids([i for i, a in enumerate(fly.actuators) if a["kind"] == "adhesion"]),
+                actuators={},
+            )
+            for ty in ActuatorType:
+                ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == ty.value and ty != ActuatorType.ADHESION]
+                if ids:
+                    maps["actuators"][ty] = self._ids(ids)
+            self._ids_by_fly[fly_name] = maps
+
+    # ---- raw views -------------------------------------------------------------------
+    def field(self, name: str):
+        """Zero-copy torch view ``(n_worlds, width)`` of an engine array (aliases device state)."""
+        if name not in self._views:
+            width = ctypes.c_int32(0)
+            ptr = self._lib.nmf_field_ptr(self._batch_h, _native.FIELDS[name], ctypes.byref(width))
+            if not ptr:
+                raise _native.NativeError(self._lib.nmf_last_error().decode())
+            self._views[name] = _tensor_from_ptr(self._torch, ptr, (self.n_worlds, max(width.value, 0)), self.device)
+        return self._views[name]
+
+    def _gather(self, field: str, ids, group: int = 1):
+        n = int(ids.numel())
+        shape = (self.n_worlds, n) if group == 1 else (self.n_worlds, n, group)
+        dst = self._torch.empty(shape, dtype=self._torch.float32, device=self.device)
+        if n:
+            _native.check(self._lib.nmf_gather(self._batch_h, _native.FIELDS[field], ids.data_ptr(), n, group,
+                                               dst.data_ptr(), self._stream()))
+        return dst
+
+    def _to_device(self, x, n_cols: int, what: str):
+        t = self._torch
+        if not isinstance(x, t.Tensor):
+            x = t.as_tensor(np.asarray(x, dtype=np.float32))
+        if x.ndim != 2 or x.shape[0] != self.n_worlds or x.shape[1] != n_cols:
+            raise ValueError(f"Expected {what} of shape ({self.n_worlds}, {n_cols}), but got {tuple(x.shape)}")
+        return x.to(device=self.device, dtype=t.float32).contiguous()
+
+    # ---- reference surface ---------------------------------------------------------------
+    def reset(self) -> None:
+        _native.check(self._lib.nmf_reset(self._batch_h, self._stream()))
+        if self.renderer is not None:
+            self.renderer.reset()
+        self._curr_step = 0
+        self._frames_rendered = 0
+        self._total_physics_time_ns = 0
+        self._total_render_time_ns = 0
+
+    def step(self, n_steps: int = 1) -> None:
+        """Advance all worlds by one timestep (``n_steps`` > 1 fuses several into one launch)."""
+        _native.check(self._lib.nmf_step(self._batch_h, int(n_steps), self._stream()))
+
+    def step_replay(self, table, act_ids, start: int, n_steps: int) -> None:
+        """Device-resident replay loop: before step ``s`` load ``ctrl[:, act_ids] = table[:, start+s]``."""
+        _native.check(self._lib.nmf_step_replay(
+            self._batch_h, table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr(),
+            int(start), int(n_steps), self._stream()))
+
+    def step_with_profile(self) -> None:
+        t0 = perf_counter_ns()
+        self.step()
+        self._total_physics_time_ns += perf_counter_ns() - t0
+        self._curr_step += 1
+
+    def warmup(self, duration_s: float = 0.05) -> None:
+        n = int(duration_s / self.timestep)
+        if n > 0:
+            self.step(n)
+
+    def get_joint_angles(self, fly_name: str):
+        return self._gather("qpos", self._ids_by_fly[fly_name]["qpos"])
+
+    def get_joint_velocities(self, fly_name: str):
+        return self._gather("qvel", self._ids_by_fly[fly_name]["qvel"])
+
+    def get_body_positions(self, fly_name: str):
+        return self._gather("seg_xpos", self._ids_by_fly[fly_name]["bodies"], 3)
+
+    def get_body_rotations(self, fly_name: str):
+        return self._gather("seg_xquat", self._ids_by_fly[fly_name]["bodies"], 4)
+
+    def get_site_positions(self, fly_name: str):
+        return self._gather("site_xpos", self._ids_by_fly[fly_name]["sites"], 3)
+
+    def get_actuator_forces(self, fly_name: str, actuator_type):
+        ids = self._ids_by_fly[fly_name]["actuators"][ActuatorType(actuator_type)]
+        return self._gather("actuator_force", ids)
+
+    def get_ground_contact_info(self, fly_name: str):
+        """(active, force, torque, pos, normal, tangent) with a leading batch axis: shapes
+        ``(n_worlds, 6)`` and ``(n_worlds, 6, 3)`` (reference ``simulation.py:210-243``)."""
+        if self.world.legpos_to_groundcontactsensors_by_fly is None:
+            raise ValueError("this world has no ground contact sensors")
+        sd = self.field("sensordata").reshape(self.n_worlds, 6, 16).clone()
+        return sd[:, :, 0], sd[:, :, 1:4], sd[:, :, 4:7], sd[:, :, 7:10], sd[:, :, 10:13], sd[:, :, 13:16]
+
+    def get_solver_stats(self):
+        """``(n_worlds, 4)``: contacts, Newton iterations, contact-overflow flag, constraint rows."""
+        return self.field("stats").clone()
+
+    def set_actuator_inputs(self, fly_name: str, actuator_type, inputs) -> None:
+        ids = self._ids_by_fly[fly_name]["actuators"][ActuatorType(actuator_type)]
+        n = int(ids.numel())
+        if len(inputs.shape) == 2 and inputs.shape[1] != n:
+            raise ValueError(
+                f"Expected {n} inputs for actuator type '{ActuatorType(actuator_type).name}', but got {inputs.shape[1]}"
+            )
+        src = self._to_device(inputs, n, "actuator inputs")
+        _native.check(self._lib.nmf_scatter(self._batch_h, _native.FIELDS["ctrl"], ids.data_ptr(), n,
+                                            src.data_ptr(), self._stream()))
+
+    def set_leg_adhesion_states(self, fly_name: str, leg_to_adhesion_state) -> None:
+        ids = self._ids_by_fly[fly_name]["adhesion"]
+        n = int(ids.numel())
+        if len(leg_to_adhesion_state.shape) == 2 and leg_to_adhesion_state.shape[1] != n:
+            raise ValueError(
+                f"Unexpected number of adhesion states: expected {n}, got {leg_to_adhesion_state.shape[1]}"
+            )
+        src = self._to_device(leg_to_adhesion_state, n, "adhesion states")
+        _native.check(self._lib.nmf_scatter(self._batch_h, _native.FIELDS["ctrl"], ids.data_ptr(), n,
+                                            src.data_ptr(), self._stream()))
+
+    @property
+    def time(self) -> float:
+        """Current simulation time in seconds (from world 0; synchronises)."""
+        return float(self.field("time")[0, 0].item())
+
+    @property
+    def timestep(self) -> float:
+        return float(self.model["opt_timestep"][0])
+
+    # ---- rendering hand-off (out of scope for the engine) ------------------
+    def set_renderer(self, *args, **kwargs):
+        raise NotImplementedError(
+            "rendering is outside the stepping engine: read poses with get_body_positions/"
+            "get_body_rotations and hand them to a renderer of your choice"
+        )
+
+    def render_as_needed(self):
+        if self.renderer is None:
+            return {}
+        return self.renderer.render_as_needed(self)
+
+    def print_performance_report(self) -> None:
+        n = max(self._curr_step, 1)
+        us = self._total_physics_time_ns / 1e3 / n
+        rate = 1e6 / us if us > 0 else float("nan")
+        print(f"physics: {us:.1f} us/step  {rate:.0f} it/s  x{rate * self.timestep:.3f} realtime "
+              f"(x{rate * self.timestep * self.n_worlds:.1f} over {self.n_worlds} worlds)")
+
+
+def _tensor_from_ptr(torch, ptr: int, shape, device):
+    """Wrap a raw device pointer as a torch tensor without copying."""
+    n = int(np.prod(shape))
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {
+        "shape": (max(n, 1),), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None,
+    }
+    t = torch.as_tensor(h, device=device)
+    return t[:n].reshape(shape)

@@ -1,0 +1,102 @@
+/*
+ * nmf.h — C ABI of the MI355X-native batched NeuroMechFly stepping engine (libnmf_hip.so).
+ *
+ * The reference has no FFI for this path: its "operator API" is the Python class
+ * flygym.warp.GPUSimulation (reference src/flygym/warp/simulation.py:28-453), which forwards
+ * to mujoco_warp.  Each entry point below replaces one group of those calls; the Python class
+ * flygym_amd.HIPSimulation binds them with ctypes (see INTEGRATION.md for the stub a flygym
+ * maintainer would add).  No torch / HIP types appear in the signatures: device buffers are
+ * plain pointers, streams are passed as void* (hipStream_t), sizes are ints.
+ *
+ * All device arrays are float32, row-major, world-major: field[n_worlds][width].
+ * All calls are stream-ordered device work without host synchronisation (hipGraph-capturable)
+ * unless stated otherwise.  Return value: 0 on success, negative on error (see nmf_last_error).
+ */
+#ifndef NMF_H_
+#define NMF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmf_model nmf_model;
+typedef struct nmf_batch nmf_batch;
+
+/* Per-world fields addressable through nmf_field_ptr / nmf_gather_* */
+enum nmf_field {
+  NMF_QPOS = 0,         /* [nq]      generalized positions (free joint 7 + hinges)            */
+  NMF_QVEL = 1,         /* [nv]                                                                */
+  NMF_CTRL = 2,         /* [nu]      actuator controls                                         */
+  NMF_QACC_WARMSTART = 3, /* [nv]                                                              */
+  NMF_SEG_XPOS = 4,     /* [nseg*3]  world positions of the named body segments               */
+  NMF_SEG_XQUAT = 5,    /* [nseg*4]  world orientations (w,x,y,z)                              */
+  NMF_SITE_XPOS = 6,    /* [nsite*3]                                                           */
+  NMF_ACTUATOR_FORCE = 7, /* [nu]                                                              */
+  NMF_SENSORDATA = 8,   /* [96]      6 legs x (found, force3, torque3, pos3, normal3, tangent3)*/
+  NMF_TIME = 9,         /* [1]                                                                 */
+  NMF_STATS = 10,       /* [4]       ncon, solver iterations, overflow flag, nefc (as floats)  */
+  NMF_QACC = 11,        /* [nv]                                                                */
+  NMF_FIELD_COUNT = 12
+};
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* nmf_last_error(void);
+
+/* Parse a compiled-model blob (flygym_amd.compiler.model.CompiledModel.to_blob()).
+ * Replaces: world.compile() + mjw.put_model  (reference simulation.py:37, warp/simulation.py:417). */
+nmf_model* nmf_model_create(const void* blob, size_t nbytes);
+void nmf_model_destroy(nmf_model* model);
+
+/* out[0..9] = nq, nv, nu, nbody, nseg, ngeom, nsite, max_contacts, nsensordata, is_star */
+int nmf_model_dims(const nmf_model* model, int32_t out[10]);
+
+/* Allocate the state of n_worlds identical worlds on `device` and reset them to the model's
+ * "neutral" keyframe.  Replaces: mjw.put_data(nworld=...)  (warp/simulation.py:418-424). */
+nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device);
+void nmf_batch_destroy(nmf_batch* batch);
+int nmf_batch_n_worlds(const nmf_batch* batch);
+
+/* Reset every world to the neutral keyframe (qpos, ctrl from the keyframe; qvel = 0; time = 0)
+ * and refresh the pose outputs.  Replaces GPUSimulation.reset (warp/simulation.py:64-71). */
+int nmf_reset(nmf_batch* batch, void* stream);
+
+/* Advance all worlds by n_steps physics steps in ONE kernel launch, controls held constant.
+ * Replaces n_steps calls of GPUSimulation.step (warp/simulation.py:260-263). */
+int nmf_step(nmf_batch* batch, int n_steps, void* stream);
+
+/* Same, but before step s the controls ctrl[w][act_ids[a]] are loaded from
+ * table[w][(start + s) % table_steps][a]  (a < n_act): the device-resident kinematic-replay
+ * loop of the reference benchmark (src/flygym_demo/benchmark/time_gpu_simulation.py:137-150:
+ * update_target_angles_kernel + set_actuator_inputs + step + increment_counter, graph-captured). */
+int nmf_step_replay(nmf_batch* batch, const float* table_dev, int table_steps, int n_act,
+                    const int32_t* act_ids_dev, int start, int n_steps, void* stream);
+
+/* Device pointer + row width of a per-world field (zero-copy views for PyTorch). */
+float* nmf_field_ptr(nmf_batch* batch, int field, int32_t* width);
+
+/* dst[w][k] = field[w][ids[k]*group .. +group)  — gather in caller order (group = 1, 3 or 4).
+ * Replaces wp_gather_indexed_cols_2d / _rows_vec3f / _rows_quatf (warp/utils.py:29-127). */
+int nmf_gather(nmf_batch* batch, int field, const int32_t* ids_dev, int n_ids, int group,
+               float* dst_dev, void* stream);
+
+/* field[w][ids[k]] = src[w][k]  — scatter controls in caller order.
+ * Replaces wp_scatter_indexed_cols_2d (warp/utils.py:84-104). */
+int nmf_scatter(nmf_batch* batch, int field, const int32_t* ids_dev, int n_ids,
+                const float* src_dev, void* stream);
+
+/* Number of physics steps taken since the last reset (host-side counter, no sync). */
+int64_t nmf_step_count(const nmf_batch* batch);
+
+/* Timing helper for benchmarks: runs nmf_step/nmf_step_replay `reps` times on `stream`
+ * bracketed by hipEvents recorded on that same stream; returns mean milliseconds per launch
+ * (blocks the host).  table_dev may be NULL for constant controls. */
+double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_steps, int n_act,
+                         const int32_t* act_ids_dev, int n_steps, int reps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMF_H_ */
