@@ -1,0 +1,198 @@
+"""Headline benchmark: env-steps/s of the batched NeuroMechFly stepping path on N x MI355X.
+
+Protocol = the reference's GPU benchmark (``src/flygym_demo/benchmark/time_gpu_simulation.py:108-198``,
+driver ``scripts/dev/run_gpu_benchmark.py:10-32``): benchmark model (``make_model`` defaults: LEGS_ONLY
+skeleton nq 73 / nv 72, 42 position actuators kp 50, 6 adhesion actuators, flat ground, 55 geom-plane
+pairs, mesh-hull collision geometry), adhesion on for all legs, untimed warm-up, then K timed steps of
+kinematic replay (world w replays clip partition w % 20), no rendering;
+``steps_per_second = K * n_worlds / wall``.
+
+    python bench.py                      # 1 GPU, 4096 worlds, 1000 timed steps after 500 warm-up steps
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 1000 --warmup 500
+
+One process per GPU; worlds are independent, so each rank steps its own 4096 (weak scaling) and the
+only inter-GPU traffic is an RCCL all-gather of the observation block once per control tick.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "oracle"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+# algorithmic HBM bytes per env-step (f32): read qpos 73 + qvel 72 + ctrl 48 +
+# qacc_warmstart 72, write qpos 73 + qvel 72 + qacc_warmstart 72  = 482 floats.
+BYTES_PER_ENV_STEP = 1928
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+OBS_DIM = 66 + 66 + 42 + 96    # joint angles, joint velocities, actuator forces, contact sensors
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--worlds-per-gpu", type=int, default=4096)
+    ap.add_argument("--steps-per-launch", type=int, default=50,
+                    help="physics steps fused into one kernel launch (= one control tick)")
+    ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=60000)
+    return ap.parse_args()
+
+
+def cpu_baseline(model_blob, table_row, act_ids, warmup, n_steps):
+    """The C oracle (a port of the pipeline, NOT real MuJoCo) on one host core, same replay input."""
+    import oracle as orc
+
+    orc.build()
+    o = orc.Oracle(model_blob, "f64")
+    o.ctrl[42:] = 1.0
+    o.step(warmup)
+    t0 = time.perf_counter()
+    o.step_replay(table_row, act_ids, 0, n_steps)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"1 world x {n_steps} replay steps after {warmup} warm-up steps, float64 C oracle "
+                  f"(oracle/nmf_oracle.c), {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd import _native
+    from flygym_amd.compose import ActuatorType
+    from flygym_amd.replay import ReplayTargetData
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world_size
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n_local = args.worlds_per_gpu
+    spl = max(1, min(args.steps_per_launch, args.steps))
+    if args.steps % spl:
+        spl = next(d for d in range(spl, 0, -1) if args.steps % d == 0)
+    n_launches = args.steps // spl
+
+    fly, world, _ = make_model(simplify_geom=args.simplify_geom)
+    sim = HIPSimulation(world, n_worlds=n_local, device=local_rank)
+    order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
+    replay = ReplayTargetData(sim.timestep, order)
+    table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
+    table = torch.as_tensor(
+        replay.make_target_angles_all_worlds(n_local, table_steps, first_world=rank * n_local), device=sim.device)
+    act_ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
+    maps = sim._ids_by_fly[fly.name]
+
+    sim.set_leg_adhesion_states(fly.name, np.ones((n_local, 6), dtype=np.float32))
+    if args.warmup > 0:
+        sim.step(args.warmup)   # reference: sim.warmup() = 500 steps at the neutral targets
+
+    obs_local = torch.empty((n_local, OBS_DIM), dtype=torch.float32, device=sim.device)
+    obs_all = torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) if world_size > 1 else None
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
+
+    def control_tick(start, k=n_launches):
+        # the kernel is launched on torch's current stream, so these events bracket exactly it
+        ev0[k].record()
+        sim.step_replay(table, act_ids, start, spl)
+        ev1[k].record()
+        if world_size > 1:
+            obs_local[:, 0:66] = sim.field("qpos")[:, 7:]
+            obs_local[:, 66:132] = sim.field("qvel")[:, 6:]
+            obs_local[:, 132:174] = sim.field("actuator_force")[:, :42]
+            obs_local[:, 174:270] = sim.field("sensordata")
+            dist.all_gather_into_tensor(obs_all, obs_local)
+
+    # untimed: one tick to settle allocator / RCCL channels
+    control_tick(0)
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n_launches):
+        control_tick(spl * (k + 1), k)
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=sim.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = bool(torch.isfinite(sim.field("qpos")).all().item())
+    stats = sim.get_solver_stats()
+    overflow = int(stats[:, 2].sum().item())
+
+    if rank == 0:
+        # mean kernel duration over the launches of the timed region (HIP events on the launch stream)
+        ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(n_launches)]))
+        total_worlds = n_local * world_size
+        value = total_worlds * args.steps / elapsed
+        achieved = BYTES_PER_ENV_STEP * n_local * spl / (ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
+            "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "4096 flies/GPU, flat ground, LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
+                            + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
+                            + ", position-actuated kinematic replay of the Spotlight tripod-walking clip "
+                              "(reference benchmark protocol), adhesion on",
+                "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
+                "timestep": sim.timestep, "realtime_factor": value * sim.timestep,
+                "parallelism": f"env-shard x{world_size}" + (", RCCL all-gather of obs per control tick" if world_size > 1 else ""),
+                "state_finite": finite, "contact_overflow_worlds": overflow,
+                "mean_contacts": float(stats[:, 0].mean().item()), "mean_newton_iters": float(stats[:, 1].mean().item()),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "nmf_step_kernel<Topo<6,8,11>>", "kernel_ms_per_launch": ms,
+                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+                "note": "the step is VALU/LDS-latency bound by construction (state crosses HBM once per launch); "
+                        "see DESIGN.md for the instruction-side analysis",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), replay.dof_angles[:table_steps].astype(np.float32),
+                                               np.arange(42, dtype=np.int32), args.warmup, args.cpu_steps)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

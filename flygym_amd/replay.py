@@ -1,0 +1,74 @@
+"""Kinematic-replay inputs: the Spotlight walking clip resampled to the simulation timestep.
+
+Mirror of the reference's ``MotionSnippet`` (``src/flygym_demo/spotlight_data/preprocessing.py:11-142``)
+and of the benchmark's ``ReplayTargetData`` (``src/flygym_demo/benchmark/time_gpu_simulation.py:67-86``).
+The recorded joint angles (660 frames x 6 legs x 7 DoF at 330 Hz) come from the asset pack.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .anatomy import JointDOF
+
+__all__ = ["MotionSnippet", "ReplayTargetData"]
+
+
+class MotionSnippet:
+    def __init__(self, data_path=None, *, angles_global2anatomical: bool = True) -> None:
+        if data_path is None:
+            from .compiler.model import load_asset_pack
+
+            pack = load_asset_pack()
+            self.joint_angles = pack["clip_joint_angles"].astype(np.float32).copy()
+            self.legs = [str(x) for x in pack["clip_legs"]]
+            self.dofs_per_leg = [tuple(str(y) for y in row) for row in pack["clip_dofs_per_leg"]]
+            self.data_fps = float(pack["clip_fps"])
+        else:
+            data = np.load(data_path, allow_pickle=True)
+            self.joint_angles = data["joint_angles"].copy()
+            self.legs = data["legs"].tolist()
+            self.dofs_per_leg = [tuple(x) for x in data["dofs_per_leg"].tolist()]
+            self.data_fps = float(data["data_fps"].item())
+        if angles_global2anatomical:
+            # right-leg roll / yaw change sign: global (IK) convention -> anatomical (:59-78)
+            right = [i for i, leg in enumerate(self.legs) if leg[0] == "r"]
+            flip = [i for i, (_, _, axis) in enumerate(self.dofs_per_leg) if axis in ("roll", "yaw")]
+            self.joint_angles[np.ix_(np.arange(self.joint_angles.shape[0]), right, flip)] *= -1
+
+    def get_joint_angles(self, output_timestep: float, output_dof_order: list[JointDOF], *,
+                         sgfilter_window_sec: float = 0.03, sgfilter_polyorder: int = 3) -> np.ndarray:
+        """Savitzky-Golay smoothing, cubic resampling onto ``arange(0, T, dt)``, reorder (:80-142)."""
+        from scipy.interpolate import interp1d
+        from scipy.signal import savgol_filter
+
+        window = int(sgfilter_window_sec * self.data_fps)
+        window += 1 - (window % 2)
+        smooth = savgol_filter(self.joint_angles, window_length=window, polyorder=sgfilter_polyorder, axis=0)
+        n = self.joint_angles.shape[0]
+        t_src = np.arange(n) / self.data_fps
+        t_out = np.arange(0, n / self.data_fps, output_timestep)
+        interp = interp1d(t_src, smooth, kind="cubic", axis=0, bounds_error=False,
+                          fill_value=(smooth[0], smooth[-1]))
+        dense = interp(t_out)
+        cols = [
+            (self.legs.index(d.child.pos), self.dofs_per_leg.index((d.parent.link, d.child.link, d.axis.value)))
+            for d in output_dof_order
+        ]
+        legs, dofs = np.array(cols, dtype=np.int64).T
+        return dense[:, legs, dofs]
+
+
+class ReplayTargetData:
+    """World ``w`` replays clip partition ``w % n_partitions`` (benchmark :73-86)."""
+
+    def __init__(self, sim_timestep: float, output_dof_order: list[JointDOF]):
+        self.snippet = MotionSnippet()
+        self.dof_angles = self.snippet.get_joint_angles(sim_timestep, output_dof_order)
+        self.n_total_steps, self.n_dofs = self.dof_angles.shape
+
+    def make_target_angles_all_worlds(self, n_worlds: int, sim_steps: int, first_world: int = 0) -> np.ndarray:
+        n_partitions = self.n_total_steps // sim_steps
+        part = (first_world + np.arange(n_worlds)) % n_partitions
+        idx = part[:, None] * sim_steps + np.arange(sim_steps)[None, :]
+        return np.ascontiguousarray(self.dof_angles[idx].astype(np.float32))

@@ -883,6 +883,19 @@ EXPORT void SFX(nmfo_step)(const void* mv, void* dv, int nsteps) {
   for (int s = 0; s < nsteps; s++) { SFX(nmfo_forward)(mv, dv); integrate((const omodel*)mv, (odata*)dv); }
 }
 
+/* kinematic replay on the CPU: ctrl[act_ids[a]] = table[(start + s) % table_steps][a] before step s
+ * (the reference benchmark loop, src/flygym_demo/benchmark/time_gpu_simulation.py:137-150) */
+EXPORT void SFX(nmfo_step_replay)(const void* mv, void* dv, const float* table, int table_steps, int n_act,
+                                  const int* act_ids, int start, int nsteps) {
+  odata* d = (odata*)dv;
+  for (int s = 0; s < nsteps; s++) {
+    const float* row = table + (size_t)((start + s) % table_steps) * n_act;
+    for (int a = 0; a < n_act; a++) d->ctrl[act_ids[a]] = (real)row[a];
+    SFX(nmfo_forward)(mv, dv);
+    integrate((const omodel*)mv, d);
+  }
+}
+
 EXPORT void SFX(nmfo_reset)(const void* mv, void* dv) {
   const omodel* m = (const omodel*)mv; odata* d = (odata*)dv;
   memcpy(d->qpos, m->key_qpos, sizeof(real) * (size_t)m->nq);

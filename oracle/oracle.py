@@ -39,6 +39,8 @@ def _lib(precision: str):
             ("nmfo_forward", None, [ctypes.c_void_p, ctypes.c_void_p]),
             ("nmfo_step", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
             ("nmfo_reset", None, [ctypes.c_void_p, ctypes.c_void_p]),
+            ("nmfo_step_replay", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
             ("nmfo_ptr", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
             ("nmfo_ints", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
         ]:
@@ -103,6 +105,13 @@ class Oracle:
 
     def step(self, n: int = 1):
         self._call("nmfo_step", self._m, self._d, int(n))
+
+    def step_replay(self, table: np.ndarray, act_ids: np.ndarray, start: int, n: int):
+        """table: (table_steps, n_act) float32; act_ids: (n_act,) int32."""
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        act_ids = np.ascontiguousarray(act_ids, dtype=np.int32)
+        self._call("nmfo_step_replay", self._m, self._d, table.ctypes.data, table.shape[0], table.shape[1],
+                   act_ids.ctypes.data, int(start), int(n))
 
     # convenience ----------------------------------------------------------
     @property

@@ -1,0 +1,215 @@
+"""Parity of the HIP engine (through the C ABI / HIPSimulation) with the CPU oracle, on MI355X.
+
+Tolerances: the engine computes in float32; the oracle in float64 (and float32 for the
+integer-exact comparisons).  One physics step from identical states must agree to float32
+rounding of a stiff system: accelerations to 2e-3 relative (of the largest |qacc|), next-step
+positions to 1e-5 mm/rad, velocities to 5e-3 relative.  Contact counts and contact geom ids must be
+bit-exact against the float32 oracle.  Rollouts (chaotic, contact-rich) are compared over a few
+hundred steps with the looser bounds written in each test.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def sim8(torch_mod, bench_model):
+    from flygym_amd import HIPSimulation
+
+    fly, world, _ = bench_model
+    sim = HIPSimulation(world, n_worlds=8, device=0)
+    return fly, sim
+
+
+def _oracles(oracle_lib, sim):
+    blob = sim.model.to_blob()
+    return oracle_lib.Oracle(blob, "f64"), oracle_lib.Oracle(blob, "f32")
+
+
+def _push_state(sim, torch, qpos, qvel, ctrl, ws):
+    sim.field("qpos")[:] = torch.as_tensor(qpos, dtype=torch.float32, device=sim.device)
+    sim.field("qvel")[:] = torch.as_tensor(qvel, dtype=torch.float32, device=sim.device)
+    sim.field("ctrl")[:] = torch.as_tensor(ctrl, dtype=torch.float32, device=sim.device)
+    sim.field("qacc_warmstart")[:] = torch.as_tensor(ws, dtype=torch.float32, device=sim.device)
+
+
+def _sample_states(oracle_lib, sim, n, seed):
+    """States along a walking trajectory (contact-rich) with random velocity perturbations."""
+    rng = np.random.default_rng(seed)
+    o, _ = _oracles(oracle_lib, sim)
+    o.ctrl[42:] = 1.0
+    o.step(400)
+    states = []
+    for k in range(n):
+        o.ctrl[:42] = sim.model["key_ctrl"][:42] + rng.normal(0, 0.25, 42)
+        o.step(60)
+        qvel = o.qvel.copy() + rng.normal(0, 0.5, o.nv) * (k % 2)
+        states.append((o.qpos.copy(), qvel, o.ctrl.copy(), o.arr("qacc_warmstart").copy()))
+    return states
+
+
+def test_single_step_parity(torch_mod, sim8, oracle_lib):
+    torch = torch_mod
+    fly, sim = sim8
+    states = _sample_states(oracle_lib, sim, 8, seed=11)
+    _push_state(sim, torch, *[np.stack([s[i] for s in states]) for i in range(4)])
+    sim.step(1)
+    torch.cuda.synchronize()
+    qacc = sim.field("qacc").cpu().numpy()
+    qpos = sim.field("qpos").cpu().numpy()
+    qvel = sim.field("qvel").cpu().numpy()
+    stats = sim.field("stats").cpu().numpy()
+    frc = sim.field("actuator_force").cpu().numpy()
+    sens = sim.field("sensordata").cpu().numpy()
+    ncon_seen = 0
+    for w, (q0, v0, c0, ws0) in enumerate(states):
+        o64, o32 = _oracles(oracle_lib, sim)
+        for o in (o64, o32):
+            o.qpos[:] = q0; o.qvel[:] = v0; o.ctrl[:] = c0; o.arr("qacc_warmstart")[:] = ws0
+            o.step(1)
+        assert int(stats[w, 0]) == o32.ints()["ncon"] == o64.ints()["ncon"]     # integer parity
+        ncon_seen += int(stats[w, 0])
+        scale = np.abs(o64.arr("qacc")).max()
+        assert np.abs(qacc[w] - o64.arr("qacc")).max() < 2e-3 * scale
+        assert np.abs(qpos[w] - o64.qpos).max() < 1e-5
+        assert np.abs(qvel[w] - o64.qvel).max() < 5e-3 * max(1.0, np.abs(o64.qvel).max())
+        np.testing.assert_allclose(frc[w], o64.arr("actuator_force"), rtol=1e-4, atol=1e-4)
+        so = o64.arr("sensordata").reshape(6, 16)
+        sh = sens[w].reshape(6, 16)
+        np.testing.assert_array_equal(sh[:, 0], so[:, 0])
+        np.testing.assert_allclose(sh[:, 1:4], so[:, 1:4], rtol=5e-3, atol=5e-3 * np.abs(so[:, 1:4]).max())
+        np.testing.assert_allclose(sh[:, 7:10], so[:, 7:10], atol=1e-4)
+    assert ncon_seen >= 24            # the sampled states really are in contact
+
+
+def test_rollout_parity_and_reference_invariants(torch_mod, sim8, oracle_lib):
+    torch = torch_mod
+    fly, sim = sim8
+    sim.reset()
+    assert sim.time == pytest.approx(0.0)
+    neutral = np.array([fly.jointdof_to_neutralangle[d] for d in fly.get_jointdofs_order()], dtype=np.float32)
+    np.testing.assert_allclose(sim.get_joint_angles(fly.name).cpu().numpy(), np.tile(neutral, (8, 1)), atol=1e-6)
+    assert float(sim.get_joint_velocities(fly.name).abs().max()) == 0.0
+    o64, _ = _oracles(oracle_lib, sim)
+    np.testing.assert_allclose(sim.get_body_positions(fly.name).cpu().numpy()[0],
+                               o64.arr("seg_xpos").reshape(69, 3), atol=2e-6)
+    sim.set_leg_adhesion_states(fly.name, np.ones((8, 6), dtype=np.float32))
+    o64.ctrl[42:] = 1.0
+    for k in range(6):
+        sim.step(50)
+        o64.step(50)
+        q = sim.field("qpos").cpu().numpy()
+        assert np.abs(q - o64.qpos[None]).max() < 5e-5, f"after {50 * (k + 1)} steps"
+        assert np.abs(q - q[0:1]).max() == 0.0                      # identical worlds stay identical
+    assert sim.time == pytest.approx(300 * 1e-4, rel=1e-3)
+    quats = sim.get_body_rotations(fly.name).cpu().numpy()
+    assert quats.shape == (8, 69, 4)
+    np.testing.assert_allclose(np.linalg.norm(quats, axis=2), 1.0, atol=1e-5)
+    np.testing.assert_allclose(sim.get_body_positions(fly.name).cpu().numpy()[3],
+                               o64.arr("seg_xpos").reshape(69, 3), atol=1e-4)
+    active, force, torque, pos, normal, tangent = sim.get_ground_contact_info(fly.name)
+    assert active.shape == (8, 6) and force.shape == (8, 6, 3)
+    so = o64.arr("sensordata").reshape(6, 16)
+    np.testing.assert_array_equal(active.cpu().numpy()[0], so[:, 0])
+    np.testing.assert_allclose(force.cpu().numpy()[0], so[:, 1:4], rtol=2e-2, atol=2e-2)
+    weight = sim.model["body_mass"].sum() * 9810.0
+    assert float(force[0, :, 2].sum()) == pytest.approx(weight + 6.0, rel=0.1)
+
+
+def test_control_inputs_and_getters(torch_mod, sim8):
+    torch = torch_mod
+    from flygym_amd.compose import ActuatorType
+
+    fly, sim = sim8
+    sim.reset()
+    n_dofs = sim.get_joint_angles(fly.name).shape[1]
+    assert n_dofs == 66
+    before = sim.get_joint_angles(fly.name).cpu().numpy().copy()
+    rng = np.random.default_rng(5)
+    inputs = rng.normal(0, 0.5, (8, 42)).astype(np.float32)
+    sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, inputs)
+    ctrl = sim.field("ctrl").cpu().numpy()
+    np.testing.assert_array_equal(ctrl[:, :42], inputs)                 # scatter is exact
+    sim.set_leg_adhesion_states(fly.name, torch.full((8, 6), 3.0, device=sim.device))
+    np.testing.assert_array_equal(sim.field("ctrl").cpu().numpy()[:, 42:], 3.0)
+    with pytest.raises(ValueError):
+        sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, np.zeros((8, 47), dtype=np.float32))
+    with pytest.raises(ValueError):
+        sim.set_leg_adhesion_states(fly.name, np.ones((8, 5), dtype=np.float32))
+    for _ in range(50):
+        sim.step()
+    after = sim.get_joint_angles(fly.name).cpu().numpy()
+    assert not np.allclose(before, after, atol=1e-4)                      # reference test_control_inputs_affect...
+    assert np.abs(after - after[0]).max() > 1e-3                         # different inputs -> different worlds
+    forces = sim.get_actuator_forces(fly.name, ActuatorType.POSITION)
+    assert forces.shape == (8, 42) and float(forces.abs().max()) <= 30.0 + 1e-4    # forcerange clamp
+    # gathers equal plain indexing of the raw arrays
+    np.testing.assert_array_equal(sim.get_joint_velocities(fly.name).cpu().numpy(), sim.field("qvel").cpu().numpy()[:, 6:])
+    np.testing.assert_array_equal(sim.get_body_rotations(fly.name).cpu().numpy().reshape(8, -1),
+                                  sim.field("seg_xquat").cpu().numpy())
+
+
+def test_in_kernel_replay_equals_per_step_scatter(torch_mod, bench_model):
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.compose import ActuatorType
+    from flygym_amd.replay import ReplayTargetData
+
+    fly, world, _ = bench_model
+    order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
+    table = ReplayTargetData(1e-4, order).make_target_angles_all_worlds(6, 1000)
+    a = HIPSimulation(world, n_worlds=6, device=0)
+    b = HIPSimulation(world, n_worlds=6, device=0)
+    tdev = torch.as_tensor(table, device=a.device)
+    ids = a._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
+    a.step(100); b.step(100)
+    a.step_replay(tdev, ids, 990, 40)                                   # wraps around the table end
+    for s in range(40):
+        b.set_actuator_inputs(fly.name, ActuatorType.POSITION, tdev[:, (990 + s) % 1000, :])
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.field("qpos"), b.field("qpos")) and torch.equal(a.field("qvel"), b.field("qvel"))
+
+
+def test_full_size_batch_properties(torch_mod, bench_model):
+    """BASELINE size (4096 worlds): finite, deterministic across launches, worlds independent."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.compose import ActuatorType
+    from flygym_amd.replay import ReplayTargetData
+
+    fly, world, _ = bench_model
+    n = 4096
+    order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
+    table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_worlds(n, 1000), device="cuda:0")
+    runs = []
+    for rep in range(2):
+        sim = HIPSimulation(world, n_worlds=n, device=0)
+        ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
+        sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+        sim.step(300)
+        if rep == 1:                          # perturb one world only
+            sim.field("qvel")[1234, 6:] += 5.0
+        sim.step_replay(table, ids, 0, 150)
+        torch.cuda.synchronize()
+        runs.append((sim.field("qpos").clone(), sim.field("stats").clone()))
+        del sim
+    q0, q1 = runs[0][0], runs[1][0]
+    assert bool(torch.isfinite(q0).all())
+    same = (q0 == q1).all(dim=1)
+    assert int((~same).sum()) == 1 and not bool(same[1234])             # bitwise determinism + independence
+    # worlds w and w+20 replay the same partition from the same state -> identical
+    assert torch.equal(q0[5], q0[25]) and not torch.equal(q0[5], q0[6])
+    assert float(runs[0][1][:, 2].sum()) == 0.0                         # no contact overflow
+    assert float(runs[0][1][:, 0].mean()) > 2.0                         # walking: legs on the ground
