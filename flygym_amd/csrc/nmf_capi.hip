@@ -56,6 +56,7 @@ struct nmf_batch {
   const nmf_model* model = nullptr;
   int n_worlds = 0, device = 0, topo = 0;
   nmf::DevModel dm{};
+  nmf::DevModel* dm_dev = nullptr;
   nmf::DevState st{};
   std::vector<void*> allocs;
   float* fields[NMF_FIELD_COUNT] = {};
@@ -158,9 +159,9 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
   if (b->topo == 0)
-    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopo>), grid, block, 0, stream, b->dm, b->st, rp, n_steps, mode);
+    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopo>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode);
   else
-    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopoActive>), grid, block, 0, stream, b->dm, b->st, rp, n_steps, mode);
+    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopoActive>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -202,6 +203,12 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   UF(pair_friction); UF(pair_solref); UF(pair_solimp); UF(pair_margin);
 #undef UF
 #undef UI
+  if (rc == 0) {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(nmf::DevModel)) != hipSuccess ||
+        hipMemcpy(p, &d, sizeof(nmf::DevModel), hipMemcpyHostToDevice) != hipSuccess) { fail("nmf_batch_create: model upload failed"); rc = -1; }
+    else { b->allocs.push_back(p); b->dm_dev = (nmf::DevModel*)p; }
+  }
   nmf::DevState& st = b->st;
   st.n_worlds = n_worlds;
   rc |= alloc_field(b, NMF_QPOS, model->nq, &st.qpos);

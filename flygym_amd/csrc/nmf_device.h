@@ -176,6 +176,17 @@ __device__ __forceinline__ void sym6_add_inertia(Sym6& A, const float* I) {
   A.v[sym_idx(3, 3)] += I[0]; A.v[sym_idx(4, 4)] += I[0]; A.v[sym_idx(5, 5)] += I[0];
 }
 
+// ---------------------------------------------------------------- 8-lane group reductions (DPP)
+// Lanes are used as 8 groups of 8; a group owns one leg and its lanes own the 6 rows/components of
+// a spatial quantity (lanes 6,7 of a group carry zeros).  The sum lands in every lane of the group.
+#define NMF_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float grp8_sum(float v) {
+  v += NMF_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += NMF_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += NMF_DPP(v, 0x141);   // row_half_mirror: lane i <-> 7-i inside each 8-lane half row
+  return v;
+}
+
 // ---------------------------------------------------------------- wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -23,6 +23,7 @@
 namespace nmf {
 
 #define WSYNC() __syncthreads()
+constexpr float kNoiseFactor = 8.f;
 
 template <class TP>
 struct __align__(16) FlyLds {
@@ -36,7 +37,8 @@ struct __align__(16) FlyLds {
   float S[TP::NV][6];
   float Ib[TP::NB][10];
   float vel[TP::NB][6], T[TP::NB][6], W[TP::NB][6];
-  float legIA[TP::NLEG][21], legpA[TP::NLEG][6];
+  float legIA[TP::NLEG][6][6], legpA[TP::NLEG][6];
+  float rootA[6][6], rootb[6];
   float c_r[kMaxCon][3], c_dist[kMaxCon], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];
   int c_geom[kMaxCon], c_body[kMaxCon], c_act[kMaxCon];
   int body_cstart[TP::NB + 1];
@@ -264,20 +266,39 @@ __device__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
 }
 
 // ------------------------------------------------------------------ chain sweeps
+// Lane layout for everything that walks a leg: the wave is 8 groups of 8 lanes; group g < NLEG owns
+// leg g and lane r < 6 of the group owns component r of a spatial vector (or row r of a 6x6).
+// Groups >= NLEG and lanes r >= 6 shadow harmless work (loads clamped, stores masked) so that every
+// lane runs the same instruction stream and the DPP reductions stay converged.
+struct LaneRole {
+  int grp, r, lg, rr;
+  bool live;      // a real (leg, component) lane
+  float mask;     // 1 for r < 6 else 0 (zero contribution to group sums)
+};
+template <class TP>
+__device__ __forceinline__ LaneRole lane_role(int lane) {
+  LaneRole L;
+  L.grp = lane >> 3; L.r = lane & 7;
+  L.lg = L.grp < TP::NLEG ? L.grp : TP::NLEG - 1;
+  L.rr = L.r < 6 ? L.r : 5;
+  L.live = L.grp < TP::NLEG && L.r < 6;
+  L.mask = L.r < 6 ? 1.f : 0.f;
+  return L;
+}
+
 // T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
 template <class TP>
 __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
-  if (lane < TP::NLEG) {
-    SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
+  const LaneRole L = lane_role<TP>(lane);
+  float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) t = t + x[j] * ldsv(s.S[j]);
-    if (lane == 0) stsv(T[0], t);
-    for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + lane * TP::NBL + l;
-      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr; j < adr + num; ++j) t = t + x[j] * ldsv(s.S[j]);
-      stsv(T[b], t);
-    }
+  for (int j = 0; j < 6; ++j) t += x[j] * s.S[j][L.rr];
+  if (lane < 6) T[0][lane] = t;
+  for (int l = 0; l < TP::NBL; ++l) {
+    int b = 1 + L.lg * TP::NBL + l;
+    int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    for (int j = adr; j < adr + num; ++j) t += x[j] * s.S[j][L.rr];
+    if (L.live) T[b][L.r] = t;
   }
   WSYNC();
 }
@@ -285,20 +306,19 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 // W[b] <- sum of W over the subtree of b (in place), then out[j] = S_j · W[body(j)]
 template <class TP>
 __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const DevModel& m, int lane) {
-  if (lane < TP::NLEG) {
-    SV acc = SV{v3(0, 0, 0), v3(0, 0, 0)};
-    for (int l = TP::NBL - 1; l >= 0; --l) {
-      int b = 1 + lane * TP::NBL + l;
-      acc = acc + ldsv(W[b]);
-      stsv(W[b], acc);
-    }
+  const LaneRole L = lane_role<TP>(lane);
+  float acc = 0.f;
+  for (int l = TP::NBL - 1; l >= 0; --l) {
+    int b = 1 + L.lg * TP::NBL + l;
+    acc += W[b][L.rr];
+    if (L.live) W[b][L.r] = acc;
   }
   WSYNC();
   if (lane < 6) {
-    float acc = W[0][lane];
+    float a0 = W[0][lane];
 #pragma unroll
-    for (int k = 0; k < TP::NLEG; ++k) acc += W[1 + k * TP::NBL][lane];
-    W[0][lane] = acc;
+    for (int k = 0; k < TP::NLEG; ++k) a0 += W[1 + k * TP::NBL][lane];
+    W[0][lane] = a0;
   }
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]]));
@@ -316,109 +336,127 @@ __device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m
   WSYNC();
 }
 
-// contact row directions l = [r x d; d]
-__device__ __forceinline__ void contact_l(V3 r, V3 d, float* l) {
-  V3 c = cross(r, d);
-  l[0] = c.x; l[1] = c.y; l[2] = c.z; l[3] = d.x; l[4] = d.y; l[5] = d.z;
+// row `r` of the 6x6 spatial inertia [[I, [h]x], [-[h]x, m 1]] built from (m, h, I sym6)
+__device__ __forceinline__ void inertia_row(const float* I, int r, float* row) {
+  const bool top = r < 3;
+  const int k = top ? r : r - 3;
+  const float e0 = k == 0 ? 1.f : 0.f, e1 = k == 1 ? 1.f : 0.f, e2 = k == 2 ? 1.f : 0.f;
+  const float hx = I[1], hy = I[2], hz = I[3];
+  // e_k x h  = row k of [h]x
+  const float c0 = e1 * hz - e2 * hy, c1 = e2 * hx - e0 * hz, c2 = e0 * hy - e1 * hx;
+  const float i0 = e0 * I[4] + e1 * I[7] + e2 * I[8], i1 = e0 * I[7] + e1 * I[5] + e2 * I[9],
+              i2 = e0 * I[8] + e1 * I[9] + e2 * I[6];
+  const float ms = I[0];
+  row[0] = top ? i0 : -c0; row[1] = top ? i1 : -c1; row[2] = top ? i2 : -c2;
+  row[3] = top ? c0 : ms * e0; row[4] = top ? c1 : ms * e1; row[5] = top ? c2 : ms * e2;
 }
 
+// row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t
 template <class TP>
-__device__ __forceinline__ void add_contact_K(Sym6& IA, const FlyLds<TP>& s, int c, const Frame& fr) {
-  int act = s.c_act[c];
+__device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, int r, const Frame& fr) {
+  const int act = s.c_act[c];
   if (!act) return;
-  V3 r = ld3(s.c_r[c]);
-  float D = s.c_D[c], mu = s.c_mu[c];
-  float ln[6], l1[6], l2[6];
-  contact_l(r, fr.n, ln); contact_l(r, fr.t1, l1); contact_l(r, fr.t2, l2);
-  float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
-  sym6_rank1(IA, ln, D * (a0 + a1 + a2 + a3));
-  if (a0 + a1 > 0.f) { sym6_rank1(IA, l1, D * mu * mu * (a0 + a1)); }
-  if (a0 != a1) sym6_rank2(IA, ln, l1, D * mu * (a0 - a1));
-  if (a2 + a3 > 0.f) { sym6_rank1(IA, l2, D * mu * mu * (a2 + a3)); }
-  if (a2 != a3) sym6_rank2(IA, ln, l2, D * mu * (a2 - a3));
+  const V3 rc = ld3(s.c_r[c]);
+  const float D = s.c_D[c], mu = s.c_mu[c];
+  const V3 xn = cross(rc, fr.n), x1 = cross(rc, fr.t1), x2 = cross(rc, fr.t2);
+  const float ln[6] = {xn.x, xn.y, xn.z, fr.n.x, fr.n.y, fr.n.z};
+  const float l1[6] = {x1.x, x1.y, x1.z, fr.t1.x, fr.t1.y, fr.t1.z};
+  const float l2[6] = {x2.x, x2.y, x2.z, fr.t2.x, fr.t2.y, fr.t2.z};
+  float lnr = 0.f, l1r = 0.f, l2r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { const float e = r == i ? 1.f : 0.f; lnr += e * ln[i]; l1r += e * l1[i]; l2r += e * l2[i]; }
+  const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+  const float Dm = D * mu, Dmm = Dm * mu;
+  const float cn = D * (a0 + a1 + a2 + a3) * lnr + Dm * (a0 - a1) * l1r + Dm * (a2 - a3) * l2r;
+  const float c1 = Dm * (a0 - a1) * lnr + Dmm * (a0 + a1) * l1r;
+  const float c2 = Dm * (a2 - a3) * lnr + Dmm * (a2 + a3) * l2r;
+#pragma unroll
+  for (int i = 0; i < 6; i++) row[i] += cn * ln[i] + c1 * l1[i] + c2 * l2[i];
 }
 
-// Articulated-body solve of (CRBA(I_b [+ K_b]) + diag(delta)) x = tau.
-// delta_j = armature_j + hdamp * damping_j.  Leaves T = twists(x).
+// Articulated-body solve of (CRBA(I_b [+ K_b]) + diag(delta)) x = tau, delta_j = armature_j +
+// hdamp * damping_j (root dofs carry no armature/damping).  Leaves T = twists(x).
+//   backward sweep : per leg, rows of the articulated inertia IA and of the bias wrench pA are
+//                    spread over the 6 lanes of the leg's group; per hinge: U = IA s, D = s.U + delta,
+//                    IA -= U UT / D, pA += U (tau - s.pA) / D   (group sums by DPP)
+//   root           : IA_root a = (wrench of tau_root) - pA_root, 6x6 Cholesky in one lane
+//   forward sweep  : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
 template <class TP>
 __device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK, float hdamp,
                           const Frame& fr, const DevModel& m, int lane) {
-  if (lane < TP::NLEG) {
-    Sym6 IA; sym6_zero(IA);
-    float pA[6] = {0, 0, 0, 0, 0, 0};
+  const LaneRole L = lane_role<TP>(lane);
+  {
+    float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float pA = 0.f;
     for (int l = TP::NBL - 1; l >= 0; --l) {
-      int b = 1 + lane * TP::NBL + l;
-      sym6_add_inertia(IA, s.Ib[b]);
-      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K(IA, s, c, fr);
-      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      const int b = 1 + L.lg * TP::NBL + l;
+      float row[6];
+      inertia_row(s.Ib[b], L.rr, row);
+      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+#pragma unroll
+      for (int i = 0; i < 6; i++) IA[i] += row[i];
+      const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
       for (int j = adr + num - 1; j >= adr; --j) {
-        float sj[6], U[6];
+        float sj[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
-        sym6_mul(IA, sj, U);
-        float D = m.dof_armature[j] + hdamp * m.dof_damping[j], sp = 0.f;
+        float U = 0.f;
 #pragma unroll
-        for (int i = 0; i < 6; i++) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
-        float invD = 1.0f / D, u = tau[j] - sp;
-        s.aba_u[j] = u; s.aba_invD[j] = invD;
+        for (int i = 0; i < 6; i++) U += IA[i] * sj[i];
+        const float sr = L.mask * s.S[j][L.rr];
+        const float D = grp8_sum(sr * U) + m.dof_armature[j] + hdamp * m.dof_damping[j];
+        const float sp = grp8_sum(sr * pA);
+        if (L.live) s.aba_U[j][L.r] = U;
+        const float invD = 1.0f / D, u = tau[j] - sp;
+        if (L.live && L.r == 0) { s.aba_u[j] = u; s.aba_invD[j] = invD; }
+        WSYNC();
+        const float k = U * invD;
 #pragma unroll
-        for (int i = 0; i < 6; i++) s.aba_U[j][i] = U[i];
-        sym6_rank1(IA, U, -invD);
-        float k = u * invD;
-#pragma unroll
-        for (int i = 0; i < 6; i++) pA[i] += U[i] * k;
+        for (int i = 0; i < 6; i++) IA[i] -= k * s.aba_U[j][i];
+        pA += k * u;
       }
     }
+    if (L.live) {
 #pragma unroll
-    for (int i = 0; i < 21; i++) s.legIA[lane][i] = IA.v[i];
+      for (int i = 0; i < 6; i++) s.legIA[L.grp][L.r][i] = IA[i];
+      s.legpA[L.grp][L.r] = pA;
+    }
+  }
+  WSYNC();
+  if (lane < 6) {     // root rows
+    float row[6];
+    inertia_row(s.Ib[0], lane, row);
+    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, lane, fr);
+    float pA = 0.f;
+    for (int k = 0; k < TP::NLEG; ++k) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) s.legpA[lane][i] = pA[i];
+      for (int i = 0; i < 6; i++) row[i] += s.legIA[k][lane][i];
+      pA += s.legpA[k][lane];
+    }
+    // wrench of the root generalized force: n = R tau_rot, f = tau_trans
+    float w;
+    if (lane < 3) w = s.xmat[0][3 * lane] * tau[3] + s.xmat[0][3 * lane + 1] * tau[4] + s.xmat[0][3 * lane + 2] * tau[5];
+    else w = tau[lane - 3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s.rootA[lane][i] = row[i];
+    s.rootb[lane] = w - pA;
   }
   WSYNC();
   if (lane == 0) {
-    Sym6 IA; sym6_zero(IA);
-    float pA[6] = {0, 0, 0, 0, 0, 0};
-    sym6_add_inertia(IA, s.Ib[0]);
-    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K(IA, s, c, fr);
-    for (int k = 0; k < TP::NLEG; ++k) {
-#pragma unroll
-      for (int i = 0; i < 21; i++) IA.v[i] += s.legIA[k][i];
-#pragma unroll
-      for (int i = 0; i < 6; i++) pA[i] += s.legpA[k][i];
-    }
-    // 6x6 system in root coordinates: A = Srᵀ IA Sr, rhs = tau_r − Srᵀ pA
-    float A[6][6], rhs[6], F[6][6];
+    float A[6][6], rhs[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      float si[6];
+      rhs[i] = s.rootb[i];
 #pragma unroll
-      for (int k = 0; k < 6; k++) si[k] = s.S[i][k];
-      sym6_mul(IA, si, F[i]);
-      float sp = 0.f;
-#pragma unroll
-      for (int k = 0; k < 6; k++) sp += si[k] * pA[k];
-      rhs[i] = tau[i] - sp;
+      for (int j = 0; j <= i; j++) A[i][j] = s.rootA[i][j];
     }
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j <= i; j++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 6; k++) acc += s.S[j][k] * F[i][k];
-        A[i][j] = acc;
-      }
-#pragma unroll
-    for (int i = 0; i < 6; i++) A[i][i] += m.dof_armature[i] + hdamp * m.dof_damping[i];
-    // Cholesky A = L Lᵀ (lower, in place), then two triangular solves
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       float d = A[j][j];
 #pragma unroll
       for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
-      d = sqrtf(d);
-      A[j][j] = d;
-      float inv = 1.0f / d;
+      const float inv = rsqrtf(d);
+      A[j][j] = inv;                 // store 1 / L_jj
 #pragma unroll
       for (int i = j + 1; i < 6; i++) {
         float v = A[i][j];
@@ -432,32 +470,37 @@ __device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK,
       float v = rhs[i];
 #pragma unroll
       for (int k = 0; k < i; k++) v -= A[i][k] * rhs[k];
-      rhs[i] = v / A[i][i];
+      rhs[i] = v * A[i][i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
       float v = rhs[i];
 #pragma unroll
       for (int k = i + 1; k < 6; k++) v -= A[k][i] * rhs[k];
-      rhs[i] = v / A[i][i];
+      rhs[i] = v * A[i][i];
     }
-    SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
+    // rhs = root twist acceleration (w; v) in world axes; dof coordinates: trans = v, rot = RT w
 #pragma unroll
-    for (int i = 0; i < 6; i++) { x[i] = rhs[i]; t = t + rhs[i] * ldsv(s.S[i]); }
-    stsv(s.T[0], t);
+    for (int i = 0; i < 6; i++) s.T[0][i] = rhs[i];
+    x[0] = rhs[3]; x[1] = rhs[4]; x[2] = rhs[5];
+    const float* R = s.xmat[0];
+    x[3] = R[0] * rhs[0] + R[3] * rhs[1] + R[6] * rhs[2];
+    x[4] = R[1] * rhs[0] + R[4] * rhs[1] + R[7] * rhs[2];
+    x[5] = R[2] * rhs[0] + R[5] * rhs[1] + R[8] * rhs[2];
   }
   WSYNC();
-  if (lane < TP::NLEG) {
-    SV a = ldsv(s.T[0]);
+  {
+    float a = s.T[0][L.rr];
     for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + lane * TP::NBL + l;
-      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      const int b = 1 + L.lg * TP::NBL + l;
+      const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
       for (int j = adr; j < adr + num; ++j) {
-        float xj = (s.aba_u[j] - dot(ldsv(s.aba_U[j]), a)) * s.aba_invD[j];
-        x[j] = xj;
-        a = a + xj * ldsv(s.S[j]);
+        const float ua = grp8_sum(L.mask * s.aba_U[j][L.rr] * a);
+        const float xj = (s.aba_u[j] - ua) * s.aba_invD[j];
+        if (L.live && L.r == 0) x[j] = xj;
+        a += xj * s.S[j][L.rr];
       }
-      stsv(s.T[b], a);
+      if (L.live) s.T[b][L.r] = a;
     }
   }
   WSYNC();
@@ -559,30 +602,38 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
     s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_act[lane] = 0;
   }
 
-  // ---- velocities and bias wrenches (serial per leg), W[b] = −(I a_bias + v x* I v)
-  if (lane < TP::NLEG) {
-    SV v = SV{v3(0, 0, 0), v3(0, 0, 0)};
+  // ---- velocities and bias accelerations: three passes over the chains
+  {
+    const LaneRole L = lane_role<TP>(lane);
+    float(*vb)[6] = s.aba_U;                      // per dof: velocity before the dof, then Sdot*qd
+    // pass 1: component-wise prefix of velocities
+    float vt = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) v = v + s.qvel[j] * ldsv(s.S[j]);
-    SV vt = v;
-    SV a = SV{v3(0, 0, 0), v3(-m.gravity[0], -m.gravity[1], -m.gravity[2])};
+    for (int j = 0; j < 3; ++j) vt += s.qvel[j] * s.S[j][L.rr];
+    float v = vt;
 #pragma unroll
-    for (int j = 3; j < 6; ++j) {
-      SV Sj = ldsv(s.S[j]);
-      a = a + s.qvel[j] * cross_motion(vt, Sj);
-      v = v + s.qvel[j] * Sj;
-    }
-    if (lane == 0) { stsv(s.vel[0], v); stsv(s.T[0], a); }
+    for (int j = 3; j < 6; ++j) { if (lane < 6) vb[j][lane] = vt; v += s.qvel[j] * s.S[j][L.rr]; }
+    if (lane < 6) s.vel[0][lane] = v;
     for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + lane * TP::NBL + l;
+      int b = 1 + L.lg * TP::NBL + l;
       int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr; j < adr + num; ++j) {
-        SV Sj = ldsv(s.S[j]);
-        float qd = s.qvel[j];
-        a = a + qd * cross_motion(v, Sj);
-        v = v + qd * Sj;
-      }
-      stsv(s.vel[b], v); stsv(s.T[b], a);
+      for (int j = adr; j < adr + num; ++j) { if (L.live) vb[j][L.r] = v; v += s.qvel[j] * s.S[j][L.rr]; }
+      if (L.live) s.vel[b][L.r] = v;
+    }
+    WSYNC();
+    // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
+    for (int j = 3 + lane; j < TP::NV; j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
+    WSYNC();
+    // pass 3: component-wise prefix of bias accelerations (root parent acceleration = -gravity)
+    float a = L.rr >= 3 ? -m.gravity[L.rr - 3] : 0.f;
+#pragma unroll
+    for (int j = 3; j < 6; ++j) a += vb[j][L.rr];
+    if (lane < 6) s.T[0][lane] = a;
+    for (int l = 0; l < TP::NBL; ++l) {
+      int b = 1 + L.lg * TP::NBL + l;
+      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+      for (int j = adr; j < adr + num; ++j) a += vb[j][L.rr];
+      if (L.live) s.T[b][L.r] = a;
     }
   }
   WSYNC();
@@ -673,15 +724,17 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
       // gradient = Ma − qfrc_smooth − Jᵀ f
       contact_wrenches(s, c, fr, -1.0f, lane);
       sweep_project(s, s.W, grad, m, lane);
-      float gn = 0.f;
+      float gn = 0.f, gm = 0.f;
       for (int j = lane; j < TP::NV; j += kWave) {
-        float gj = grad[j] + Ma[j] - s.qfrc_smooth[j];
+        float jtf = grad[j], gj = jtf + Ma[j] - s.qfrc_smooth[j];
+        float mag = fabsf(Ma[j]) + fabsf(s.qfrc_smooth[j]) + fabsf(jtf);
         grad[j] = -gj;   // store the right-hand side of the Newton system
-        gn += gj * gj;
+        gn += gj * gj; gm += mag * mag;
       }
-      gn = wave_sum(gn);
+      gn = wave_sum(gn); gm = wave_sum(gm);
       WSYNC();
-      if (scale * sqrtf(gn) < m.tolerance) break;
+      // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
+      if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
       mul_M(s, search, Mv, m, lane);
@@ -722,7 +775,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
       iters = iter + 1;
       float improvement = cost - newcost;
       cost = newcost;
-      if (scale * improvement < m.tolerance) break;
+      if (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(cost)) break;
     }
     // constraint forces
     contact_wrenches(s, c, fr, 1.0f, lane);
@@ -818,8 +871,9 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
 
 // mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
 template <class TP>
-__global__ void __launch_bounds__(kWave) nmf_step_kernel(DevModel m, DevState st, ReplayArgs rp, int n_steps, int mode) {
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
+  const DevModel& m = *mp;
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= st.n_worlds) return;
   float time;
@@ -879,7 +933,7 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
 using FlyTopo = Topo<6, 8, 11>;      // LEGS_ONLY skeleton: 49 bodies, 72 dofs
 using FlyTopoActive = Topo<6, 4, 7>; // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
-template __global__ void nmf_step_kernel<FlyTopo>(DevModel, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoActive>(DevModel, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopo>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoActive>(const DevModel*, DevState, ReplayArgs, int, int);
 
 }  // namespace nmf

@@ -59,6 +59,9 @@ typedef float real;
 #endif
 
 #define NMF_MAXCON 64
+#ifndef NMF_NOISE_FACTOR
+#define NMF_NOISE_FACTOR 8
+#endif
 #define NMF_MINVAL 1e-15
 #define GEOM_CAPSULE 0
 #define GEOM_HULL 1
@@ -758,8 +761,16 @@ static void solve_constraints(const omodel* m, odata* d) {
         for (int k = 0; k <= j; k++) if (row[k] != 0) { d->H[j * nv + k] += s * row[k]; if (k != j) d->H[k * nv + j] += s * row[k]; }
       }
     }
-    real gn = 0; for (int j = 0; j < nv; j++) gn += grad[j] * grad[j];
-    if (scale * R_SQRT(gn) < m->tolerance) break;
+    /* stop when the gradient is below the tolerance OR at its own rounding-noise level:
+       grad is a sum of three vectors, so its noise floor is ~eps * |magnitudes| */
+    real gn = 0, gm = 0;
+    for (int j = 0; j < nv; j++) {
+      gn += grad[j] * grad[j];
+      real jtf = grad[j] - (Ma[j] - d->qfrc_smooth[j]);
+      real mag = R_FABS(Ma[j]) + R_FABS(d->qfrc_smooth[j]) + R_FABS(jtf);
+      gm += mag * mag;
+    }
+    if (scale * R_SQRT(gn) < m->tolerance || R_SQRT(gn) <= NMF_NOISE_FACTOR * R_EPS * R_SQRT(gm)) break;
     factor_tree(m, d->H, d->L, d->Ld);
     for (int j = 0; j < nv; j++) search[j] = -grad[j];
     solve_tree(m, d->L, d->Ld, search);
@@ -790,7 +801,7 @@ static void solve_constraints(const omodel* m, odata* d) {
     d->solver_iter = iter + 1;
     real improvement = cost - newcost;
     cost = newcost;
-    if (scale * improvement < m->tolerance) break;
+    if (scale * improvement < m->tolerance || improvement <= NMF_NOISE_FACTOR * R_EPS * R_FABS(cost)) break;
   }
   d->solver_cost = cost;
   for (int i = 0; i < nefc; i++) {
