@@ -176,6 +176,15 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 11 && model->star[3] == 8) topo = 0;
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 7 && model->star[3] == 4) topo = 1;
   if (topo < 0) { fail("nmf_batch_create: the HIP engine supports the LEGS_ONLY (6x8 bodies, 6x11 dofs) and LEGS_ACTIVE_ONLY (6x4, 6x7) skeletons"); return nullptr; }
+  {  // the kernels hard-wire the per-leg hinge layout; refuse anything else
+    const HostArray* dn = model->find("body_dofnum");
+    const int pat0[8] = {3, 2, 1, 1, 1, 1, 1, 1}, pat1[4] = {3, 2, 1, 1};
+    const int* pat = topo == 0 ? pat0 : pat1;
+    const int nbl = topo == 0 ? 8 : 4;
+    bool ok = dn && dn->is_int && (int)dn->i.size() == 1 + 6 * nbl && dn->i[0] == 6;
+    for (int b = 1; ok && b < 1 + 6 * nbl; ++b) ok = dn->i[(size_t)b] == pat[(b - 1) % nbl];
+    if (!ok) { fail("nmf_batch_create: unexpected hinge layout along the legs"); return nullptr; }
+  }
   if (model->ng > nmf::kWave) { fail("nmf_batch_create: more than 64 contact geoms"); return nullptr; }
   if (model->nu > nmf::kMaxCtrl) { fail("nmf_batch_create: more than 48 actuators"); return nullptr; }
   if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
@@ -320,3 +329,14 @@ extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int ta
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)ms / reps;
 }
+
+#ifdef NMF_STAGE_PROFILE
+// diagnostic build only: cumulative s_memtime cycles per pipeline stage of wave 0
+extern "C" int nmf_debug_stage_cycles(unsigned long long* out, int n, int reset) {
+  unsigned long long host[NMF_NSTAGE] = {};
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(nmf::g_stage_cycles), sizeof(host)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < NMF_NSTAGE; ++i) out[i] = host[i];
+  if (reset) { unsigned long long z[NMF_NSTAGE] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(nmf::g_stage_cycles), z, sizeof(z)); }
+  return 0;
+}
+#endif

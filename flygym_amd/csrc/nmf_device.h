@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace nmf {
 
 constexpr int kWave = 64;
@@ -18,14 +21,34 @@ constexpr float kMinVal = 1e-15f;
 enum { GEOM_CAPSULE = 0, GEOM_HULL = 1 };
 enum { ACT_POSITION = 0, ACT_ADHESION = 1, ACT_MOTOR = 2 };
 
-// Star-of-chains topology: one free root body + NLEG serial chains of NBL bodies / NDL hinges.
-template <int NLEG_, int NBL_, int NDL_>
+// Star-of-chains topology: one free root body + NLEG identical serial chains; DOFS... are the
+// hinge counts of the chain's bodies from the root outwards (LEGS_ONLY leg: 3,2,1,1,1,1,1,1).
+// Everything about the chain layout is a compile-time constant so that the leg sweeps unroll
+// completely and never load structure from memory.
+template <int NLEG_, int... DOFS>
 struct Topo {
-  static constexpr int NLEG = NLEG_, NBL = NBL_, NDL = NDL_;
-  static constexpr int NB = 1 + NLEG_ * NBL_;
-  static constexpr int NV = 6 + NLEG_ * NDL_;
+  static constexpr int NLEG = NLEG_;
+  static constexpr int NBL = sizeof...(DOFS);
+  static constexpr int NDL = (DOFS + ...);
+  static constexpr int NB = 1 + NLEG_ * NBL;
+  static constexpr int NV = 6 + NLEG_ * NDL;
   static constexpr int NQ = NV + 1;
+  static constexpr int dofs(int l) { constexpr int t[] = {DOFS...}; return t[l]; }
+  static constexpr int first_dof(int l) { int a = 0; for (int i = 0; i < l; ++i) a += dofs(i); return a; }
+  static constexpr int lbody(int d) { int a = 0; for (int l = 0; l < NBL; ++l) { a += dofs(l); if (d < a) return l; } return NBL - 1; }
+  static constexpr bool is_last(int d) { return d == first_dof(lbody(d)) + dofs(lbody(d)) - 1; }
+  static constexpr bool is_first(int d) { return d == first_dof(lbody(d)); }
 };
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// static_for<N>([&](auto I) { constexpr int i = decltype(I)::value; ... });
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 struct DevModel {
   int nb, nv, nq, nu, ng, nseg, nsite, nsensor, max_iter;
@@ -188,10 +211,23 @@ __device__ __forceinline__ float grp8_sum(float v) {
 }
 
 // ---------------------------------------------------------------- wave reductions
+// 64-lane sum on the VALU (DPP), result broadcast through an SGPR: no LDS-crossbar round trips.
+#define NMF_DPP_ROWS(v, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += NMF_DPP(v, 0xB1);            // xor 1
+  v += NMF_DPP(v, 0x4E);            // xor 2
+  v += NMF_DPP(v, 0x141);           // 8-lane halves
+  v += NMF_DPP(v, 0x140);           // row_mirror: every lane of a 16-lane row holds the row sum
+  v += NMF_DPP_ROWS(v, 0x142, 0xa); // row_bcast15 into rows 1 and 3
+  v += NMF_DPP_ROWS(v, 0x143, 0xc); // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// broadcast lane `i` (0..7) of every 8-lane group to the whole group (LDS crossbar, no memory)
+template <int I>
+__device__ __forceinline__ float grp8_bcast(float v) {
+  // ds_swizzle bit-mask mode: lane' = ((lane & and) | or) ^ xor over 32-lane halves
+  constexpr int pattern = 0x18 | (I << 5);
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pattern));
 }
 __device__ __forceinline__ void wave_argmin(float& v, int& i) {
 #pragma unroll

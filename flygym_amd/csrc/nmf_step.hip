@@ -25,6 +25,23 @@ namespace nmf {
 #define WSYNC() __syncthreads()
 constexpr float kNoiseFactor = 8.f;
 
+// Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
+// -DNMF_STAGE_PROFILE into a separate diagnostic library; the product build has no trace of it.
+#ifdef NMF_STAGE_PROFILE
+#define NMF_NSTAGE 24
+__device__ unsigned long long g_stage_cycles[NMF_NSTAGE];
+struct StageClock { unsigned long long last; };
+#define STAGE_INIT() StageClock sc_; sc_.last = clock64()
+#define STAGE_ARG , StageClock& sc_
+#define STAGE_PASS , sc_
+#define STAGE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sc_.last; sc_.last = t_; } } while (0)
+#else
+#define STAGE_INIT()
+#define STAGE_ARG
+#define STAGE_PASS
+#define STAGE(k)
+#endif
+
 template <class TP>
 struct __align__(16) FlyLds {
   float qpos[TP::NQ + 3];
@@ -39,6 +56,8 @@ struct __align__(16) FlyLds {
   float vel[TP::NB][6], T[TP::NB][6], W[TP::NB][6];
   float legIA[TP::NLEG][6][6], legpA[TP::NLEG][6];
   float rootA[6][6], rootb[6];
+  int dofbody[TP::NV];
+  float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_dist[kMaxCon], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];
   int c_geom[kMaxCon], c_body[kMaxCon], c_act[kMaxCon];
   int body_cstart[TP::NB + 1];
@@ -59,7 +78,7 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
 
 // ------------------------------------------------------------------ kinematics
 template <class TP>
-__device__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
   float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.aba_U[0][0]);
   float(*relq)[4] = reinterpret_cast<float(*)[4]>(&s.W[0][0]);
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.T[0][0]);
@@ -77,7 +96,9 @@ __device__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
   }
   WSYNC();
   for (int b = 1 + lane; b < TP::NB; b += kWave) {
-    int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    const int lb = (b - 1) % TP::NBL;
+    int adr = 6 + ((b - 1) / TP::NBL) * TP::NDL, num = 0;
+    static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
     Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
     for (int j = adr + num - 1; j >= adr; --j) {
       st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
@@ -107,7 +128,7 @@ __device__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
       S.a = v3(s.xmat[0][c], s.xmat[0][3 + c], s.xmat[0][6 + c]);
       S.l = v3(0.f, 0.f, 0.f);
     } else {
-      int b = m.dof_body[j];
+      int b = s.dofbody[j];
       V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
       V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
       S.a = a;
@@ -145,7 +166,7 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
 
 // ------------------------------------------------------------------ collision (geom vs ground plane)
 template <class TP>
-__device__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
   const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
   const float pd = m.plane[3];
   const V3 o = ld3(s.xpos[0]);
@@ -294,12 +315,12 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 #pragma unroll
   for (int j = 0; j < 6; ++j) t += x[j] * s.S[j][L.rr];
   if (lane < 6) T[0][lane] = t;
-  for (int l = 0; l < TP::NBL; ++l) {
-    int b = 1 + L.lg * TP::NBL + l;
-    int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-    for (int j = adr; j < adr + num; ++j) t += x[j] * s.S[j][L.rr];
-    if (L.live) T[b][L.r] = t;
-  }
+  const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
+  static_for<TP::NDL>([&](auto D) {
+    constexpr int d = decltype(D)::value;
+    t += x[j0 + d] * s.S[j0 + d][L.rr];
+    if constexpr (TP::is_last(d)) { if (L.live) T[b0 + TP::lbody(d)][L.r] = t; }
+  });
   WSYNC();
 }
 
@@ -307,12 +328,14 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 template <class TP>
 __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const DevModel& m, int lane) {
   const LaneRole L = lane_role<TP>(lane);
+  const int b0 = 1 + L.lg * TP::NBL;
   float acc = 0.f;
-  for (int l = TP::NBL - 1; l >= 0; --l) {
-    int b = 1 + L.lg * TP::NBL + l;
-    acc += W[b][L.rr];
-    if (L.live) W[b][L.r] = acc;
-  }
+  static_for<TP::NBL>([&](auto I) {
+    constexpr int l = TP::NBL - 1 - decltype(I)::value;
+    acc += W[b0 + l][L.rr];
+    if (L.live) W[b0 + l][L.r] = acc;
+  });
+  // root = own + the six leg bases (group sums are free: every group holds its base in acc)
   WSYNC();
   if (lane < 6) {
     float a0 = W[0][lane];
@@ -321,7 +344,7 @@ __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const De
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]]));
+  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[s.dofbody[j]]));
   WSYNC();
 }
 
@@ -332,7 +355,7 @@ __device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m
   for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
   WSYNC();
   sweep_project(s, s.W, y, m, lane);
-  for (int j = lane; j < TP::NV; j += kWave) y[j] += m.dof_armature[j] * x[j];
+  for (int j = lane; j < TP::NV; j += kWave) y[j] += s.arm[j] * x[j];
   WSYNC();
 }
 
@@ -382,40 +405,41 @@ __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& 
 //   root           : IA_root a = (wrench of tau_root) - pA_root, 6x6 Cholesky in one lane
 //   forward sweep  : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
 template <class TP>
-__device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK, float hdamp,
+__device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK, float hdamp,
                           const Frame& fr, const DevModel& m, int lane) {
   const LaneRole L = lane_role<TP>(lane);
+  const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
   {
     float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pA = 0.f;
-    for (int l = TP::NBL - 1; l >= 0; --l) {
-      const int b = 1 + L.lg * TP::NBL + l;
-      float row[6];
-      inertia_row(s.Ib[b], L.rr, row);
-      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+    static_for<TP::NDL>([&](auto DD) {
+      constexpr int d = TP::NDL - 1 - decltype(DD)::value;
+      const int j = j0 + d;
+      if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
+        const int b = b0 + TP::lbody(d);
+        float row[6];
+        inertia_row(s.Ib[b], L.rr, row);
+        if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
 #pragma unroll
-      for (int i = 0; i < 6; i++) IA[i] += row[i];
-      const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr + num - 1; j >= adr; --j) {
-        float sj[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
-        float U = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) U += IA[i] * sj[i];
-        const float sr = L.mask * s.S[j][L.rr];
-        const float D = grp8_sum(sr * U) + m.dof_armature[j] + hdamp * m.dof_damping[j];
-        const float sp = grp8_sum(sr * pA);
-        if (L.live) s.aba_U[j][L.r] = U;
-        const float invD = 1.0f / D, u = tau[j] - sp;
-        if (L.live && L.r == 0) { s.aba_u[j] = u; s.aba_invD[j] = invD; }
-        WSYNC();
-        const float k = U * invD;
-#pragma unroll
-        for (int i = 0; i < 6; i++) IA[i] -= k * s.aba_U[j][i];
-        pA += k * u;
+        for (int i = 0; i < 6; i++) IA[i] += row[i];
       }
-    }
+      float sj[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
+      float U = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) U += IA[i] * sj[i];
+      const float sr = L.mask * s.S[j][L.rr];
+      const float D = grp8_sum(sr * U) + s.arm[j] + hdamp * s.damp[j];
+      const float sp = grp8_sum(sr * pA);
+      if (L.live) s.aba_U[j][L.r] = U;
+      const float invD = 1.0f / D, u = tau[j] - sp;
+      if (L.live && L.r == 0) { s.aba_u[j] = u; s.aba_invD[j] = invD; }
+      const float k = U * invD;
+      IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
+      IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
+      pA += k * u;
+    });
     if (L.live) {
 #pragma unroll
       for (int i = 0; i < 6; i++) s.legIA[L.grp][L.r][i] = IA[i];
@@ -428,6 +452,7 @@ __device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK,
     inertia_row(s.Ib[0], lane, row);
     if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, lane, fr);
     float pA = 0.f;
+#pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
 #pragma unroll
       for (int i = 0; i < 6; i++) row[i] += s.legIA[k][lane][i];
@@ -491,17 +516,15 @@ __device__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK,
   WSYNC();
   {
     float a = s.T[0][L.rr];
-    for (int l = 0; l < TP::NBL; ++l) {
-      const int b = 1 + L.lg * TP::NBL + l;
-      const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr; j < adr + num; ++j) {
-        const float ua = grp8_sum(L.mask * s.aba_U[j][L.rr] * a);
-        const float xj = (s.aba_u[j] - ua) * s.aba_invD[j];
-        if (L.live && L.r == 0) x[j] = xj;
-        a += xj * s.S[j][L.rr];
-      }
-      if (L.live) s.T[b][L.r] = a;
-    }
+    static_for<TP::NDL>([&](auto DD) {
+      constexpr int d = decltype(DD)::value;
+      const int j = j0 + d;
+      const float ua = grp8_sum(L.mask * s.aba_U[j][L.rr] * a);
+      const float xj = (s.aba_u[j] - ua) * s.aba_invD[j];
+      if (L.live && L.r == 0) x[j] = xj;
+      a += xj * s.S[j][L.rr];
+      if constexpr (TP::is_last(d)) { if (L.live) s.T[b0 + TP::lbody(d)][L.r] = a; }
+    });
   }
   WSYNC();
 }
@@ -559,20 +582,28 @@ __device__ void contact_wrenches(FlyLds<TP>& s, const ContactRegs& c, const Fram
   }
   for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], SV{v3(0, 0, 0), v3(0, 0, 0)});
   WSYNC();
-  if (lane < 6) {
-    int ncon = s.ncon;
-    for (int cc = 0; cc < ncon; ++cc) s.W[s.c_body[cc]][lane] += s.c_w[cc][lane];
+  {
+    // contacts are sorted by body: group g < NLEG adds the contacts of leg g, group NLEG those of the root
+    const LaneRole L = lane_role<TP>(lane);
+    if (L.r < 6 && L.grp <= TP::NLEG) {
+      const int bfirst = L.grp < TP::NLEG ? 1 + L.grp * TP::NBL : 0;
+      const int blast = L.grp < TP::NLEG ? bfirst + TP::NBL : 1;
+      for (int cc = s.body_cstart[bfirst]; cc < s.body_cstart[blast]; ++cc) s.W[s.c_body[cc]][L.r] += s.c_w[cc][L.r];
+    }
   }
   WSYNC();
 }
 
 // ------------------------------------------------------------------ the step
 template <class TP>
-__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   stage_kinematics(s, m, lane);
+  STAGE(1);
   stage_inertia(s, m, lane);
+  STAGE(2);
   stage_collision(s, m, lane);
+  STAGE(3);
   const int ncon = s.ncon;
 
   // ---- contact parameters (lane c owns contact c)
@@ -602,9 +633,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
     s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_act[lane] = 0;
   }
 
+  STAGE(4);
   // ---- velocities and bias accelerations: three passes over the chains
   {
     const LaneRole L = lane_role<TP>(lane);
+    const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
     float(*vb)[6] = s.aba_U;                      // per dof: velocity before the dof, then Sdot*qd
     // pass 1: component-wise prefix of velocities
     float vt = 0.f;
@@ -614,12 +647,12 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
 #pragma unroll
     for (int j = 3; j < 6; ++j) { if (lane < 6) vb[j][lane] = vt; v += s.qvel[j] * s.S[j][L.rr]; }
     if (lane < 6) s.vel[0][lane] = v;
-    for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + L.lg * TP::NBL + l;
-      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr; j < adr + num; ++j) { if (L.live) vb[j][L.r] = v; v += s.qvel[j] * s.S[j][L.rr]; }
-      if (L.live) s.vel[b][L.r] = v;
-    }
+    static_for<TP::NDL>([&](auto D) {
+      constexpr int d = decltype(D)::value;
+      if (L.live) vb[j0 + d][L.r] = v;
+      v += s.qvel[j0 + d] * s.S[j0 + d][L.rr];
+      if constexpr (TP::is_last(d)) { if (L.live) s.vel[b0 + TP::lbody(d)][L.r] = v; }
+    });
     WSYNC();
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
     for (int j = 3 + lane; j < TP::NV; j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
@@ -629,12 +662,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
 #pragma unroll
     for (int j = 3; j < 6; ++j) a += vb[j][L.rr];
     if (lane < 6) s.T[0][lane] = a;
-    for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + L.lg * TP::NBL + l;
-      int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-      for (int j = adr; j < adr + num; ++j) a += vb[j][L.rr];
-      if (L.live) s.T[b][L.r] = a;
-    }
+    static_for<TP::NDL>([&](auto D) {
+      constexpr int d = decltype(D)::value;
+      a += vb[j0 + d][L.rr];
+      if constexpr (TP::is_last(d)) { if (L.live) s.T[b0 + TP::lbody(d)][L.r] = a; }
+    });
   }
   WSYNC();
   for (int b = lane; b < TP::NB; b += kWave) {
@@ -644,6 +676,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
   }
   for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = 0.f;  // direct actuator forces
   WSYNC();
+  STAGE(5);
   // ---- actuation
   for (int u = lane; u < m.nu; u += kWave) {
     float ctrl = s.ctrl[u];
@@ -677,8 +710,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
     s.qfrc_smooth[j] += passive + s.vA[j];
   }
   WSYNC();
+  STAGE(6);
   // ---- unconstrained acceleration
   aba_solve(s, s.qfrc_smooth, s.qacc_smooth, false, 0.f, fr, m, lane);
+  STAGE(7);
 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
@@ -720,6 +755,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
     }
     WSYNC();
     const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
+    STAGE(8);
     for (int iter = 0; iter < m.max_iter; ++iter) {
       // gradient = Ma − qfrc_smooth − Jᵀ f
       contact_wrenches(s, c, fr, -1.0f, lane);
@@ -735,12 +771,15 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
       WSYNC();
       // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
+      STAGE(9);
       aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
+      STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
       mul_M(s, search, Mv, m, lane);
       float g1 = 0.f, g2 = 0.f;
       for (int j = lane; j < TP::NV; j += kWave) { g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * Mv[j]; }
       g1 = wave_sum(g1); g2 = wave_sum(g2);
+      STAGE(11);
       // exact line search
       float alpha = 0.f, lo = 0.f, hi = -1.f;
       for (int ls = 0; ls < 30; ++ls) {
@@ -762,6 +801,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
         alpha = next;
         if (change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
       }
+      STAGE(12);
       if (alpha <= 0.f) break;
       for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] += alpha * search[j]; Ma[j] += alpha * Mv[j]; }
       if (c.on) {
@@ -773,15 +813,18 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
       for (int j = lane; j < TP::NV; j += kWave) gq += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
       float newcost = wave_sum(gq) + constraint_cost<TP>(c);
       iters = iter + 1;
+      STAGE(13);
       float improvement = cost - newcost;
       cost = newcost;
       if (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(cost)) break;
     }
+    STAGE(9);
     // constraint forces
     contact_wrenches(s, c, fr, 1.0f, lane);
     sweep_project(s, s.W, s.qfrc_con, m, lane);
   }
   if (lane == 0) s.iters = iters;
+  STAGE(14);
 
   // ---- contact sensors (oracle contact_sensors): c_w holds the world-frame contact wrenches about o
   for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
@@ -809,10 +852,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane) {
     }
   }
   WSYNC();
+  STAGE(17);
 }
 
 template <class TP>
-__device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   for (int j = lane; j < TP::NV; j += kWave) { s.qacc_ws[j] = s.qacc[j]; s.vA[j] = s.qfrc_smooth[j] + s.qfrc_con[j]; }
@@ -876,6 +920,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   const DevModel& m = *mp;
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= st.n_worlds) return;
+  STAGE_INIT();
+  for (int j = lane; j < TP::NV; j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; s.dofbody[j] = m.dof_body[j]; }
   float time;
   if (mode == 1) {
     for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = m.key_qpos[i];
@@ -902,12 +948,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int a = lane; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
         WSYNC();
       }
-      physics_forward(s, m, lane);
-      physics_integrate(s, m, lane);
+      STAGE(0);
+      physics_forward(s, m, lane STAGE_PASS);
+      physics_integrate(s, m, lane STAGE_PASS);
+      STAGE(15);
       time += m.timestep;
     }
   }
   write_outputs(s, m, st, w, lane, time);
+  STAGE(16);
 }
 
 // Indexed gather / scatter in caller order (replaces the reference's Warp kernels,
@@ -930,8 +979,8 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
   }
 }
 
-using FlyTopo = Topo<6, 8, 11>;      // LEGS_ONLY skeleton: 49 bodies, 72 dofs
-using FlyTopoActive = Topo<6, 4, 7>; // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
+using FlyTopo = Topo<6, 3, 2, 1, 1, 1, 1, 1, 1>;   // LEGS_ONLY skeleton: 49 bodies, 72 dofs
+using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
 template __global__ void nmf_step_kernel<FlyTopo>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopoActive>(const DevModel*, DevState, ReplayArgs, int, int);

@@ -1,0 +1,39 @@
+"""Per-stage cycle breakdown of the step kernel (diagnostic build, run through gpurun)."""
+import ctypes, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+from flygym_amd import _native
+lib_prof = ROOT / "flygym_amd" / "libnmf_hip_prof.so"
+if "--build" in sys.argv or not lib_prof.exists():
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNMF_STAGE_PROFILE",
+                    f"-I{ROOT/'include'}", f"-I{ROOT/'flygym_amd/csrc'}", str(ROOT/"flygym_amd/csrc/nmf_capi.hip"), "-o", str(lib_prof)], check=True)
+    if "--build" in sys.argv: sys.exit(0)
+_native.LIB_PATH = lib_prof
+from flygym_amd import HIPSimulation, make_model
+from flygym_amd.compose import ActuatorType
+from flygym_amd.replay import ReplayTargetData
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
+fly, world, _ = make_model()
+sim = HIPSimulation(world, n_worlds=n, device=0)
+L = _native.lib()
+L.nmf_debug_stage_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
+table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_worlds(n, 1000), device=sim.device)
+ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
+sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+sim.step(500); torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 24)()
+L.nmf_debug_stage_cycles(buf, 24, 1)
+steps = 500
+sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
+L.nmf_debug_stage_cycles(buf, 24, 1)
+names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
+         "ABA smooth", "solver init", "newton: wrench+grad", "newton: ABA(H)", "newton: M*search+jv", "newton: linesearch",
+         "newton: update+cost", "final forces", "integrate (ABA Euler)", "write outputs", "sensors"]
+cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
+tot = cyc.sum()
+print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
+for nm, c in zip(names, cyc):
+    print(f"  {nm:24s} {c:9.0f}  {100*c/tot:5.1f}%")
