@@ -30,35 +30,36 @@ constexpr float kNoiseFactor = 8.f;
 #ifdef NMF_STAGE_PROFILE
 #define NMF_NSTAGE 24
 __device__ unsigned long long g_stage_cycles[NMF_NSTAGE];
-struct StageClock { unsigned long long last; };
-#define STAGE_INIT() StageClock sc_; sc_.last = clock64()
+struct StageClock { unsigned long long last; unsigned long long* acc; };
+#define STAGE_INIT() __shared__ unsigned long long stage_acc_[NMF_NSTAGE]; StageClock sc_; sc_.acc = stage_acc_; \
+  if (threadIdx.x < NMF_NSTAGE) stage_acc_[threadIdx.x] = 0; __syncthreads(); sc_.last = clock64()
+#define STAGE_FLUSH() do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < NMF_NSTAGE) g_stage_cycles[threadIdx.x] += stage_acc_[threadIdx.x]; } while (0)
 #define STAGE_ARG , StageClock& sc_
 #define STAGE_PASS , sc_
-#define STAGE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sc_.last; sc_.last = t_; } } while (0)
+#define STAGE(k) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sc_.acc[k] += t_ - sc_.last; sc_.last = clock64(); } } while (0)
 #else
 #define STAGE_INIT()
 #define STAGE_ARG
 #define STAGE_PASS
 #define STAGE(k)
+#define STAGE_FLUSH()
 #endif
 
 template <class TP>
 struct __align__(16) FlyLds {
   float qpos[TP::NQ + 3];
-  float qvel[TP::NV], qacc_ws[TP::NV], qacc[TP::NV], qacc_smooth[TP::NV], qfrc_smooth[TP::NV],
-      qfrc_con[TP::NV];
+  float qvel[TP::NV], qacc[TP::NV], qacc_smooth[TP::NV], qfrc_smooth[TP::NV];   // qacc doubles as the warm start
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float aba_u[TP::NV], aba_invD[TP::NV], aba_U[TP::NV][6];
   float ctrl[kMaxCtrl], act_force[kMaxCtrl];
   float xpos[TP::NB][3], xquat[TP::NB][4], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];
-  float vel[TP::NB][6], T[TP::NB][6], W[TP::NB][6];
+  float T[TP::NB][6], W[TP::NB][6];     // body twists / wrenches (velocities live in W until the bias stage)
   float legIA[TP::NLEG][6][6], legpA[TP::NLEG][6];
   float rootA[6][6], rootb[6];
-  int dofbody[TP::NV];
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
-  float c_r[kMaxCon][3], c_dist[kMaxCon], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];
+  float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];   // c_D holds the distance until setup
   int c_geom[kMaxCon], c_body[kMaxCon], c_act[kMaxCon];
   int body_cstart[TP::NB + 1];
   float sens[96];
@@ -74,6 +75,15 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
   float l = sqrtf(dot(t1, t1));
   t1 = (1.0f / l) * t1;
   return Frame{n, t1, cross(n, t1)};
+}
+
+template <class TP>
+__device__ __forceinline__ int dof_body_of(int j) {
+  if (j < 6) return 0;
+  const int leg = (j - 6) / TP::NDL, d = (j - 6) % TP::NDL;
+  int lb = 0;
+  static_for<TP::NBL - 1>([&](auto I) { constexpr int l = decltype(I)::value; lb += d >= TP::first_dof(l + 1) ? 1 : 0; });
+  return 1 + leg * TP::NBL + lb;
 }
 
 // ------------------------------------------------------------------ kinematics
@@ -128,7 +138,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       S.a = v3(s.xmat[0][c], s.xmat[0][3 + c], s.xmat[0][6 + c]);
       S.l = v3(0.f, 0.f, 0.f);
     } else {
-      int b = s.dofbody[j];
+      int b = dof_body_of<TP>(j);
       V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
       V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
       S.a = a;
@@ -200,7 +210,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
       int slot = ncon + __popcll(vm & ((1ull << lane) - 1ull));
       if (valid) {
         if (slot < kMaxCon) {
-          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_dist[slot] = dist;
+          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_D[slot] = dist;
           st3(s.c_r[slot], (ps - (0.5f * dist) * n) - o);
         } else overflow = 1;
       }
@@ -267,7 +277,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
           V3 v = ld3(V + 3 * vi);
           float dist = dot(nb, v) + c0;
           V3 pw = mat_vec(R, v) + xp;
-          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_dist[slot] = dist;
+          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_D[slot] = dist;
           st3(s.c_r[slot], (pw - (0.5f * dist) * n) - o);
         } else overflow = 1;
       }
@@ -344,7 +354,7 @@ __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const De
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[s.dofbody[j]]));
+  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[dof_body_of<TP>(j)]));
   WSYNC();
 }
 
@@ -610,7 +620,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   ContactRegs c;
   c.on = lane < ncon;
   if (c.on) {
-    c.r = ld3(s.c_r[lane]); c.body = s.c_body[lane]; c.geom = s.c_geom[lane]; c.dist = s.c_dist[lane];
+    c.r = ld3(s.c_r[lane]); c.body = s.c_body[lane]; c.geom = s.c_geom[lane]; c.dist = s.c_D[lane];
     int g = c.geom;
     c.mu = m.pair_friction[5 * g];
     c.margin = m.pair_margin[g];
@@ -646,14 +656,22 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
     float v = vt;
 #pragma unroll
     for (int j = 3; j < 6; ++j) { if (lane < 6) vb[j][lane] = vt; v += s.qvel[j] * s.S[j][L.rr]; }
-    if (lane < 6) s.vel[0][lane] = v;
+    if (lane < 6) s.W[0][lane] = v;
     static_for<TP::NDL>([&](auto D) {
       constexpr int d = decltype(D)::value;
       if (L.live) vb[j0 + d][L.r] = v;
       v += s.qvel[j0 + d] * s.S[j0 + d][L.rr];
-      if constexpr (TP::is_last(d)) { if (L.live) s.vel[b0 + TP::lbody(d)][L.r] = v; }
+      if constexpr (TP::is_last(d)) { if (L.live) s.W[b0 + TP::lbody(d)][L.r] = v; }
     });
     WSYNC();
+    // reference acceleration of the contact rows needs the body velocities (still in W here)
+    if (c.on) {
+      float velrow[4];
+      rows_of_twist(c, fr, ldsv(s.W[c.body]), velrow);
+      const float rr0 = c.dist - c.margin;
+#pragma unroll
+      for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
+    }
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
     for (int j = 3 + lane; j < TP::NV; j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
     WSYNC();
@@ -670,7 +688,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   }
   WSYNC();
   for (int b = lane; b < TP::NB; b += kWave) {
-    SV v = ldsv(s.vel[b]);
+    SV v = ldsv(s.W[b]);
     SV f = inert_mul(s.Ib[b], ldsv(s.T[b])) + cross_force(v, inert_mul(s.Ib[b], v));
     stsv(s.W[b], -1.0f * f);
   }
@@ -718,25 +736,17 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
   if (ncon == 0) {
-    for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.qfrc_con[j] = 0.f; }
+    for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
     float* Ma = s.vC; float* grad = s.vA; float* search = s.vB; float* Mv = s.vD;
-    // reference acceleration from the velocity twists
-    if (c.on) {
-      float vel[4];
-      rows_of_twist(c, fr, ldsv(s.vel[c.body]), vel);
-      float r = c.dist - c.margin;
-#pragma unroll
-      for (int k = 0; k < 4; k++) c.aref[k] = -c.B * vel[k] - c.K * c.imp * r;
-    }
     // candidate 1: warm start
-    mul_M(s, s.qacc_ws, Ma, m, lane);
+    mul_M(s, s.qacc, Ma, m, lane);                  // qacc still holds the warm start
     if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
     float g = 0.f;
-    for (int j = lane; j < TP::NV; j += kWave) g += 0.5f * (s.qacc_ws[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
+    for (int j = lane; j < TP::NV; j += kWave) g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
     float cost = wave_sum(g) + constraint_cost<TP>(c);
     // candidate 2: unconstrained acceleration
     sweep_twists(s, s.qacc_smooth, s.T, m, lane);
@@ -750,8 +760,6 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] = c2.jar[k];
       for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Ma[j] = s.qfrc_smooth[j]; }
-    } else {
-      for (int j = lane; j < TP::NV; j += kWave) s.qacc[j] = s.qacc_ws[j];
     }
     WSYNC();
     const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
@@ -821,7 +829,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
     STAGE(9);
     // constraint forces
     contact_wrenches(s, c, fr, 1.0f, lane);
-    sweep_project(s, s.W, s.qfrc_con, m, lane);
+    sweep_project(s, s.W, s.vD, m, lane);           // qfrc_constraint lives in vD until the Euler step
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);
@@ -859,7 +867,7 @@ template <class TP>
 __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
-  for (int j = lane; j < TP::NV; j += kWave) { s.qacc_ws[j] = s.qacc[j]; s.vA[j] = s.qfrc_smooth[j] + s.qfrc_con[j]; }
+  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
   WSYNC();
   aba_solve(s, s.vA, s.vB, false, h, fr, m, lane);
   for (int j = lane; j < TP::NV; j += kWave) s.qvel[j] += h * s.vB[j];
@@ -886,7 +894,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
   for (int i = lane; i < TP::NQ; i += kWave) st.qpos[(size_t)w * TP::NQ + i] = s.qpos[i];
   for (int i = lane; i < TP::NV; i += kWave) {
     st.qvel[(size_t)w * TP::NV + i] = s.qvel[i];
-    st.qacc_ws[(size_t)w * TP::NV + i] = s.qacc_ws[i];
+    st.qacc_ws[(size_t)w * TP::NV + i] = s.qacc[i];
     st.qacc[(size_t)w * TP::NV + i] = s.qacc[i];
   }
   for (int i = lane; i < m.nu; i += kWave) {
@@ -921,11 +929,11 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= st.n_worlds) return;
   STAGE_INIT();
-  for (int j = lane; j < TP::NV; j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; s.dofbody[j] = m.dof_body[j]; }
+  for (int j = lane; j < TP::NV; j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
   float time;
   if (mode == 1) {
     for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = m.key_qpos[i];
-    for (int i = lane; i < TP::NV; i += kWave) { s.qvel[i] = 0.f; s.qacc_ws[i] = 0.f; s.qacc[i] = 0.f; }
+    for (int i = lane; i < TP::NV; i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
     for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; s.act_force[i] = 0.f; }
     for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
     if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
@@ -936,7 +944,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = st.qpos[(size_t)w * TP::NQ + i];
     for (int i = lane; i < TP::NV; i += kWave) {
       s.qvel[i] = st.qvel[(size_t)w * TP::NV + i];
-      s.qacc_ws[i] = st.qacc_ws[(size_t)w * TP::NV + i];
+      s.qacc[i] = st.qacc_ws[(size_t)w * TP::NV + i];
     }
     for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = st.ctrl[(size_t)w * m.nu + i];
     time = st.time[w];
@@ -957,6 +965,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   write_outputs(s, m, st, w, lane, time);
   STAGE(16);
+  STAGE_FLUSH();
 }
 
 // Indexed gather / scatter in caller order (replaces the reference's Warp kernels,
