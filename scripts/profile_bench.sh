@@ -1,13 +1,20 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): rocprofv3 kernel trace + stats of the default bench command.
+# Run on the GPU box (through gpurun).  rocprofv3 passes over the default bench command:
+#   1. --kernel-trace --stats            (durations)
+#   2. --pmc FETCH_SIZE                  (HBM read bytes;  own pass, kernel-trace only)
+#   3. --pmc WRITE_SIZE                  (HBM write bytes; own pass)
+#   4. --pmc SQ_* issue/wait counters    (own pass)
 # usage: scripts/profile_bench.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- \
-  python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
-ls -la "$OUT"
-cat "$OUT"/*kernel_stats.csv
-grep '"metric"' "$OUT/bench.log" | cut -c1-600
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- $BENCH > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$TAG" -- $BENCH > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$TAG" -- $BENCH > "$OUT/bench_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o "$TAG" -- $BENCH > "$OUT/bench_sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -o "$TAG" -- $BENCH > "$OUT/bench_sq2.log" 2>&1
+find "$OUT" -name "*.csv" | head -30
+grep -h '"metric"' "$OUT"/bench_*.log | cut -c1-160

@@ -1,0 +1,99 @@
+"""Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into profiles/<tag>_*.{csv,md}.
+
+The step kernel is launched once per control tick; the bench's timed region is the LAST
+`steps/steps_per_launch` launches of nmf_step_kernel in the trace (earlier ones are the reset, the
+500-step warm-up and one settle tick), so the summary reports both the all-launch rocprofv3 stats and
+the timed-region mean that bench.py's `roofline.kernel_ms_per_launch` must agree with.
+"""
+import csv, json, re, shutil, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1]
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+
+def find(sub, suffix):
+    hits = sorted((src / sub).rglob(f"*{suffix}"))
+    return hits[0] if hits else None
+
+
+def bench_line(log):
+    for line in (src / log).read_text().splitlines():
+        if line.startswith('{"metric"'):
+            return json.loads(line)
+    return None
+
+
+out = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline` on 1x MI355X\n"]
+b = bench_line("bench_trace.log")
+n_launch = b["steps"] // b["config"]["steps_per_launch"]
+out.append(f"bench line under the tracer: value {b['value']:.4e} env-steps/s, kernel_ms_per_launch "
+           f"{b['roofline']['kernel_ms_per_launch']:.3f} ms ({b['config']['steps_per_launch']} steps x {b['config']['worlds_per_gpu']} worlds per launch), "
+           f"timed region = last {n_launch} launches\n")
+
+stats = find("trace", "kernel_stats.csv")
+shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
+out.append("## `--kernel-trace --stats` (all launches of the process)\n\n| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
+for row in csv.DictReader(open(stats)):
+    name = re.sub(r"\(.*", "", row["Name"])[:70]
+    if float(row["Percentage"]) > 0.01:
+        out.append(f"| `{name}` | {row['Calls']} | {float(row['TotalDurationNs'])/1e6:.3f} | {float(row['AverageNs'])/1e6:.4f} | {float(row['Percentage']):.2f} |")
+
+trace = find("trace", "kernel_trace.csv")
+rows = [r for r in csv.DictReader(open(trace)) if "nmf_step_kernel" in r["Kernel_Name"]]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+timed = dur[-n_launch:]
+out.append(f"\n## step-kernel launches in dispatch order (ms)\n\n`{[round(d, 3) for d in dur]}`\n")
+out.append(f"timed-region mean over the last {n_launch} launches: **{sum(timed)/len(timed):.3f} ms** "
+           f"(bench.py HIP-event mean: {b['roofline']['kernel_ms_per_launch']:.3f} ms)\n")
+r0 = rows[-1]
+out.append(f"resources: VGPR {r0.get('VGPR_Count', r0.get('Arch_VGPR_Count','?'))}, accum VGPR {r0.get('Accum_VGPR_Count','?')}, SGPR {r0.get('SGPR_Count','?')}, "
+           f"LDS {r0.get('LDS_Block_Size','?')} B/block, scratch {r0.get('Scratch_Size', r0.get('Private_Segment_Size','?'))} B, grid {r0.get('Grid_Size','?')}, workgroup {r0.get('Workgroup_Size','?')}\n")
+
+
+def counters(sub):
+    f = find(sub, "counter_collection.csv")
+    if not f:
+        return {}
+    acc = {}
+    rows = [r for r in csv.DictReader(open(f)) if "nmf_step_kernel" in r["Kernel_Name"]]
+    by_disp = {}
+    for r in rows:
+        by_disp.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    disp = list(by_disp.values())[-n_launch:]
+    for d in disp:
+        for k, v in d.items():
+            acc[k] = acc.get(k, 0.0) + v / len(disp)
+    return acc
+
+
+fetch, write = counters("pmc_fetch"), counters("pmc_write")
+traffic = None
+if fetch and write:
+    fk, wk = fetch.get("FETCH_SIZE", 0.0), write.get("WRITE_SIZE", 0.0)
+    # MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on
+    # gfx950 (this kernel's reads are dword-wide, so the x2 is an upper bound); WRITE_SIZE uncalibrated.
+    traffic = (2 * fk + wk) * 1024
+    algo = 1928 * b["config"]["worlds_per_gpu"] * b["config"]["steps_per_launch"]
+    out.append(f"## HBM traffic per timed launch (PMC, separate passes)\n\nFETCH_SIZE {fk:.1f} KiB (x2 gfx950 correction -> {2*fk*1024/1e6:.2f} MB), "
+               f"WRITE_SIZE {wk:.1f} KiB ({wk*1024/1e6:.2f} MB) -> traffic **{traffic/1e6:.2f} MB** per launch; algorithmic bytes "
+               f"(1928 B x worlds x steps) = {algo/1e6:.2f} MB; compulsory state+table traffic of a {b['config']['steps_per_launch']}-step persistent launch = "
+               f"{(1928 + 168*b['config']['steps_per_launch']) * b['config']['worlds_per_gpu']/1e6:.2f} MB\n")
+sq = {**counters("pmc_sq"), **counters("pmc_sq2")}
+if sq:
+    out.append("## SQ counters per timed launch (mean)\n\n| counter | value |\n|---|---|")
+    for k in sorted(sq):
+        out.append(f"| {k} | {sq[k]:.4g} |")
+    if "SQ_WAVE_CYCLES" in sq and sq["SQ_WAVE_CYCLES"]:
+        wc = sq["SQ_WAVE_CYCLES"]
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+            if k in sq:
+                out.append(f"| {k} / SQ_WAVE_CYCLES | {sq[k]/wc:.3f} |")
+    out.append("")
+(dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
+(dst / f"{tag}_bench.json").write_text(json.dumps(b, indent=1) + "\n")
+print("\n".join(out))
+print("traffic bytes per launch:", traffic)
