@@ -89,7 +89,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world_size
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    # NMF_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, all-gather, barrier, max-reduce)
+    # even with one rank, so it can be validated on a single-GPU box
+    use_dist = world_size > 1 or bool(os.environ.get("NMF_BENCH_FORCE_DIST"))
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -114,7 +121,7 @@ def main():
         sim.step(args.warmup)   # reference: sim.warmup() = 500 steps at the neutral targets
 
     obs_local = torch.empty((n_local, OBS_DIM), dtype=torch.float32, device=sim.device)
-    obs_all = torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) if world_size > 1 else None
+    obs_all = torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) if use_dist else None
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
@@ -124,7 +131,7 @@ def main():
         ev0[k].record()
         sim.step_replay(table, act_ids, start, spl)
         ev1[k].record()
-        if world_size > 1:
+        if use_dist:
             obs_local[:, 0:66] = sim.field("qpos")[:, 7:]
             obs_local[:, 66:132] = sim.field("qvel")[:, 6:]
             obs_local[:, 132:174] = sim.field("actuator_force")[:, :42]
@@ -134,18 +141,18 @@ def main():
     # untimed: one tick to settle allocator / RCCL channels
     control_tick(0)
     torch.cuda.synchronize()
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(n_launches):
         control_tick(spl * (k + 1), k)
     torch.cuda.synchronize()
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world_size > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=sim.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -172,7 +179,7 @@ def main():
                               "(reference benchmark protocol), adhesion on",
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
                 "timestep": sim.timestep, "realtime_factor": value * sim.timestep,
-                "parallelism": f"env-shard x{world_size}" + (", RCCL all-gather of obs per control tick" if world_size > 1 else ""),
+                "parallelism": f"env-shard x{world_size}" + (", RCCL all-gather of obs per control tick" if use_dist else ""),
                 "state_finite": finite, "contact_overflow_worlds": overflow,
                 "mean_contacts": float(stats[:, 0].mean().item()), "mean_newton_iters": float(stats[:, 1].mean().item()),
             },
@@ -188,10 +195,12 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), replay.dof_angles[:table_steps].astype(np.float32),
                                                np.arange(42, dtype=np.int32), args.warmup, args.cpu_steps)
-        print(json.dumps(out))
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
