@@ -192,7 +192,7 @@ def main():
                         "see DESIGN.md for the instruction-side analysis",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), replay.dof_angles[:table_steps].astype(np.float32),
                                                np.arange(42, dtype=np.int32), args.warmup, args.cpu_steps)
     if use_dist:
