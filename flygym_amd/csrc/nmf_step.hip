@@ -358,10 +358,11 @@ __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const De
   WSYNC();
 }
 
-// y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x)
+// y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x).
+// have_twists: T already holds twists(x) (the ABA leaves them there).
 template <class TP>
-__device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m, int lane) {
-  sweep_twists(s, x, s.T, m, lane);
+__device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m, int lane, bool have_twists = false) {
+  if (!have_twists) sweep_twists(s, x, s.T, m, lane);
   for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
   WSYNC();
   sweep_project(s, s.W, y, m, lane);
@@ -443,7 +444,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
       const float D = grp8_sum(sr * U) + s.arm[j] + hdamp * s.damp[j];
       const float sp = grp8_sum(sr * pA);
       if (L.live) s.aba_U[j][L.r] = U;
-      const float invD = 1.0f / D, u = tau[j] - sp;
+      float invD = __builtin_amdgcn_rcpf(D);
+      invD = invD * (2.0f - D * invD);
+      const float u = tau[j] - sp;
       if (L.live && L.r == 0) { s.aba_u[j] = u; s.aba_invD[j] = invD; }
       const float k = U * invD;
       IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
@@ -555,6 +558,7 @@ __device__ __forceinline__ float impedance(const float* si, float r) {
   if (x >= 1.f) y = 1.f;
   else if (x <= 0.f) y = 0.f;
   else if (power == 1.f) y = x;
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (dmax - d0);
@@ -577,9 +581,12 @@ __device__ float constraint_cost(const ContactRegs& c) {
   return wave_sum(v);
 }
 
-// W[b] = − Σ_{contacts c on b} Σ_k f_k l_k   (deterministic order), f_k = −D jar_k on active rows
+// out = sign * JT f  for the contact forces f_k = −D jar_k on the active rows: every contact lane
+// publishes its world wrench (about the root origin) in c_w, then the leg groups suffix-sum the
+// wrenches of their bodies' contacts (contacts are sorted by body) and the dofs project.
 template <class TP>
-__device__ void contact_wrenches(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign, int lane) {
+__device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign, float* out,
+                                const DevModel& m, int lane) {
   if (c.on) {
     float f[4]; int act = 0;
 #pragma unroll
@@ -590,17 +597,28 @@ __device__ void contact_wrenches(FlyLds<TP>& s, const ContactRegs& c, const Fram
     stsv(s.c_w[lane], sign * w);
     s.c_act[lane] = act;
   }
-  for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], SV{v3(0, 0, 0), v3(0, 0, 0)});
   WSYNC();
-  {
-    // contacts are sorted by body: group g < NLEG adds the contacts of leg g, group NLEG those of the root
-    const LaneRole L = lane_role<TP>(lane);
-    if (L.r < 6 && L.grp <= TP::NLEG) {
-      const int bfirst = L.grp < TP::NLEG ? 1 + L.grp * TP::NBL : 0;
-      const int blast = L.grp < TP::NLEG ? bfirst + TP::NBL : 1;
-      for (int cc = s.body_cstart[bfirst]; cc < s.body_cstart[blast]; ++cc) s.W[s.c_body[cc]][L.r] += s.c_w[cc][L.r];
-    }
+  const LaneRole L = lane_role<TP>(lane);
+  const int b0 = 1 + L.lg * TP::NBL;
+  float acc = 0.f;
+  int cend = s.body_cstart[b0 + TP::NBL];
+  static_for<TP::NBL>([&](auto I) {
+    constexpr int l = TP::NBL - 1 - decltype(I)::value;
+    const int cbeg = s.body_cstart[b0 + l];
+    for (int cc = cbeg; cc < cend; ++cc) acc += s.c_w[cc][L.rr];
+    cend = cbeg;
+    if (L.live) s.W[b0 + l][L.r] = acc;
+  });
+  WSYNC();
+  if (lane < 6) {
+    float a0 = 0.f;
+    for (int cc = s.body_cstart[0]; cc < s.body_cstart[1]; ++cc) a0 += s.c_w[cc][lane];
+#pragma unroll
+    for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[1 + k * TP::NBL][lane];
+    s.W[0][lane] = a0;
   }
+  WSYNC();
+  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)]));
   WSYNC();
 }
 
@@ -622,6 +640,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   if (c.on) {
     c.r = ld3(s.c_r[lane]); c.body = s.c_body[lane]; c.geom = s.c_geom[lane]; c.dist = s.c_D[lane];
     int g = c.geom;
+    s.c_geom[lane] = g | ((m.geom_sensor[g] + 1) << 8);     // low byte: geom, next byte: leg sensor + 1
     c.mu = m.pair_friction[5 * g];
     c.margin = m.pair_margin[g];
     const float* solref = &m.pair_solref[2 * g];
@@ -766,8 +785,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
     STAGE(8);
     for (int iter = 0; iter < m.max_iter; ++iter) {
       // gradient = Ma − qfrc_smooth − Jᵀ f
-      contact_wrenches(s, c, fr, -1.0f, lane);
-      sweep_project(s, s.W, grad, m, lane);
+      contact_project(s, c, fr, -1.0f, grad, m, lane);
       float gn = 0.f, gm = 0.f;
       for (int j = lane; j < TP::NV; j += kWave) {
         float jtf = grad[j], gj = jtf + Ma[j] - s.qfrc_smooth[j];
@@ -783,7 +801,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
       aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
-      mul_M(s, search, Mv, m, lane);
+      mul_M(s, search, Mv, m, lane, true);
       float g1 = 0.f, g2 = 0.f;
       for (int j = lane; j < TP::NV; j += kWave) { g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * Mv[j]; }
       g1 = wave_sum(g1); g2 = wave_sum(g2);
@@ -828,8 +846,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
     }
     STAGE(9);
     // constraint forces
-    contact_wrenches(s, c, fr, 1.0f, lane);
-    sweep_project(s, s.W, s.vD, m, lane);           // qfrc_constraint lives in vD until the Euler step
+    contact_project(s, c, fr, 1.0f, s.vD, m, lane);   // qfrc_constraint lives in vD until the Euler step
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);
@@ -840,7 +857,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   if (m.nsensor && lane < 6 && ncon > 0) {
     float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
     for (int cc = 0; cc < ncon; ++cc) {
-      if (m.geom_sensor[s.c_geom[cc]] != lane) continue;
+      if ((s.c_geom[cc] >> 8) - 1 != lane) continue;
       V3 f = ld3(&s.c_w[cc][3]);
       float fn = dot(f, fr.n);
       V3 p = ld3(s.c_r[cc]);
@@ -849,7 +866,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
     if (cnt) {
       pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
       for (int cc = 0; cc < ncon; ++cc) {
-        if (m.geom_sensor[s.c_geom[cc]] != lane) continue;
+        if ((s.c_geom[cc] >> 8) - 1 != lane) continue;
         V3 f = ld3(&s.c_w[cc][3]);
         F = F + f;
         Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
