@@ -229,19 +229,40 @@ __device__ __forceinline__ float grp8_bcast(float v) {
   constexpr int pattern = 0x18 | (I << 5);
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pattern));
 }
+// wave-wide min / max on the VALU (same DPP ladder as wave_sum); `idn` is the identity fed to the
+// rows a row_bcast step does not write
+#define NMF_DPP_OLD(old, v, ctrl, rows) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rows), 0xf, false)
+template <class Op>
+__device__ __forceinline__ int wave_reduce_bits(int v, int idn, Op op) {
+  v = op(v, NMF_DPP_OLD(idn, v, 0xB1, 0xf));
+  v = op(v, NMF_DPP_OLD(idn, v, 0x4E, 0xf));
+  v = op(v, NMF_DPP_OLD(idn, v, 0x141, 0xf));
+  v = op(v, NMF_DPP_OLD(idn, v, 0x140, 0xf));
+  v = op(v, NMF_DPP_OLD(idn, v, 0x142, 0xa));
+  v = op(v, NMF_DPP_OLD(idn, v, 0x143, 0xc));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_min(float v) {
+  return __builtin_bit_cast(float, wave_reduce_bits(__builtin_bit_cast(int, v), 0x7f800000, [](int a, int b) {
+    return __builtin_bit_cast(int, fminf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); }));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  return __builtin_bit_cast(float, wave_reduce_bits(__builtin_bit_cast(int, v), (int)0xff800000, [](int a, int b) {
+    return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); }));
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+  return wave_reduce_bits(v, 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+}
+// value extremum with the lowest index among ties (two VALU reductions; no ds_bpermute)
 __device__ __forceinline__ void wave_argmin(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) {
-    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
-    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
+  const float m = wave_min(v);
+  i = wave_min_int(v == m ? i : 0x7fffffff);
+  v = m;
 }
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) {
-    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
+  const float m = wave_max(v);
+  i = wave_min_int(v == m ? i : 0x7fffffff);
+  v = m;
 }
 
 }  // namespace nmf
