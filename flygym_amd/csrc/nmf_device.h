@@ -128,6 +128,25 @@ __device__ __forceinline__ void qmat(float* m, Q4 q) {
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
 }
 
+__device__ __forceinline__ Q4 mat_quat(const float* m) {   // rotation matrix -> unit quaternion
+  const float t = m[0] + m[4] + m[8];
+  Q4 q;
+  if (t > 0.f) {
+    const float r = sqrtf(t + 1.f) * 2.f;
+    q = Q4{0.25f * r, (m[7] - m[5]) / r, (m[2] - m[6]) / r, (m[3] - m[1]) / r};
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    const float r = sqrtf(1.f + m[0] - m[4] - m[8]) * 2.f;
+    q = Q4{(m[7] - m[5]) / r, 0.25f * r, (m[1] + m[3]) / r, (m[2] + m[6]) / r};
+  } else if (m[4] > m[8]) {
+    const float r = sqrtf(1.f + m[4] - m[0] - m[8]) * 2.f;
+    q = Q4{(m[2] - m[6]) / r, (m[1] + m[3]) / r, 0.25f * r, (m[5] + m[7]) / r};
+  } else {
+    const float r = sqrtf(1.f + m[8] - m[0] - m[4]) * 2.f;
+    q = Q4{(m[3] - m[1]) / r, (m[2] + m[6]) / r, (m[5] + m[7]) / r, 0.25f * r};
+  }
+  return q;
+}
+
 // spatial 6-vectors: motion (w; v) and force (n; f), world axes, about the root origin
 struct SV { V3 a, l; };  // angular part, linear part
 __device__ __forceinline__ SV ldsv(const float* p) { return SV{ld3(p), ld3(p + 3)}; }

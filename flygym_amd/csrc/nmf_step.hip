@@ -52,7 +52,7 @@ struct __align__(16) FlyLds {
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float aba_u[TP::NV], aba_invD[TP::NV], aba_U[TP::NV][6];
   float ctrl[kMaxCtrl], act_force[kMaxCtrl];
-  float xpos[TP::NB][3], xquat[TP::NB][4], xmat[TP::NB][9];
+  float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];
   float T[TP::NB][6], W[TP::NB][6];     // body twists / wrenches (velocities live in W until the bias stage)
@@ -86,12 +86,32 @@ __device__ __forceinline__ int dof_body_of(int j) {
   return 1 + leg * TP::NBL + lb;
 }
 
+// ------------------------------------------------------------------ lane roles
+struct LaneRole {
+  int grp, r, lg, rr;
+  bool live;      // a real (leg, component) lane
+  float mask;     // 1 for r < 6 else 0 (zero contribution to group sums)
+};
+template <class TP>
+__device__ __forceinline__ LaneRole lane_role(int lane) {
+  LaneRole L;
+  L.grp = lane >> 3; L.r = lane & 7;
+  L.lg = L.grp < TP::NLEG ? L.grp : TP::NLEG - 1;
+  L.rr = L.r < 6 ? L.r : 5;
+  L.live = L.grp < TP::NLEG && L.r < 6;
+  L.mask = L.r < 6 ? 1.f : 0.f;
+  return L;
+}
+
 // ------------------------------------------------------------------ kinematics
 template <class TP>
 __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
-  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.aba_U[0][0]);
-  float(*relq)[4] = reinterpret_cast<float(*)[4]>(&s.W[0][0]);
+  // scratch (dead between steps): joint quaternions in the solver vectors, per-body relative
+  // rotation matrices + offsets in the ABA hand-off buffer, body-frame hinge axes in T
+  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.vA[0]);            // NV x 4  <= 6 NV floats (vA..aba_invD)
+  float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.aba_u[0]) - 1;   // bodies 1..NB-1: (NB-1) x 12 floats in aba_u..aba_U
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.T[0][0]);
+  static_assert((TP::NB - 1) * 12 <= TP::NV * 8 && TP::NV * 4 <= TP::NV * 4, "kinematics scratch does not fit");
   for (int j = 6 + lane; j < TP::NV; j += kWave) {
     float sn, cs;
     sincosf(0.5f * s.qpos[j + 1], &sn, &cs);
@@ -101,7 +121,6 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   if (lane == 0) {
     Q4 q = qnorm(ldq(&s.qpos[3]));
     st3(s.xpos[0], ld3(&s.qpos[0]));
-    stq(s.xquat[0], q);
     qmat(s.xmat[0], q);
   }
   WSYNC();
@@ -114,18 +133,32 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
       P = qmul(ldq(jq[j]), P);
     }
-    stq(relq[b], qmul(ldq(&m.body_quat[4 * b]), P));
+    qmat(relm[b], qnorm(qmul(ldq(&m.body_quat[4 * b]), P)));
+    st3(&relm[b][9], ld3(&m.body_pos[3 * b]));
   }
   WSYNC();
-  if (lane < TP::NLEG) {
-    for (int l = 0; l < TP::NBL; ++l) {
-      int b = 1 + lane * TP::NBL + l, p = l == 0 ? 0 : b - 1;
-      V3 off = mat_vec(s.xmat[p], ld3(&m.body_pos[3 * b]));
-      st3(s.xpos[b], ld3(s.xpos[p]) + off);
-      Q4 q = qnorm(qmul(ldq(s.xquat[p]), ldq(relq[b])));
-      stq(s.xquat[b], q);
-      qmat(s.xmat[b], q);
-    }
+  {
+    // chain of rigid transforms down each leg: lane (leg, r < 3) carries row r of the rotation and
+    // component r of the position:  R_b = R_parent * Rrel_b ,  p_b = p_parent + R_parent * off_b
+    const LaneRole L = lane_role<TP>(lane);
+    const int r3 = L.r < 3 ? L.r : 2;
+    const bool live3 = L.grp < TP::NLEG && L.r < 3;
+    float R0 = s.xmat[0][3 * r3], R1 = s.xmat[0][3 * r3 + 1], R2 = s.xmat[0][3 * r3 + 2];
+    float p = s.xpos[0][r3];
+    const int b0 = 1 + L.lg * TP::NBL;
+    static_for<TP::NBL>([&](auto I) {
+      constexpr int l = decltype(I)::value;
+      const float* M = relm[b0 + l];
+      p += R0 * M[9] + R1 * M[10] + R2 * M[11];
+      const float n0 = R0 * M[0] + R1 * M[3] + R2 * M[6];
+      const float n1 = R0 * M[1] + R1 * M[4] + R2 * M[7];
+      const float n2 = R0 * M[2] + R1 * M[5] + R2 * M[8];
+      R0 = n0; R1 = n1; R2 = n2;
+      if (live3) {
+        s.xmat[b0 + l][3 * L.r] = R0; s.xmat[b0 + l][3 * L.r + 1] = R1; s.xmat[b0 + l][3 * L.r + 2] = R2;
+        s.xpos[b0 + l][L.r] = p;
+      }
+    });
   }
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave) {
@@ -301,22 +334,6 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
 // leg g and lane r < 6 of the group owns component r of a spatial vector (or row r of a 6x6).
 // Groups >= NLEG and lanes r >= 6 shadow harmless work (loads clamped, stores masked) so that every
 // lane runs the same instruction stream and the DPP reductions stay converged.
-struct LaneRole {
-  int grp, r, lg, rr;
-  bool live;      // a real (leg, component) lane
-  float mask;     // 1 for r < 6 else 0 (zero contribution to group sums)
-};
-template <class TP>
-__device__ __forceinline__ LaneRole lane_role(int lane) {
-  LaneRole L;
-  L.grp = lane >> 3; L.r = lane & 7;
-  L.lg = L.grp < TP::NLEG ? L.grp : TP::NLEG - 1;
-  L.rr = L.r < 6 ? L.r : 5;
-  L.live = L.grp < TP::NLEG && L.r < 6;
-  L.mask = L.r < 6 ? 1.f : 0.f;
-  return L;
-}
-
 // T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
 template <class TP>
 __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
@@ -922,7 +939,8 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
   for (int sg = lane; sg < m.nseg; sg += kWave) {
     int b = m.seg_body[sg];
     V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.seg_pos[3 * sg]));
-    Q4 q = qnorm(qmul(ldq(s.xquat[b]), ldq(&m.seg_quat[4 * sg])));
+    Q4 q = qnorm(qmul(mat_quat(s.xmat[b]), ldq(&m.seg_quat[4 * sg])));
+    if (q.w < 0.f) q = Q4{-q.w, -q.x, -q.y, -q.z};
     st3(&st.seg_xpos[((size_t)w * m.nseg + sg) * 3], p);
     stq(&st.seg_xquat[((size_t)w * m.nseg + sg) * 4], q);
   }
