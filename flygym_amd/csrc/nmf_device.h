@@ -14,7 +14,7 @@
 namespace nmf {
 
 constexpr int kWave = 64;
-constexpr int kMaxCon = 64;      // contacts per fly kept by the engine (overflow is flagged)
+constexpr int kMaxCon = 48;      // contacts per fly kept by the engine (overflow is flagged)
 constexpr int kMaxCtrl = 48;
 constexpr float kMinVal = 1e-15f;
 

@@ -48,22 +48,36 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 template <class TP>
 struct __align__(16) FlyLds {
   float qpos[TP::NQ + 3];
-  float qvel[TP::NV], qacc[TP::NV], qacc_smooth[TP::NV], qfrc_smooth[TP::NV];   // qacc doubles as the warm start
+  float qvel[TP::NV], qacc[TP::NV];      // qacc doubles as the warm start
+  // qacc_smooth .. vD are contiguous (6 NV floats): the velocity stage borrows them as one buffer
+  float qacc_smooth[TP::NV], qfrc_smooth[TP::NV];
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
-  float aba_u[TP::NV], aba_invD[TP::NV], aba_U[TP::NV][6];
-  float ctrl[kMaxCtrl], act_force[kMaxCtrl];
+  float ctrl[kMaxCtrl];
   float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];
-  float T[TP::NB][6], W[TP::NB][6];     // body twists / wrenches (velocities live in W until the bias stage)
-  float legIA[TP::NLEG][6][6], legpA[TP::NLEG][6];
-  float rootA[6][6], rootb[6];
+  // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
+  // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
+  float T[TP::NB][6], W[TP::NB][6];
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];   // c_D holds the distance until setup
-  int c_geom[kMaxCon], c_body[kMaxCon], c_act[kMaxCon];
+  int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
   int body_cstart[TP::NB + 1];
-  float sens[96];
   int ncon, overflow, iters;
+};
+
+__device__ __forceinline__ int info_geom(int i) { return i & 0xff; }
+__device__ __forceinline__ int info_sensor(int i) { return ((i >> 8) & 0xf) - 1; }
+__device__ __forceinline__ int info_body(int i) { return (i >> 12) & 0xff; }
+__device__ __forceinline__ int info_act(int i) { return (i >> 20) & 0xf; }
+__device__ __forceinline__ int info_pack(int geom, int sensor, int body, int act) {
+  return geom | ((sensor + 1) << 8) | (body << 12) | (act << 20);
+}
+
+// ABA leg -> root hand-off, overlaid on the T..W region (free while an ABA sweep runs)
+template <class TP>
+struct AbaHandoff {
+  float legIA[TP::NLEG][6][6], legpA[TP::NLEG][6], rootA[6][6], rootb[6];
 };
 
 struct Frame { V3 n, t1, t2; };
@@ -108,10 +122,10 @@ template <class TP>
 __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
   // scratch (dead between steps): joint quaternions in the solver vectors, per-body relative
   // rotation matrices + offsets in the ABA hand-off buffer, body-frame hinge axes in T
-  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.vA[0]);            // NV x 4  <= 6 NV floats (vA..aba_invD)
-  float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.aba_u[0]) - 1;   // bodies 1..NB-1: (NB-1) x 12 floats in aba_u..aba_U
-  float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.T[0][0]);
-  static_assert((TP::NB - 1) * 12 <= TP::NV * 8 && TP::NV * 4 <= TP::NV * 4, "kinematics scratch does not fit");
+  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.vA[0]);            // NV x 4 floats = vA..vD
+  float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.T[0][0]) - 1;    // bodies 1..NB-1: (NB-1) x 12 floats in T..W
+  float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.Ib[0][0]);          // NV x 3 floats (Ib is rebuilt afterwards)
+  static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
   for (int j = 6 + lane; j < TP::NV; j += kWave) {
     float sn, cs;
     sincosf(0.5f * s.qpos[j + 1], &sn, &cs);
@@ -243,7 +257,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
       int slot = ncon + __popcll(vm & ((1ull << lane) - 1ull));
       if (valid) {
         if (slot < kMaxCon) {
-          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_D[slot] = dist;
+          s.c_info[slot] = info_pack(g, -1, b, 0); s.c_D[slot] = dist;
           st3(s.c_r[slot], (ps - (0.5f * dist) * n) - o);
         } else overflow = 1;
       }
@@ -310,7 +324,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
           V3 v = ld3(V + 3 * vi);
           float dist = dot(nb, v) + c0;
           V3 pw = mat_vec(R, v) + xp;
-          s.c_geom[slot] = g; s.c_body[slot] = b; s.c_D[slot] = dist;
+          s.c_info[slot] = info_pack(g, -1, b, 0); s.c_D[slot] = dist;
           st3(s.c_r[slot], (pw - (0.5f * dist) * n) - o);
         } else overflow = 1;
       }
@@ -323,7 +337,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   WSYNC();
   for (int b = lane; b <= TP::NB; b += kWave) {
     int cnt = 0;
-    for (int c = 0; c < ncon; ++c) cnt += s.c_body[c] < b ? 1 : 0;
+    for (int c = 0; c < ncon; ++c) cnt += info_body(s.c_info[c]) < b ? 1 : 0;
     s.body_cstart[b] = cnt;
   }
   WSYNC();
@@ -405,7 +419,7 @@ __device__ __forceinline__ void inertia_row(const float* I, int r, float* row) {
 // row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t
 template <class TP>
 __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, int r, const Frame& fr) {
-  const int act = s.c_act[c];
+  const int act = info_act(s.c_info[c]);
   if (!act) return;
   const V3 rc = ld3(s.c_r[c]);
   const float D = s.c_D[c], mu = s.c_mu[c];
@@ -437,6 +451,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
                           const Frame& fr, const DevModel& m, int lane) {
   const LaneRole L = lane_role<TP>(lane);
   const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
+  static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
+  AbaHandoff<TP>& H = *reinterpret_cast<AbaHandoff<TP>*>(&s.T[0][0]);
+  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL];   // this lane's row of U_j and the group-uniform u_j, 1/D_j
   {
     float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pA = 0.f;
@@ -460,11 +477,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
       const float sr = L.mask * s.S[j][L.rr];
       const float D = grp8_sum(sr * U) + s.arm[j] + hdamp * s.damp[j];
       const float sp = grp8_sum(sr * pA);
-      if (L.live) s.aba_U[j][L.r] = U;
       float invD = __builtin_amdgcn_rcpf(D);
       invD = invD * (2.0f - D * invD);
       const float u = tau[j] - sp;
-      if (L.live && L.r == 0) { s.aba_u[j] = u; s.aba_invD[j] = invD; }
+      Ureg[d] = L.mask * U; ureg[d] = u; invDreg[d] = invD;
       const float k = U * invD;
       IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
       IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
@@ -472,8 +488,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
     });
     if (L.live) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) s.legIA[L.grp][L.r][i] = IA[i];
-      s.legpA[L.grp][L.r] = pA;
+      for (int i = 0; i < 6; i++) H.legIA[L.grp][L.r][i] = IA[i];
+      H.legpA[L.grp][L.r] = pA;
     }
   }
   WSYNC();
@@ -485,25 +501,25 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) row[i] += s.legIA[k][lane][i];
-      pA += s.legpA[k][lane];
+      for (int i = 0; i < 6; i++) row[i] += H.legIA[k][lane][i];
+      pA += H.legpA[k][lane];
     }
     // wrench of the root generalized force: n = R tau_rot, f = tau_trans
     float w;
     if (lane < 3) w = s.xmat[0][3 * lane] * tau[3] + s.xmat[0][3 * lane + 1] * tau[4] + s.xmat[0][3 * lane + 2] * tau[5];
     else w = tau[lane - 3];
 #pragma unroll
-    for (int i = 0; i < 6; i++) s.rootA[lane][i] = row[i];
-    s.rootb[lane] = w - pA;
+    for (int i = 0; i < 6; i++) H.rootA[lane][i] = row[i];
+    H.rootb[lane] = w - pA;
   }
   WSYNC();
   if (lane == 0) {
     float A[6][6], rhs[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      rhs[i] = s.rootb[i];
+      rhs[i] = H.rootb[i];
 #pragma unroll
-      for (int j = 0; j <= i; j++) A[i][j] = s.rootA[i][j];
+      for (int j = 0; j <= i; j++) A[i][j] = H.rootA[i][j];
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -549,8 +565,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
     static_for<TP::NDL>([&](auto DD) {
       constexpr int d = decltype(DD)::value;
       const int j = j0 + d;
-      const float ua = grp8_sum(L.mask * s.aba_U[j][L.rr] * a);
-      const float xj = (s.aba_u[j] - ua) * s.aba_invD[j];
+      const float ua = grp8_sum(Ureg[d] * a);
+      const float xj = (ureg[d] - ua) * invDreg[d];
       if (L.live && L.r == 0) x[j] = xj;
       a += xj * s.S[j][L.rr];
       if constexpr (TP::is_last(d)) { if (L.live) s.T[b0 + TP::lbody(d)][L.r] = a; }
@@ -563,7 +579,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
 struct ContactRegs {
   bool on;
   V3 r;
-  int body, geom;
+  int body, geom, info;
   float dist, mu, D, K, B, imp, margin;
   float aref[4], jar[4], jv[4];
 };
@@ -612,7 +628,7 @@ __device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame
     V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
     SV w = SV{cross(c.r, F), F};
     stsv(s.c_w[lane], sign * w);
-    s.c_act[lane] = act;
+    s.c_info[lane] = c.info | (act << 20);
   }
   WSYNC();
   const LaneRole L = lane_role<TP>(lane);
@@ -641,7 +657,7 @@ __device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame
 
 // ------------------------------------------------------------------ the step
 template <class TP>
-__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
+__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   stage_kinematics(s, m, lane);
   STAGE(1);
@@ -655,9 +671,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   ContactRegs c;
   c.on = lane < ncon;
   if (c.on) {
-    c.r = ld3(s.c_r[lane]); c.body = s.c_body[lane]; c.geom = s.c_geom[lane]; c.dist = s.c_D[lane];
+    const int info0 = s.c_info[lane];
+    c.r = ld3(s.c_r[lane]); c.body = info_body(info0); c.geom = info_geom(info0); c.dist = s.c_D[lane];
     int g = c.geom;
-    s.c_geom[lane] = g | ((m.geom_sensor[g] + 1) << 8);     // low byte: geom, next byte: leg sensor + 1
+    c.info = info_pack(g, m.geom_sensor[g], c.body, 0);
     c.mu = m.pair_friction[5 * g];
     c.margin = m.pair_margin[g];
     const float* solref = &m.pair_solref[2 * g];
@@ -676,7 +693,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
       c.K = 1.0f / (dmax * dmax * tc * tc * dr * dr);
       c.B = 2.0f / (dmax * tc);
     } else { c.K = -tc / (solimp[1] * solimp[1]); c.B = -dr / solimp[1]; }
-    s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_act[lane] = 0;
+    s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_info[lane] = c.info;
   }
 
   STAGE(4);
@@ -684,7 +701,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   {
     const LaneRole L = lane_role<TP>(lane);
     const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
-    float(*vb)[6] = s.aba_U;                      // per dof: velocity before the dof, then Sdot*qd
+    float(*vb)[6] = reinterpret_cast<float(*)[6]>(&s.qacc_smooth[0]);   // NV x 6 floats: qacc_smooth .. vD
     // pass 1: component-wise prefix of velocities
     float vt = 0.f;
 #pragma unroll
@@ -755,7 +772,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
       if (m.act_limited[2 * u]) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
       s.vA[j] += f;
     }
-    s.act_force[u] = f;
+    if (last) st.actuator_force[(size_t)w * m.nu + u] = f;     // pure output: only the launch's last step stores it
   }
   WSYNC();
   sweep_project(s, s.W, s.qfrc_smooth, m, lane);
@@ -868,29 +885,33 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane STAGE
   if (lane == 0) s.iters = iters;
   STAGE(14);
 
-  // ---- contact sensors (oracle contact_sensors): c_w holds the world-frame contact wrenches about o
-  for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
-  WSYNC();
-  if (m.nsensor && lane < 6 && ncon > 0) {
-    float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
-    for (int cc = 0; cc < ncon; ++cc) {
-      if ((s.c_geom[cc] >> 8) - 1 != lane) continue;
-      V3 f = ld3(&s.c_w[cc][3]);
-      float fn = dot(f, fr.n);
-      V3 p = ld3(s.c_r[cc]);
-      wsum += fn; pc = pc + fn * p; pm = pm + p; cnt++;
-    }
-    if (cnt) {
-      pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
+  // ---- contact sensors (oracle contact_sensors): a pure output, evaluated on the launch's last step only and
+  // written straight to HBM.  c_w holds the world-frame contact wrenches about the root origin.
+  if (last) {
+    float* out = &st.sensordata[(size_t)w * 96];
+    for (int i = lane; i < 96; i += kWave) out[i] = 0.f;
+    WSYNC();
+    if (m.nsensor && lane < 6 && ncon > 0) {
+      float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
       for (int cc = 0; cc < ncon; ++cc) {
-        if ((s.c_geom[cc] >> 8) - 1 != lane) continue;
+        if (info_sensor(s.c_info[cc]) != lane) continue;
         V3 f = ld3(&s.c_w[cc][3]);
-        F = F + f;
-        Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
+        float fn = dot(f, fr.n);
+        V3 p = ld3(s.c_r[cc]);
+        wsum += fn; pc = pc + fn * p; pm = pm + p; cnt++;
       }
-      float* out = &s.sens[16 * lane];
-      V3 o = ld3(s.xpos[0]);
-      out[0] = (float)cnt; st3(out + 1, F); st3(out + 4, Tq); st3(out + 7, pc + o); st3(out + 10, fr.n); st3(out + 13, fr.t1);
+      if (cnt) {
+        pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
+        for (int cc = 0; cc < ncon; ++cc) {
+          if (info_sensor(s.c_info[cc]) != lane) continue;
+          V3 f = ld3(&s.c_w[cc][3]);
+          F = F + f;
+          Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
+        }
+        float* o16 = out + 16 * lane;
+        V3 o = ld3(s.xpos[0]);
+        o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, fr.n); st3(o16 + 13, fr.t1);
+      }
     }
   }
   WSYNC();
@@ -933,9 +954,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
   }
   for (int i = lane; i < m.nu; i += kWave) {
     st.ctrl[(size_t)w * m.nu + i] = s.ctrl[i];
-    st.actuator_force[(size_t)w * m.nu + i] = s.act_force[i];
   }
-  for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = s.sens[i];
   for (int sg = lane; sg < m.nseg; sg += kWave) {
     int b = m.seg_body[sg];
     V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.seg_pos[3 * sg]));
@@ -969,8 +988,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   if (mode == 1) {
     for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = m.key_qpos[i];
     for (int i = lane; i < TP::NV; i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
-    for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; s.act_force[i] = 0.f; }
-    for (int i = lane; i < 96; i += kWave) s.sens[i] = 0.f;
+    for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
+    for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
     if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
     time = 0.f;
     WSYNC();
@@ -992,7 +1011,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
         WSYNC();
       }
       STAGE(0);
-      physics_forward(s, m, lane STAGE_PASS);
+      physics_forward(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);
       physics_integrate(s, m, lane STAGE_PASS);
       STAGE(15);
       time += m.timestep;

@@ -30,8 +30,8 @@ class HIPSimulation:
         world: a configured :class:`~flygym_amd.compose.BaseWorld` with one fly.
         n_worlds: number of parallel worlds on this GPU.
         max_constraints, max_contacts: accepted for signature compatibility with
-            ``GPUSimulation`` (``warp/simulation.py:50-56``).  The engine keeps up to 64 contacts
-            (256 constraint rows) per world in registers/LDS; overflow is reported through
+            ``GPUSimulation`` (``warp/simulation.py:50-56``).  The engine keeps up to 48 contacts
+            (192 constraint rows) per world in registers/LDS; overflow is reported through
             :meth:`get_solver_stats` instead of being silently dropped.
         device: CUDA/HIP device index (one process per GPU for multi-GPU runs).
     """

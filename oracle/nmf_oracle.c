@@ -58,7 +58,7 @@ typedef float real;
 #define R_EPS 1.1920929e-07f
 #endif
 
-#define NMF_MAXCON 64
+#define NMF_MAXCON 48
 #ifndef NMF_NOISE_FACTOR
 #define NMF_NOISE_FACTOR 8
 #endif

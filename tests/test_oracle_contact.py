@@ -80,7 +80,7 @@ def test_hull_manifold_gives_up_to_four_contacts(bench_model, oracle_lib):
     o.qpos[2] = 0.3
     o.step(1200)
     i = o.ints()
-    assert i["overflow"] == 0 and 1 <= i["ncon"] <= 64
+    assert i["overflow"] == 0 and 1 <= i["ncon"] <= 48
     assert np.isfinite(o.qpos).all()
     per_geom = np.bincount(i["con_geom"], minlength=55)
     assert per_geom.max() <= 4
