@@ -29,7 +29,7 @@ class NativeError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_device.h", INCLUDE / "nmf.h"]
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_device.h", INCLUDE / "nmf.h"]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     cmd = [
@@ -70,6 +70,8 @@ def lib():
             "nmf_scatter": (ci, [vp, ci, vp, ci, vp, vp]),
             "nmf_step_count": (ctypes.c_int64, [vp]),
             "nmf_time_launches": (ctypes.c_double, [vp, vp, ci, ci, vp, ci, ci, vp]),
+            "nmf_retina_resample": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+            "nmf_odor_intensity": (ci, [vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -13,6 +13,7 @@
 
 #include "nmf.h"
 #include "nmf_step.hip"
+#include "nmf_sensors.hip"
 
 namespace {
 
@@ -328,6 +329,35 @@ extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int ta
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)ms / reps;
+}
+
+extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const uint8_t* pale_dev,
+                                   const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
+                                   float* out_dev, void* stream) {
+  if (!images_dev || !id_map_dev || !pale_dev || !inv_norm_dev || !out_dev) return fail("nmf_retina_resample: null buffer");
+  if (n_images <= 0) return 0;
+  if (n_pixels <= 0 || n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia)
+    return fail("nmf_retina_resample: need 0 < n_ommatidia <= 1024 and n_pixels > 0");
+  if ((reinterpret_cast<uintptr_t>(images_dev) | reinterpret_cast<uintptr_t>(id_map_dev)) & 15u || (n_pixels * 3) % 16)
+    return fail("nmf_retina_resample: images / id map must be 16-byte aligned and image size a multiple of 16 bytes");
+  hipLaunchKernelGGL(nmf::nmf_retina_kernel, dim3((unsigned)n_images), dim3(nmf::kRetinaThreads), 0, (hipStream_t)stream,
+                     images_dev, id_map_dev, pale_dev, inv_norm_dev, n_pixels, n_ommatidia, out_dev);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nmf_odor_intensity(nmf_batch* b, const int32_t* sensor_seg_dev, const float* sensor_rel_dev, int n_sensors,
+                                  const float* source_pos_dev, const float* source_peak_dev, int n_sources, int n_dims,
+                                  float* out_dev, void* stream) {
+  if (!b) return fail("nmf_odor_intensity: null batch");
+  if (n_sensors <= 0 || n_sources < 0 || n_dims <= 0 || !sensor_seg_dev || !sensor_rel_dev || !out_dev)
+    return fail("nmf_odor_intensity: bad arguments");
+  int total = b->n_worlds * n_sensors;
+  hipLaunchKernelGGL(nmf::nmf_odor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     b->st.seg_xpos, b->st.seg_xquat, b->model->nseg, sensor_seg_dev, sensor_rel_dev, n_sensors,
+                     source_pos_dev, source_peak_dev, n_sources, n_dims, out_dev, b->n_worlds);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 #ifdef NMF_STAGE_PROFILE

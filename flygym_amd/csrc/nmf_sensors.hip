@@ -1,0 +1,99 @@
+// nmf_sensors.hip — vision and olfaction sensor kernels (gfx950).
+//
+// The reference snapshot (flygym 2.0.1) ships only the *constants* of these sensors
+// (src/flygym/assets/model/legacy/flygym1_config.yaml:141-192: 721 ommatidia per eye, 512x450 raw image,
+// eye-camera poses; odor sensor sites on the rostrum and the funiculi) — no code and no id-map files
+// (SURVEY §0.3, §8 a18/a19).  The semantics below are therefore build-defined and pinned
+// by the numpy oracle in oracle/sensors_oracle.py.
+//
+// Retina resample: every pixel of a raw eye image belongs to at most one ommatidium (id map, 0 = none);
+// an ommatidium is "yellow" (reads the green channel) or "pale" (reads the blue channel); its reading
+// is the mean of that channel over its pixels, scaled to [0, 1], stored in channel 0 (yellow) or 1
+// (pale) of out[image][ommatidium][2], the other channel being 0.
+//
+// This kernel IS HBM-bound: 3 bytes in per pixel (691 200 B per eye frame) against 5.8 KB out.  One
+// workgroup per image; each thread streams 16-pixel chunks as three 16-byte loads (+ two for the id
+// map, which all images share and L2 keeps), folds runs of equal ids in registers and flushes them
+// with integer LDS atomics — exact and order-independent, hence bit-reproducible.
+#include "nmf_device.h"
+
+namespace nmf {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRetinaThreads = 512;
+constexpr int kMaxOmmatidia = 1024;
+
+__global__ void __launch_bounds__(kRetinaThreads)
+nmf_retina_kernel(const uint8_t* __restrict__ images, const int16_t* __restrict__ id_map,
+                  const uint8_t* __restrict__ pale, const float* __restrict__ inv_norm, int n_pix, int n_omm,
+                  float* __restrict__ out) {
+  __shared__ unsigned int acc[kMaxOmmatidia];
+  const int img = blockIdx.x;
+  for (int i = threadIdx.x; i < n_omm; i += kRetinaThreads) acc[i] = 0u;
+  __syncthreads();
+  const uint8_t* src = images + (size_t)img * n_pix * 3;
+  const int n_chunk = n_pix / 16;                       // 16 pixels = 48 image bytes + 32 id bytes
+  for (int ch = threadIdx.x; ch < n_chunk; ch += kRetinaThreads) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)ch * 48);
+    // image bytes are read exactly once: non-temporal; the id map is shared by every image: cached
+    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1), c = __builtin_nontemporal_load(p + 2);
+    const u32x4* q = reinterpret_cast<const u32x4*>(id_map + (size_t)ch * 16);
+    const u32x4 i0 = q[0], i1 = q[1];
+    const unsigned int w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    const unsigned int iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+    int cur = 0; unsigned int sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int id = (int)((iw[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+      // bytes of pixel k: 3k (R), 3k+1 (G), 3k+2 (B)
+      const unsigned int g = (w[(3 * k + 1) >> 2] >> (((3 * k + 1) & 3) * 8)) & 0xffu;
+      const unsigned int bl = (w[(3 * k + 2) >> 2] >> (((3 * k + 2) & 3) * 8)) & 0xffu;
+      if (id != cur) {
+        if (cur > 0) atomicAdd(&acc[cur - 1], sum);
+        cur = id; sum = 0u;
+      }
+      if (id > 0) sum += pale[id - 1] ? bl : g;
+    }
+    if (cur > 0) atomicAdd(&acc[cur - 1], sum);
+  }
+  // tail pixels (n_pix not a multiple of 16)
+  for (int px = n_chunk * 16 + threadIdx.x; px < n_pix; px += kRetinaThreads) {
+    const int id = id_map[px];
+    if (id > 0) atomicAdd(&acc[id - 1], (unsigned int)src[(size_t)px * 3 + (pale[id - 1] ? 2 : 1)]);
+  }
+  __syncthreads();
+  float* dst = out + (size_t)img * n_omm * 2;
+  for (int i = threadIdx.x; i < n_omm; i += kRetinaThreads) {
+    const float v = (float)acc[i] * inv_norm[i];
+    const bool p = pale[i] != 0;
+    dst[2 * i] = p ? 0.f : v;
+    dst[2 * i + 1] = p ? v : 0.f;
+  }
+}
+
+// Odor intensity at the fly's odor sensors:  out[w][d][k] = sum_s peak[s][d] / |x_sensor(w,k) - x_source(s)|^2
+// (inverse-square diffusion, the flygym 1.x OdorArena default).  Sensor k sits at seg_xpos + R(seg_xquat) rel_pos
+// of its parent segment.  One thread per (world, sensor).
+__global__ void nmf_odor_kernel(const float* __restrict__ seg_xpos, const float* __restrict__ seg_xquat, int nseg,
+                                const int* __restrict__ sensor_seg, const float* __restrict__ sensor_rel, int n_sensor,
+                                const float* __restrict__ src_pos, const float* __restrict__ src_peak, int n_src, int n_dim,
+                                float* __restrict__ out, int n_worlds) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_worlds * n_sensor) return;
+  const int w = t / n_sensor, k = t % n_sensor, sg = sensor_seg[k];
+  const float* xp = seg_xpos + ((size_t)w * nseg + sg) * 3;
+  const Q4 q = ldq(seg_xquat + ((size_t)w * nseg + sg) * 4);
+  float R[9];
+  qmat(R, q);
+  const V3 p = ld3(xp) + mat_vec(R, ld3(sensor_rel + 3 * k));
+  for (int d = 0; d < n_dim; ++d) {
+    float acc = 0.f;
+    for (int s = 0; s < n_src; ++s) {
+      const V3 e = p - ld3(src_pos + 3 * s);
+      acc += src_peak[s * n_dim + d] / dot(e, e);
+    }
+    out[((size_t)w * n_dim + d) * n_sensor + k] = acc;
+  }
+}
+
+}  // namespace nmf

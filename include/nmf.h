@@ -96,6 +96,24 @@ int64_t nmf_step_count(const nmf_batch* batch);
 double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_steps, int n_act,
                          const int32_t* act_ids_dev, int n_steps, int reps, void* stream);
 
+/* ---- sensors the north star names; the reference snapshot holds only their constants
+ * (src/flygym/assets/model/legacy/flygym1_config.yaml:141-192), so semantics are build-defined. ---- */
+
+/* Hex-ommatidia resample of raw eye images.  images[n_images][n_pixels][3] uint8 RGB; id_map[n_pixels] int16
+ * (0 = no ommatidium, k = ommatidium k-1; shared by all images); pale[n_ommatidia] uint8 (1 = pale type, reads
+ * blue; 0 = yellow type, reads green); inv_norm[k] = 1 / (255 * pixels of ommatidium k);
+ * out[n_images][n_ommatidia][2] float32 (channel 0 yellow, 1 pale).  Buffers 16-byte aligned. */
+int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const uint8_t* pale_dev,
+                        const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
+                        float* out_dev, void* stream);
+
+/* Odor intensity at n_sensors points rigidly attached to named segments (sensor_seg = index into the
+ * batch's segment order, sensor_rel = offset in the segment frame): out[w][d][k] = sum_s peak[s][d] / dist^2.
+ * Reads the pose outputs of the last nmf_step / nmf_reset. */
+int nmf_odor_intensity(nmf_batch* batch, const int32_t* sensor_seg_dev, const float* sensor_rel_dev, int n_sensors,
+                       const float* source_pos_dev, const float* source_peak_dev, int n_sources, int n_dims,
+                       float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
