@@ -6,7 +6,8 @@
 // (SURVEY §0.3, §8 a18/a19).  The semantics below are therefore build-defined and pinned
 // by the numpy oracle in oracle/sensors_oracle.py.
 //
-// Retina resample: every pixel of a raw eye image belongs to at most one ommatidium (id map, 0 = none);
+// Retina resample: every pixel of a raw eye image belongs to at most one ommatidium (typed id map: bits 0..14
+// = id, 0 = none; bit 15 = the ommatidium is pale, so no per-pixel type lookup is needed);
 // an ommatidium is "yellow" (reads the green channel) or "pale" (reads the blue channel); its reading
 // is the mean of that channel over its pixels, scaled to [0, 1], stored in channel 0 (yellow) or 1
 // (pale) of out[image][ommatidium][2], the other channel being 0.
@@ -33,18 +34,15 @@ nmf_retina_kernel(const uint8_t* __restrict__ images, const int16_t* __restrict_
   __syncthreads();
   const uint8_t* src = images + (size_t)img * n_pix * 3;
   const int n_chunk = n_pix / 16;                       // 16 pixels = 48 image bytes + 32 id bytes
-  for (int ch = threadIdx.x; ch < n_chunk; ch += kRetinaThreads) {
-    const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)ch * 48);
-    // image bytes are read exactly once: non-temporal; the id map is shared by every image: cached
-    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1), c = __builtin_nontemporal_load(p + 2);
-    const u32x4* q = reinterpret_cast<const u32x4*>(id_map + (size_t)ch * 16);
-    const u32x4 i0 = q[0], i1 = q[1];
+  // two chunks per iteration: ten 16-byte loads in flight per thread before any use
+  auto fold = [&](const u32x4 a, const u32x4 b, const u32x4 c, const u32x4 i0, const u32x4 i1) {
     const unsigned int w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
     const unsigned int iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
     int cur = 0; unsigned int sum = 0u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int id = (int)((iw[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+      const unsigned int tid = (iw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;   // bit 15: pale (reads blue)
+      const int id = (int)(tid & 0x7fffu);
       // bytes of pixel k: 3k (R), 3k+1 (G), 3k+2 (B)
       const unsigned int g = (w[(3 * k + 1) >> 2] >> (((3 * k + 1) & 3) * 8)) & 0xffu;
       const unsigned int bl = (w[(3 * k + 2) >> 2] >> (((3 * k + 2) & 3) * 8)) & 0xffu;
@@ -52,14 +50,33 @@ nmf_retina_kernel(const uint8_t* __restrict__ images, const int16_t* __restrict_
         if (cur > 0) atomicAdd(&acc[cur - 1], sum);
         cur = id; sum = 0u;
       }
-      if (id > 0) sum += pale[id - 1] ? bl : g;
+      if (id > 0) sum += (tid & 0x8000u) ? bl : g;
     }
     if (cur > 0) atomicAdd(&acc[cur - 1], sum);
+  };
+  int ch = threadIdx.x;
+  for (; ch + kRetinaThreads < n_chunk; ch += 2 * kRetinaThreads) {
+    const u32x4* p0 = reinterpret_cast<const u32x4*>(src + (size_t)ch * 48);
+    const u32x4* p1 = reinterpret_cast<const u32x4*>(src + (size_t)(ch + kRetinaThreads) * 48);
+    // image bytes are read exactly once: non-temporal; the id map is shared by every image: cached
+    const u32x4 a0 = __builtin_nontemporal_load(p0), b0 = __builtin_nontemporal_load(p0 + 1), c0 = __builtin_nontemporal_load(p0 + 2);
+    const u32x4 a1 = __builtin_nontemporal_load(p1), b1 = __builtin_nontemporal_load(p1 + 1), c1 = __builtin_nontemporal_load(p1 + 2);
+    const u32x4* q0 = reinterpret_cast<const u32x4*>(id_map + (size_t)ch * 16);
+    const u32x4* q1 = reinterpret_cast<const u32x4*>(id_map + (size_t)(ch + kRetinaThreads) * 16);
+    const u32x4 i00 = q0[0], i01 = q0[1], i10 = q1[0], i11 = q1[1];
+    fold(a0, b0, c0, i00, i01);
+    fold(a1, b1, c1, i10, i11);
+  }
+  for (; ch < n_chunk; ch += kRetinaThreads) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)ch * 48);
+    const u32x4* q = reinterpret_cast<const u32x4*>(id_map + (size_t)ch * 16);
+    fold(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), q[0], q[1]);
   }
   // tail pixels (n_pix not a multiple of 16)
   for (int px = n_chunk * 16 + threadIdx.x; px < n_pix; px += kRetinaThreads) {
-    const int id = id_map[px];
-    if (id > 0) atomicAdd(&acc[id - 1], (unsigned int)src[(size_t)px * 3 + (pale[id - 1] ? 2 : 1)]);
+    const unsigned int tid = (unsigned short)id_map[px];
+    const int id = (int)(tid & 0x7fffu);
+    if (id > 0) atomicAdd(&acc[id - 1], (unsigned int)src[(size_t)px * 3 + ((tid & 0x8000u) ? 2 : 1)]);
   }
   __syncthreads();
   float* dst = out + (size_t)img * n_omm * 2;

@@ -91,7 +91,9 @@ class Retina:
 
     def _device_constants(self, torch, device):
         if self._dev is None or self._dev[0] != device:
-            self._dev = (device, torch.as_tensor(self.id_map.ravel(), device=device),
+            ids = self.id_map.ravel().astype(np.int64)
+            typed = ids | (np.where(ids > 0, self.pale_mask[np.maximum(ids, 1) - 1], 0).astype(np.int64) << 15)
+            self._dev = (device, torch.as_tensor(typed.astype(np.uint16).view(np.int16), device=device),
                          torch.as_tensor(self.pale_mask, device=device), torch.as_tensor(self.inv_norm, device=device))
         return self._dev[1:]
 

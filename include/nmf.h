@@ -99,9 +99,9 @@ double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_ste
 /* ---- sensors the north star names; the reference snapshot holds only their constants
  * (src/flygym/assets/model/legacy/flygym1_config.yaml:141-192), so semantics are build-defined. ---- */
 
-/* Hex-ommatidia resample of raw eye images.  images[n_images][n_pixels][3] uint8 RGB; id_map[n_pixels] int16
- * (0 = no ommatidium, k = ommatidium k-1; shared by all images); pale[n_ommatidia] uint8 (1 = pale type, reads
- * blue; 0 = yellow type, reads green); inv_norm[k] = 1 / (255 * pixels of ommatidium k);
+/* Hex-ommatidia resample of raw eye images.  images[n_images][n_pixels][3] uint8 RGB; id_map[n_pixels] 16-bit:
+ * bits 0..14 = 0 (no ommatidium) or k (ommatidium k-1), bit 15 = that ommatidium is pale; shared by all images;
+ * pale[n_ommatidia] uint8 (1 = pale type, reads blue; 0 = yellow type, reads green); inv_norm[k] = 1 / (255 * pixels of ommatidium k);
  * out[n_images][n_ommatidia][2] float32 (channel 0 yellow, 1 pale).  Buffers 16-byte aligned. */
 int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const uint8_t* pale_dev,
                         const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
