@@ -47,9 +47,12 @@ def parse_args():
     ap.add_argument("--worlds-per-gpu", type=int, default=4096)
     ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="physics steps fused into one kernel launch (= one control tick)")
+    ap.add_argument("--workload", choices=["cpg", "replay"], default="cpg",
+                    help="cpg: BASELINE config 2 (position-actuated tripod CPG); replay: the reference benchmark's "
+                         "kinematic replay of the Spotlight clip (world w <- partition w %% 20)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=60000)
+    ap.add_argument("--cpu-steps", type=int, default=200000)
     return ap.parse_args()
 
 
@@ -66,7 +69,7 @@ def cpu_baseline(model_blob, table_row, act_ids, warmup, n_steps):
     dt = time.perf_counter() - t0
     return {
         "value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-        "sample": f"1 world x {n_steps} replay steps after {warmup} warm-up steps, float64 C oracle "
+        "sample": f"1 world x {n_steps} steps of the same control table after {warmup} warm-up steps, float64 C oracle "
                   f"(oracle/nmf_oracle.c), {dt:.1f} s on 1 of {os.cpu_count()} host cores",
     }
 
@@ -110,9 +113,16 @@ def main():
     sim = HIPSimulation(world, n_worlds=n_local, device=local_rank)
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
     replay = ReplayTargetData(sim.timestep, order)
-    table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
-    table = torch.as_tensor(
-        replay.make_target_angles_all_worlds(n_local, table_steps, first_world=rank * n_local), device=sim.device)
+    if args.workload == "replay":
+        table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
+        table_np = replay.make_target_angles_all_worlds(n_local, table_steps, first_world=rank * n_local)
+    else:
+        from flygym_amd.controllers import TripodCPG
+
+        table_steps = 2500  # three 12 Hz gait cycles: the table wraps around seamlessly
+        table_np = TripodCPG(order, sim.timestep).targets(n_local, table_steps, first_world=rank * n_local,
+                                                          total_worlds=n_local * world_size)
+    table = torch.as_tensor(table_np, device=sim.device)
     act_ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
     maps = sim._ids_by_fly[fly.name]
 
@@ -175,8 +185,11 @@ def main():
             "config": {
                 "workload": "4096 flies/GPU, flat ground, LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
-                            + ", position-actuated kinematic replay of the Spotlight tripod-walking clip "
-                              "(reference benchmark protocol), adhesion on",
+                            + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
+                               if args.workload == "cpg" else
+                               ", position-actuated kinematic replay of the Spotlight tripod-walking clip "
+                               "(reference benchmark protocol)") + ", adhesion on",
+                "control": args.workload,
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
                 "timestep": sim.timestep, "realtime_factor": value * sim.timestep,
                 "parallelism": f"env-shard x{world_size}" + (", RCCL all-gather of obs per control tick" if use_dist else ""),
@@ -186,14 +199,14 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "nmf_step_kernel<Topo<6,8,11>>", "kernel_ms_per_launch": ms,
+                "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>>", "kernel_ms_per_launch": ms,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 "note": "the step is VALU/LDS-latency bound by construction (state crosses HBM once per launch); "
                         "see DESIGN.md for the instruction-side analysis",
             },
         }
         if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), replay.dof_angles[:table_steps].astype(np.float32),
+            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), np.ascontiguousarray(table_np[0]),
                                                np.arange(42, dtype=np.int32), args.warmup, args.cpu_steps)
     if use_dist:
         dist.barrier()

@@ -1,0 +1,88 @@
+"""Open-loop controllers that produce position-actuator targets for the batched engine.
+
+``TripodCPG`` is the "position-actuated CPG tripod gait" of BASELINE config 2.  The reference snapshot has
+no CPG (flygym 2.0.1 dropped flygym 1.x's controllers), so this one is build-defined:
+
+* six phase oscillators, one per leg, advancing at ``frequency`` (default 12 Hz); tripod phase biases
+  ``{lf, rm, lh} = 0`` and ``{rf, lm, rh} = pi``;
+* each leg's seven actuated joint angles are a periodic function of its phase: one step cycle cut from the
+  Spotlight walking clip (the mean stride between the clip's swing onsets of that leg), resampled on a uniform
+  phase grid and blended to be periodic;
+* world ``w`` of ``n_worlds`` starts with the global phase offset ``2 pi w / n_worlds`` — deterministic, seed free.
+
+The controller emits a ``(n_worlds, steps, 42)`` float32 target table on the GPU, i.e. exactly the input of
+``HIPSimulation.step_replay`` / ``nmf_step_replay``: the CPG runs inside the stepping kernel's control-load stage.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .anatomy import LEGS, JointDOF
+from .replay import MotionSnippet
+
+__all__ = ["TripodCPG"]
+
+TRIPOD_PHASE_BIAS = {"lf": 0.0, "rm": 0.0, "lh": 0.0, "rf": np.pi, "lm": np.pi, "rh": np.pi}
+
+
+class TripodCPG:
+    def __init__(self, actuated_dofs: list[JointDOF], timestep: float, *, frequency: float = 12.0, n_phase_bins: int = 256):
+        self.actuated_dofs = list(actuated_dofs)
+        self.timestep = float(timestep)
+        self.frequency = float(frequency)
+        self.n_bins = int(n_phase_bins)
+        clip = MotionSnippet().get_joint_angles(timestep, self.actuated_dofs)          # (T, 42) at the sim timestep
+        self.leg_of_dof = np.array([LEGS.index(d.child.pos) for d in self.actuated_dofs])
+        self.cycle = np.zeros((self.n_bins, len(self.actuated_dofs)), dtype=np.float32)
+        for leg in range(6):
+            cols = np.where(self.leg_of_dof == leg)[0]
+            self.cycle[:, cols] = self._step_cycle(clip[:, cols])
+
+    def _step_cycle(self, angles: np.ndarray) -> np.ndarray:
+        """One periodic stride of a leg: stance/swing onsets from the femur-tibia (4th actuated) angle's
+        upward mean crossings, strides resampled to ``n_bins`` phase bins and averaged."""
+        key = angles[:, min(5, angles.shape[1] - 1)]
+        centred = key - key.mean()
+        onsets = np.where((centred[:-1] < 0) & (centred[1:] >= 0))[0]
+        onsets = onsets[np.diff(onsets, prepend=-10 ** 9) > int(0.02 / self.timestep)]   # debounce 20 ms
+        grid = np.linspace(0.0, 1.0, self.n_bins, endpoint=False)
+        strides = []
+        for a, b in zip(onsets[:-1], onsets[1:]):
+            if b - a < int(0.03 / self.timestep):
+                continue
+            src = np.linspace(0.0, 1.0, b - a, endpoint=False)
+            strides.append(np.stack([np.interp(grid, src, angles[a:b, k]) for k in range(angles.shape[1])], axis=1))
+        if not strides:
+            raise ValueError("no stride found in the clip")
+        cyc = np.mean(strides, axis=0)
+        # make the cycle periodic: remove the end-to-start jump linearly over the cycle
+        jump = cyc[0] - (2 * cyc[-1] - cyc[-2])
+        cyc = cyc + np.outer(grid, jump)
+        return cyc.astype(np.float32)
+
+    def phases(self, n_worlds: int, steps: int, start_step: int = 0, first_world: int = 0,
+               total_worlds: int | None = None) -> np.ndarray:
+        """(n_worlds, steps, 6) oscillator phases in [0, 2 pi); ``first_world`` / ``total_worlds`` place a
+        shard of worlds inside a larger (multi-GPU) population."""
+        t = (start_step + np.arange(steps)) * self.timestep
+        world = 2 * np.pi * (first_world + np.arange(n_worlds)) / (total_worlds or n_worlds)
+        bias = np.array([TRIPOD_PHASE_BIAS[leg] for leg in LEGS])
+        ph = 2 * np.pi * self.frequency * t[None, :, None] + world[:, None, None] + bias[None, None, :]
+        return np.mod(ph, 2 * np.pi)
+
+    def targets(self, n_worlds: int, steps: int, start_step: int = 0, device=None, first_world: int = 0,
+                total_worlds: int | None = None):
+        """Target table ``(n_worlds, steps, n_act)`` float32 (torch tensor on ``device`` if given, else numpy)."""
+        ph = self.phases(n_worlds, steps, start_step, first_world, total_worlds)[..., self.leg_of_dof]   # (W, S, 42)
+        x = ph / (2 * np.pi) * self.n_bins
+        i0 = np.floor(x).astype(np.int64) % self.n_bins
+        frac = (x - np.floor(x)).astype(np.float32)
+        cols = np.arange(len(self.actuated_dofs))[None, None, :]
+        table = (1 - frac) * self.cycle[i0, cols] + frac * self.cycle[(i0 + 1) % self.n_bins, cols]
+        table = np.ascontiguousarray(table.astype(np.float32))
+        if device is None:
+            return table
+        import torch
+
+        return torch.as_tensor(table, device=device)
