@@ -597,6 +597,16 @@ __device__ __forceinline__ float impedance(const float* si, float r) {
   return d0 + y * (dmax - d0);
 }
 
+// Refresh the fields of the contact registers that also live in LDS.  Called right after every non-inlined
+// ABA sweep so that only the row residuals (aref, jar) stay live in registers across the call.
+template <class TP>
+__device__ __forceinline__ void contact_reload(ContactRegs& c, const FlyLds<TP>& s, int lane) {
+  if (c.on) {
+    c.r = ld3(s.c_r[lane]); c.D = s.c_D[lane]; c.mu = s.c_mu[lane];
+    c.info = s.c_info[lane] & 0xfffff; c.body = info_body(c.info);
+  }
+}
+
 // rows k = 0..3 :  n + mu t1, n − mu t1, n + mu t2, n − mu t2   applied to the body twist at r
 __device__ __forceinline__ void rows_of_twist(const ContactRegs& c, const Frame& fr, SV t, float* out) {
   V3 vp = t.l + cross(t.a, c.r);
@@ -784,6 +794,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   STAGE(6);
   // ---- unconstrained acceleration
   aba_solve(s, s.qfrc_smooth, s.qacc_smooth, false, 0.f, fr, m, lane);
+  contact_reload(c, s, lane);
   STAGE(7);
 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
@@ -833,6 +844,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       STAGE(9);
       aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
+      contact_reload(c, s, lane);
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
       mul_M(s, search, Mv, m, lane, true);
