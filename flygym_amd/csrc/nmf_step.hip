@@ -64,7 +64,21 @@ struct __align__(16) FlyLds {
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
   int body_cstart[TP::NB + 1];
   int ncon, overflow, iters;
+  // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
+  // ds_* instruction (a float* argument would be a generic pointer -> flat_load / flat_store)
+  __device__ __forceinline__ float* vec(int id) {
+    switch (id) {
+      case 0: return qacc;
+      case 1: return qacc_smooth;
+      case 2: return qfrc_smooth;
+      case 3: return vA;
+      case 4: return vB;
+      case 5: return vC;
+      default: return vD;
+    }
+  }
 };
+enum { V_QACC = 0, V_QACC_SMOOTH = 1, V_QFRC_SMOOTH = 2, V_A = 3, V_B = 4, V_C = 5, V_D = 6 };
 
 __device__ __forceinline__ int info_geom(int i) { return i & 0xff; }
 __device__ __forceinline__ int info_sensor(int i) { return ((i >> 8) & 0xf) - 1; }
@@ -156,7 +170,6 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
     // component r of the position:  R_b = R_parent * Rrel_b ,  p_b = p_parent + R_parent * off_b
     const LaneRole L = lane_role<TP>(lane);
     const int r3 = L.r < 3 ? L.r : 2;
-    const bool live3 = L.grp < TP::NLEG && L.r < 3;
     float R0 = s.xmat[0][3 * r3], R1 = s.xmat[0][3 * r3 + 1], R2 = s.xmat[0][3 * r3 + 2];
     float p = s.xpos[0][r3];
     const int b0 = 1 + L.lg * TP::NBL;
@@ -168,10 +181,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       const float n1 = R0 * M[1] + R1 * M[4] + R2 * M[7];
       const float n2 = R0 * M[2] + R1 * M[5] + R2 * M[8];
       R0 = n0; R1 = n1; R2 = n2;
-      if (live3) {
-        s.xmat[b0 + l][3 * L.r] = R0; s.xmat[b0 + l][3 * L.r + 1] = R1; s.xmat[b0 + l][3 * L.r + 2] = R2;
-        s.xpos[b0 + l][L.r] = p;
-      }
+      s.xmat[b0 + l][3 * r3] = R0; s.xmat[b0 + l][3 * r3 + 1] = R1; s.xmat[b0 + l][3 * r3 + 2] = R2;
+      s.xpos[b0 + l][r3] = p;
     });
   }
   WSYNC();
@@ -346,8 +357,9 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
 // ------------------------------------------------------------------ chain sweeps
 // Lane layout for everything that walks a leg: the wave is 8 groups of 8 lanes; group g < NLEG owns
 // leg g and lane r < 6 of the group owns component r of a spatial vector (or row r of a 6x6).
-// Groups >= NLEG and lanes r >= 6 shadow harmless work (loads clamped, stores masked) so that every
-// lane runs the same instruction stream and the DPP reductions stay converged.
+// Groups >= NLEG shadow the last leg and lanes r >= 6 shadow row 5: they compute bit-identical values and
+// store them to the same LDS words as their twins, so the sweeps are branch-free straight-line code (no exec
+// masking) and the DPP reductions stay converged; `mask` removes the shadow rows from group sums.
 // T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
 template <class TP>
 __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
@@ -360,7 +372,7 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
   static_for<TP::NDL>([&](auto D) {
     constexpr int d = decltype(D)::value;
     t += x[j0 + d] * s.S[j0 + d][L.rr];
-    if constexpr (TP::is_last(d)) { if (L.live) T[b0 + TP::lbody(d)][L.r] = t; }
+    if constexpr (TP::is_last(d)) T[b0 + TP::lbody(d)][L.rr] = t;
   });
   WSYNC();
 }
@@ -374,7 +386,7 @@ __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const De
   static_for<TP::NBL>([&](auto I) {
     constexpr int l = TP::NBL - 1 - decltype(I)::value;
     acc += W[b0 + l][L.rr];
-    if (L.live) W[b0 + l][L.r] = acc;
+    W[b0 + l][L.rr] = acc;
   });
   // root = own + the six leg bases (group sums are free: every group holds its base in acc)
   WSYNC();
@@ -447,13 +459,16 @@ __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& 
 //   root           : IA_root a = (wrench of tau_root) - pA_root, 6x6 Cholesky in one lane
 //   forward sweep  : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
 template <class TP>
-__device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x, bool withK, float hdamp,
-                          const Frame& fr, const DevModel& m, int lane) {
+__device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
+                          const DevModel& m, int lane) {
+  const float* tau = s.vec(tau_id);
+  float* x = s.vec(x_id);
+  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const LaneRole L = lane_role<TP>(lane);
   const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
   AbaHandoff<TP>& H = *reinterpret_cast<AbaHandoff<TP>*>(&s.T[0][0]);
-  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL];   // this lane's row of U_j and the group-uniform u_j, 1/D_j
+  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[TP::NDL];   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j
   {
     float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pA = 0.f;
@@ -474,7 +489,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
       float U = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; i++) U += IA[i] * sj[i];
-      const float sr = L.mask * s.S[j][L.rr];
+      const float sown = s.S[j][L.rr];
+      const float sr = L.mask * sown;
+      Sreg[d] = sown;
       const float D = grp8_sum(sr * U) + s.arm[j] + hdamp * s.damp[j];
       const float sp = grp8_sum(sr * pA);
       float invD = __builtin_amdgcn_rcpf(D);
@@ -486,11 +503,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
       IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
       pA += k * u;
     });
-    if (L.live) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) H.legIA[L.grp][L.r][i] = IA[i];
-      H.legpA[L.grp][L.r] = pA;
-    }
+    for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
+    H.legpA[L.lg][L.rr] = pA;
   }
   WSYNC();
   if (lane < 6) {     // root rows
@@ -567,9 +582,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, const float* tau, float* x
       const int j = j0 + d;
       const float ua = grp8_sum(Ureg[d] * a);
       const float xj = (ureg[d] - ua) * invDreg[d];
-      if (L.live && L.r == 0) x[j] = xj;
-      a += xj * s.S[j][L.rr];
-      if constexpr (TP::is_last(d)) { if (L.live) s.T[b0 + TP::lbody(d)][L.r] = a; }
+      x[j] = xj;
+      a += xj * Sreg[d];
+      if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
     });
   }
   WSYNC();
@@ -650,7 +665,7 @@ __device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame
     const int cbeg = s.body_cstart[b0 + l];
     for (int cc = cbeg; cc < cend; ++cc) acc += s.c_w[cc][L.rr];
     cend = cbeg;
-    if (L.live) s.W[b0 + l][L.r] = acc;
+    s.W[b0 + l][L.rr] = acc;
   });
   WSYNC();
   if (lane < 6) {
@@ -722,9 +737,9 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     if (lane < 6) s.W[0][lane] = v;
     static_for<TP::NDL>([&](auto D) {
       constexpr int d = decltype(D)::value;
-      if (L.live) vb[j0 + d][L.r] = v;
+      vb[j0 + d][L.rr] = v;
       v += s.qvel[j0 + d] * s.S[j0 + d][L.rr];
-      if constexpr (TP::is_last(d)) { if (L.live) s.W[b0 + TP::lbody(d)][L.r] = v; }
+      if constexpr (TP::is_last(d)) s.W[b0 + TP::lbody(d)][L.rr] = v;
     });
     WSYNC();
     // reference acceleration of the contact rows needs the body velocities (still in W here)
@@ -746,7 +761,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     static_for<TP::NDL>([&](auto D) {
       constexpr int d = decltype(D)::value;
       a += vb[j0 + d][L.rr];
-      if constexpr (TP::is_last(d)) { if (L.live) s.T[b0 + TP::lbody(d)][L.r] = a; }
+      if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
     });
   }
   WSYNC();
@@ -793,7 +808,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   WSYNC();
   STAGE(6);
   // ---- unconstrained acceleration
-  aba_solve(s, s.qfrc_smooth, s.qacc_smooth, false, 0.f, fr, m, lane);
+  aba_solve(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane);
   contact_reload(c, s, lane);
   STAGE(7);
 
@@ -843,7 +858,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       STAGE(9);
-      aba_solve(s, grad, search, true, 0.f, fr, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
+      aba_solve(s, V_A, V_B, true, 0.f, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
       contact_reload(c, s, lane);
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
@@ -936,7 +951,7 @@ __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STA
   const float h = m.timestep;
   for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
   WSYNC();
-  aba_solve(s, s.vA, s.vB, false, h, fr, m, lane);
+  aba_solve(s, V_A, V_B, false, h, m, lane);
   for (int j = lane; j < TP::NV; j += kWave) s.qvel[j] += h * s.vB[j];
   WSYNC();
   if (lane == 0) {
