@@ -55,7 +55,8 @@ struct __align__(16) FlyLds {
   float ctrl[kMaxCtrl];
   float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
-  float Ib[TP::NB][10];
+  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products)
+  float Isym[TP::NB][21];               // the same as a symmetric 6x6 (upper triangle): row fetches for the ABA
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][6], W[TP::NB][6];
@@ -228,6 +229,11 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
     I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
     I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
     I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
+    float* Q = s.Isym[b];                // [[I, [h]x], [-[h]x, m 1]], upper triangle row-major
+    Q[0] = I[4]; Q[1] = I[7]; Q[2] = I[8]; Q[3] = 0.f;   Q[4] = -I[3]; Q[5] = I[2];
+    Q[6] = I[5]; Q[7] = I[9]; Q[8] = I[3]; Q[9] = 0.f;   Q[10] = -I[1];
+    Q[11] = I[6]; Q[12] = -I[2]; Q[13] = I[1]; Q[14] = 0.f;
+    Q[15] = ms; Q[16] = 0.f; Q[17] = 0.f; Q[18] = ms; Q[19] = 0.f; Q[20] = ms;
   }
   WSYNC();
 }
@@ -458,6 +464,23 @@ __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& 
 //                    IA -= U UT / D, pA += U (tau - s.pA) / D   (group sums by DPP)
 //   root           : IA_root a = (wrench of tau_root) - pA_root, 6x6 Cholesky in one lane
 //   forward sweep  : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
+// one articulated-body elimination step for hinge/axis `sj` (6 floats, group-uniform) with this lane's row IA,
+// bias component pA, own component `sown`, diagonal term delta and generalized force tauj
+__device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float* sj, float sown, float mask, float delta,
+                                         float tauj, float& Uout, float& uout, float& invDout) {
+  const float U = (IA[0] * sj[0] + IA[1] * sj[1]) + (IA[2] * sj[2] + IA[3] * sj[3]) + (IA[4] * sj[4] + IA[5] * sj[5]);
+  const float sr = mask * sown;
+  const float D = grp8_sum(sr * U) + delta;
+  const float sp = grp8_sum(sr * pA);
+  const float invD = __builtin_amdgcn_rcpf(D);
+  const float u = tauj - sp;
+  const float k = U * invD;
+  IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
+  IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
+  pA += k * u;
+  Uout = mask * U; uout = u; invDout = invD;
+}
+
 template <class TP>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
                           const DevModel& m, int lane) {
@@ -468,125 +491,83 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
   AbaHandoff<TP>& H = *reinterpret_cast<AbaHandoff<TP>*>(&s.T[0][0]);
-  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[TP::NDL];   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j
-  {
-    float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float pA = 0.f;
-    static_for<TP::NDL>([&](auto DD) {
-      constexpr int d = TP::NDL - 1 - decltype(DD)::value;
-      const int j = j0 + d;
-      if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
-        const int b = b0 + TP::lbody(d);
-        float row[6];
-        inertia_row(s.Ib[b], L.rr, row);
-        if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+  // offsets of row rr inside the symmetric storage (lane constants)
+  int so[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) IA[i] += row[i];
-      }
-      float sj[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
-      float U = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; i++) U += IA[i] * sj[i];
-      const float sown = s.S[j][L.rr];
-      const float sr = L.mask * sown;
-      Sreg[d] = sown;
-      const float D = grp8_sum(sr * U) + s.arm[j] + hdamp * s.damp[j];
-      const float sp = grp8_sum(sr * pA);
-      float invD = __builtin_amdgcn_rcpf(D);
-      invD = invD * (2.0f - D * invD);
-      const float u = tau[j] - sp;
-      Ureg[d] = L.mask * U; ureg[d] = u; invDreg[d] = invD;
-      const float k = U * invD;
-      IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
-      IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
-      pA += k * u;
-    });
-#pragma unroll
-    for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
-    H.legpA[L.lg][L.rr] = pA;
+  for (int c = 0; c < 6; c++) {
+    const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr;
+    so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
   }
+  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[TP::NDL];   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j
+  float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float pA = 0.f;
+  // ---- backward sweep along the leg
+  static_for<TP::NDL>([&](auto DD) {
+    constexpr int d = TP::NDL - 1 - decltype(DD)::value;
+    const int j = j0 + d;
+    if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
+      const int b = b0 + TP::lbody(d);
+      float row[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
+      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+#pragma unroll
+      for (int i = 0; i < 6; i++) IA[i] += row[i];
+    }
+    float sj[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
+    const float sown = s.S[j][L.rr];
+    Sreg[d] = sown;
+    aba_step(IA, pA, sj, sown, L.mask, s.arm[j] + hdamp * s.damp[j], tau[j], Ureg[d], ureg[d], invDreg[d]);
+  });
+#pragma unroll
+  for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
+  H.legpA[L.lg][L.rr] = pA;
   WSYNC();
-  if (lane < 6) {     // root rows
+  // ---- root: every group eliminates the six root dofs redundantly (no single-lane solve, no broadcast)
+  float Ur[6], ur[6], invDr[6], Sr[6];
+  {
     float row[6];
-    inertia_row(s.Ib[0], lane, row);
-    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, lane, fr);
-    float pA = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
+    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+    pA = 0.f;
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) row[i] += H.legIA[k][lane][i];
-      pA += H.legpA[k][lane];
-    }
-    // wrench of the root generalized force: n = R tau_rot, f = tau_trans
-    float w;
-    if (lane < 3) w = s.xmat[0][3 * lane] * tau[3] + s.xmat[0][3 * lane + 1] * tau[4] + s.xmat[0][3 * lane + 2] * tau[5];
-    else w = tau[lane - 3];
-#pragma unroll
-    for (int i = 0; i < 6; i++) H.rootA[lane][i] = row[i];
-    H.rootb[lane] = w - pA;
-  }
-  WSYNC();
-  if (lane == 0) {
-    float A[6][6], rhs[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      rhs[i] = H.rootb[i];
-#pragma unroll
-      for (int j = 0; j <= i; j++) A[i][j] = H.rootA[i][j];
+      for (int i = 0; i < 6; i++) row[i] += H.legIA[k][L.rr][i];
+      pA += H.legpA[k][L.rr];
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      float d = A[j][j];
+    for (int i = 0; i < 6; i++) IA[i] = row[i];
+    static_for<6>([&](auto DD) {
+      constexpr int j = 5 - decltype(DD)::value;
+      float sj[6];
 #pragma unroll
-      for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
-      const float inv = rsqrtf(d);
-      A[j][j] = inv;                 // store 1 / L_jj
-#pragma unroll
-      for (int i = j + 1; i < 6; i++) {
-        float v = A[i][j];
-#pragma unroll
-        for (int k = 0; k < j; k++) v -= A[i][k] * A[j][k];
-        A[i][j] = v * inv;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      float v = rhs[i];
-#pragma unroll
-      for (int k = 0; k < i; k++) v -= A[i][k] * rhs[k];
-      rhs[i] = v * A[i][i];
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; i--) {
-      float v = rhs[i];
-#pragma unroll
-      for (int k = i + 1; k < 6; k++) v -= A[k][i] * rhs[k];
-      rhs[i] = v * A[i][i];
-    }
-    // rhs = root twist acceleration (w; v) in world axes; dof coordinates: trans = v, rot = RT w
-#pragma unroll
-    for (int i = 0; i < 6; i++) s.T[0][i] = rhs[i];
-    x[0] = rhs[3]; x[1] = rhs[4]; x[2] = rhs[5];
-    const float* R = s.xmat[0];
-    x[3] = R[0] * rhs[0] + R[3] * rhs[1] + R[6] * rhs[2];
-    x[4] = R[1] * rhs[0] + R[4] * rhs[1] + R[7] * rhs[2];
-    x[5] = R[2] * rhs[0] + R[5] * rhs[1] + R[8] * rhs[2];
-  }
-  WSYNC();
-  {
-    float a = s.T[0][L.rr];
-    static_for<TP::NDL>([&](auto DD) {
-      constexpr int d = decltype(DD)::value;
-      const int j = j0 + d;
-      const float ua = grp8_sum(Ureg[d] * a);
-      const float xj = (ureg[d] - ua) * invDreg[d];
-      x[j] = xj;
-      a += xj * Sreg[d];
-      if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
+      for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
+      const float sown = s.S[j][L.rr];
+      Sr[j] = sown;
+      aba_step(IA, pA, sj, sown, L.mask, 0.f, tau[j], Ur[j], ur[j], invDr[j]);
     });
   }
+  // ---- forward sweep: root dofs, then down the leg
+  float a = 0.f;
+  static_for<6>([&](auto DD) {
+    constexpr int j = decltype(DD)::value;
+    const float xj = (ur[j] - grp8_sum(Ur[j] * a)) * invDr[j];
+    x[j] = xj;
+    a += xj * Sr[j];
+  });
+  s.T[0][L.rr] = a;
+  static_for<TP::NDL>([&](auto DD) {
+    constexpr int d = decltype(DD)::value;
+    const int j = j0 + d;
+    const float xj = (ureg[d] - grp8_sum(Ureg[d] * a)) * invDreg[d];
+    x[j] = xj;
+    a += xj * Sreg[d];
+    if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
+  });
   WSYNC();
 }
 
