@@ -864,10 +864,18 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
         if (d2 <= 0.f || d1 == 0.f) break;
         if (d1 < 0.f) lo = alpha; else hi = alpha;
         float next = alpha - d1 / d2;
-        if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
+        bool bisected = false;
+        if (hi >= 0.f && (next <= lo || next >= hi)) { next = 0.5f * (lo + hi); bisected = true; }
+        // phi' is linear while the active set does not change: then `next` is the exact minimiser
+        bool moved = false;
+        if (c.on) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) moved |= ((c.jar[k] + alpha * c.jv[k]) < 0.f) != ((c.jar[k] + next * c.jv[k]) < 0.f);
+        }
+        const bool same = !bisected && !__any(moved);
         float change = fabsf(next - alpha);
         alpha = next;
-        if (change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
+        if (same || change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
       }
       STAGE(12);
       if (alpha <= 0.f) break;

@@ -788,10 +788,14 @@ static void solve_constraints(const omodel* m, odata* d) {
       if (d2 <= 0 || d1 == 0) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       real next = alpha - d1 / d2;
-      if (hi >= 0 && (next <= lo || next >= hi)) next = (real)0.5 * (lo + hi);
+      int bisected = 0;
+      if (hi >= 0 && (next <= lo || next >= hi)) { next = (real)0.5 * (lo + hi); bisected = 1; }
+      /* phi' is linear while the active set does not change: then `next` is the exact minimiser */
+      int same = !bisected;
+      for (int i = 0; same && i < nefc; i++) same = ((jar[i] + alpha * jv[i]) < 0) == ((jar[i] + next * jv[i]) < 0);
       real change = R_FABS(next - alpha);
       alpha = next;
-      if (change <= (real)8 * R_EPS * R_FABS(next)) break;
+      if (same || change <= (real)8 * R_EPS * R_FABS(next)) break;
     }
     if (alpha <= 0) break;
     for (int j = 0; j < nv; j++) { qacc[j] += alpha * search[j]; Ma[j] += alpha * Mv[j]; }
