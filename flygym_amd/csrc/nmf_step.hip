@@ -383,9 +383,10 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
   WSYNC();
 }
 
-// W[b] <- sum of W over the subtree of b (in place), then out[j] = S_j · W[body(j)]
-template <class TP>
-__device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const DevModel& m, int lane) {
+// W[b] <- sum of W over the subtree of b (in place), then emit(j, S_j · W[body(j)]) for every dof j
+// (the projection and whatever the caller does with it share one pass: no intermediate vector, no extra sync)
+template <class TP, class Emit>
+__device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Emit&& emit) {
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = 1 + L.lg * TP::NBL;
   float acc = 0.f;
@@ -403,20 +404,18 @@ __device__ void sweep_project(FlyLds<TP>& s, float (*W)[6], float* out, const De
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(W[dof_body_of<TP>(j)]));
+  for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[dof_body_of<TP>(j)])));
   WSYNC();
 }
 
 // y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x).
 // have_twists: T already holds twists(x) (the ABA leaves them there).
-template <class TP>
-__device__ void mul_M(FlyLds<TP>& s, const float* x, float* y, const DevModel& m, int lane, bool have_twists = false) {
+template <class TP, class Emit>
+__device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const DevModel& m, int lane, bool have_twists, Emit&& emit) {
   if (!have_twists) sweep_twists(s, x, s.T, m, lane);
   for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
   WSYNC();
-  sweep_project(s, s.W, y, m, lane);
-  for (int j = lane; j < TP::NV; j += kWave) y[j] += s.arm[j] * x[j];
-  WSYNC();
+  sweep_project(s, s.W, m, lane, [&](int j, float v) { emit(j, v + s.arm[j] * x[j]); });
 }
 
 // row `r` of the 6x6 spatial inertia [[I, [h]x], [-[h]x, m 1]] built from (m, h, I sym6)
@@ -623,9 +622,9 @@ __device__ float constraint_cost(const ContactRegs& c) {
 // out = sign * JT f  for the contact forces f_k = −D jar_k on the active rows: every contact lane
 // publishes its world wrench (about the root origin) in c_w, then the leg groups suffix-sum the
 // wrenches of their bodies' contacts (contacts are sorted by body) and the dofs project.
-template <class TP>
-__device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign, float* out,
-                                const DevModel& m, int lane) {
+template <class TP, class Emit>
+__device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign,
+                                                const DevModel& m, int lane, Emit&& emit) {
   if (c.on) {
     float f[4]; int act = 0;
 #pragma unroll
@@ -657,7 +656,7 @@ __device__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame
     s.W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) out[j] = dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)]));
+  for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)])));
   WSYNC();
 }
 
@@ -781,12 +780,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     if (last) st.actuator_force[(size_t)w * m.nu + u] = f;     // pure output: only the launch's last step stores it
   }
   WSYNC();
-  sweep_project(s, s.W, s.qfrc_smooth, m, lane);
-  for (int j = lane; j < TP::NV; j += kWave) {
-    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - m.dof_damping[j] * s.qvel[j];
-    s.qfrc_smooth[j] += passive + s.vA[j];
-  }
-  WSYNC();
+  sweep_project(s, s.W, m, lane, [&](int j, float v) {
+    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - s.damp[j] * s.qvel[j];
+    s.qfrc_smooth[j] = v + passive + s.vA[j];
+  });
   STAGE(6);
   // ---- unconstrained acceleration
   aba_solve(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane);
@@ -801,12 +798,14 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   } else {
     float* Ma = s.vC; float* grad = s.vA; float* search = s.vB; float* Mv = s.vD;
     // candidate 1: warm start
-    mul_M(s, s.qacc, Ma, m, lane);                  // qacc still holds the warm start
+    float g = 0.f;
+    mul_M(s, s.qacc, m, lane, false, [&](int j, float v) {      // qacc still holds the warm start
+      Ma[j] = v;
+      g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (v - s.qfrc_smooth[j]);
+    });
     if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
-    float g = 0.f;
-    for (int j = lane; j < TP::NV; j += kWave) g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
     float cost = wave_sum(g) + constraint_cost<TP>(c);
     // candidate 2: unconstrained acceleration
     sweep_twists(s, s.qacc_smooth, s.T, m, lane);
@@ -826,16 +825,14 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     STAGE(8);
     for (int iter = 0; iter < m.max_iter; ++iter) {
       // gradient = Ma − qfrc_smooth − Jᵀ f
-      contact_project(s, c, fr, -1.0f, grad, m, lane);
       float gn = 0.f, gm = 0.f;
-      for (int j = lane; j < TP::NV; j += kWave) {
-        float jtf = grad[j], gj = jtf + Ma[j] - s.qfrc_smooth[j];
+      contact_project(s, c, fr, -1.0f, m, lane, [&](int j, float jtf) {
+        float gj = jtf + Ma[j] - s.qfrc_smooth[j];
         float mag = fabsf(Ma[j]) + fabsf(s.qfrc_smooth[j]) + fabsf(jtf);
         grad[j] = -gj;   // store the right-hand side of the Newton system
         gn += gj * gj; gm += mag * mag;
-      }
+      });
       gn = wave_sum(gn); gm = wave_sum(gm);
-      WSYNC();
       // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       STAGE(9);
@@ -843,9 +840,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       contact_reload(c, s, lane);
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
-      mul_M(s, search, Mv, m, lane, true);
       float g1 = 0.f, g2 = 0.f;
-      for (int j = lane; j < TP::NV; j += kWave) { g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * Mv[j]; }
+      mul_M(s, search, m, lane, true, [&](int j, float v) {
+        Mv[j] = v;
+        g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * v;
+      });
       g1 = wave_sum(g1); g2 = wave_sum(g2);
       STAGE(11);
       // exact line search
@@ -896,7 +895,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     STAGE(9);
     // constraint forces
-    contact_project(s, c, fr, 1.0f, s.vD, m, lane);   // qfrc_constraint lives in vD until the Euler step
+    contact_project(s, c, fr, 1.0f, m, lane, [&](int j, float v) { s.vD[j] = v; });   // qfrc_constraint lives in vD until the Euler step
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);
