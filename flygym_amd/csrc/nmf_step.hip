@@ -239,123 +239,147 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
 }
 
 // ------------------------------------------------------------------ collision (geom vs ground plane)
+// Scratch of the collision stage, overlaid on the T..W region (free between steps)
+struct CollisionScratch {
+  float r[kMaxCon][3], dist[kMaxCon];
+  int info[kMaxCon];       // geom | k << 8 | body << 12   (k-th contact of that hull)
+};
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 template <class TP>
 __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
+  static_assert(sizeof(CollisionScratch) <= sizeof(float) * TP::NB * 12, "collision scratch does not fit T..W");
+  CollisionScratch& X = *reinterpret_cast<CollisionScratch*>(&s.T[0][0]);
+  int* geom_slot0 = reinterpret_cast<int*>(&s.vA[0]);     // first contact slot of every geom (kWave ints; NV >= 48... vA..vB)
+  static_assert(2 * TP::NV >= kWave, "slot table does not fit vA..vB");
   const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
   const float pd = m.plane[3];
   const V3 o = ld3(s.xpos[0]);
+  // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
+  int g_body = 0, g_type = -1, g_hadr = 0, g_hnum = 0, cnt = 0;
+  float g_margin = 0.f, cd0 = 0.f, cd1 = 0.f;
+  V3 cp0 = v3(0, 0, 0), cp1 = v3(0, 0, 0);
   bool near = false;
   if (lane < m.ng) {
-    int b = m.geom_body[lane];
-    V3 cw = mat_vec(s.xmat[b], ld3(&m.geom_bsphere[4 * lane]));
-    float dc = dot(n, cw) + dot(n, ld3(s.xpos[b])) - pd;
-    near = dc - m.geom_bsphere[4 * lane + 3] <= m.pair_margin[lane];
+    g_body = m.geom_body[lane]; g_type = m.geom_type[lane]; g_margin = m.pair_margin[lane];
+    g_hadr = m.geom_hulladr[lane]; g_hnum = m.geom_hullnum[lane];
+    const float* R = s.xmat[g_body];
+    const V3 xp = ld3(s.xpos[g_body]);
+    V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * lane]));
+    float dc = dot(n, cw) + dot(n, xp) - pd;
+    near = dc - m.geom_bsphere[4 * lane + 3] <= g_margin;
+    if (near && g_type == GEOM_CAPSULE) {
+      const float rad = m.geom_radius[lane];
+      const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * lane])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * lane])) + xp;
+      const float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
+      const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
+      if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
+      if (d1 <= g_margin) { if (cnt) { cd1 = d1; cp1 = q1; } else { cd0 = d1; cp0 = q1; } cnt++; }
+    }
   }
-  unsigned long long mask = __ballot(near);
-  int ncon = 0, overflow = 0;
-  while (mask) {
-    int g = __ffsll((long long)mask) - 1;
-    mask &= mask - 1;
-    int b = m.geom_body[g];
+  // ---- phase 2: near convex hulls one after the other, each scanned by the whole wave; the geom's
+  // parameters are broadcast from its lane's registers (no memory round trip)
+  unsigned long long hmask = __ballot(near && g_type == GEOM_HULL);
+  int nh = 0;
+  while (hmask) {
+    const int g = __ffsll((long long)hmask) - 1;
+    hmask &= hmask - 1;
+    const int b = __builtin_amdgcn_readlane(g_body, g);
+    const float margin = readlane_f(g_margin, g);
+    const float* V = m.hull_vert + 3 * __builtin_amdgcn_readlane(g_hadr, g);
+    const int nvv = __builtin_amdgcn_readlane(g_hnum, g);
     const float* R = s.xmat[b];
-    V3 xp = ld3(s.xpos[b]);
-    float margin = m.pair_margin[g];
-    if (m.geom_type[g] == GEOM_CAPSULE) {
-      bool valid = false; float dist = 0.f; V3 ps = v3(0, 0, 0);
-      if (lane < 2) {
-        const float* pl = (lane == 0 ? m.geom_p0 : m.geom_p1) + 3 * g;
-        V3 pw = mat_vec(R, ld3(pl)) + xp;
-        float r = m.geom_radius[g];
-        dist = dot(n, pw) - pd - r;
-        valid = dist <= margin;
-        ps = pw - r * n;
-      }
-      unsigned long long vm = __ballot(valid);
-      int slot = ncon + __popcll(vm & ((1ull << lane) - 1ull));
-      if (valid) {
-        if (slot < kMaxCon) {
-          s.c_info[slot] = info_pack(g, -1, b, 0); s.c_D[slot] = dist;
-          st3(s.c_r[slot], (ps - (0.5f * dist) * n) - o);
-        } else overflow = 1;
-      }
-      ncon += __popcll(vm);
-    } else {
-      V3 nb = matT_vec(R, n);
-      float c0 = dot(n, xp) - pd;
-      const float* V = m.hull_vert + 3 * m.geom_hulladr[g];
-      int nvv = m.geom_hullnum[g];
-      float best = INFINITY; int bi = 0x7fffffff;
-      for (int i = lane; i < nvv; i += kWave) {
-        float di = dot(nb, ld3(V + 3 * i)) + c0;
-        if (di < best) { best = di; bi = i; }
-      }
-      wave_argmin(best, bi);
-      float dmin = best; int ia = bi;
-      if (!(dmin <= margin)) continue;
-      float thr = fminf(dmin + m.hull_skin, margin);
-      int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
-      V3 va = ld3(V + 3 * ia);
-      // b: farthest candidate from a
+    const V3 xp = ld3(s.xpos[b]);
+    const V3 nb = matT_vec(R, n);
+    const float c0 = dot(n, xp) - pd;
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < nvv; i += kWave) {
+      float di = dot(nb, ld3(V + 3 * i)) + c0;
+      if (di < best) { best = di; bi = i; }
+    }
+    wave_argmin(best, bi);
+    const float dmin = best; const int ia = bi;
+    if (!(dmin <= margin)) continue;
+    const float thr = fminf(dmin + m.hull_skin, margin);
+    int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
+    const V3 va = ld3(V + 3 * ia);
+    // b: farthest candidate from a
+    best = -INFINITY; bi = 0x7fffffff;
+    for (int i = lane; i < nvv; i += kWave) {
+      V3 vi = ld3(V + 3 * i);
+      float di = dot(nb, vi) + c0;
+      if (di > thr) continue;
+      V3 e = vi - va; float sc = dot(e, e);
+      if (sc > best) { best = sc; bi = i; }
+    }
+    wave_argmax(best, bi);
+    if (best > 1e-10f) {
+      s1 = bi; nsel = 2;
+      const V3 ab = ld3(V + 3 * bi) - va;
+      const float lab2 = dot(ab, ab);
       best = -INFINITY; bi = 0x7fffffff;
       for (int i = lane; i < nvv; i += kWave) {
         V3 vi = ld3(V + 3 * i);
         float di = dot(nb, vi) + c0;
         if (di > thr) continue;
-        V3 e = vi - va; float sc = dot(e, e);
+        V3 cr = cross(vi - va, ab); float sc = dot(cr, cr);
         if (sc > best) { best = sc; bi = i; }
       }
       wave_argmax(best, bi);
-      if (best > 1e-10f) {
-        s1 = bi; nsel = 2;
-        V3 ab = ld3(V + 3 * bi) - va;
-        float lab2 = dot(ab, ab);
-        best = -INFINITY; bi = 0x7fffffff; float side = 0.f;
+      if (best > 1e-10f * lab2) {
+        s2 = bi; nsel = 3;
+        const float side = dot(cross(ld3(V + 3 * bi) - va, ab), nb);
+        const float sg = side > 0.f ? -1.f : 1.f;
+        best = -INFINITY; bi = 0x7fffffff;
         for (int i = lane; i < nvv; i += kWave) {
           V3 vi = ld3(V + 3 * i);
           float di = dot(nb, vi) + c0;
           if (di > thr) continue;
-          V3 cr = cross(vi - va, ab); float sc = dot(cr, cr);
+          float sc = sg * dot(cross(vi - va, ab), nb);
           if (sc > best) { best = sc; bi = i; }
         }
         wave_argmax(best, bi);
-        if (best > 1e-10f * lab2) {
-          s2 = bi; nsel = 3;
-          side = dot(cross(ld3(V + 3 * bi) - va, ab), nb);
-          float sg = side > 0.f ? -1.f : 1.f;
-          best = -INFINITY; bi = 0x7fffffff;
-          for (int i = lane; i < nvv; i += kWave) {
-            V3 vi = ld3(V + 3 * i);
-            float di = dot(nb, vi) + c0;
-            if (di > thr) continue;
-            float sc = sg * dot(cross(vi - va, ab), nb);
-            if (sc > best) { best = sc; bi = i; }
-          }
-          wave_argmax(best, bi);
-          if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
-        }
+        if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
       }
-      if (lane < nsel) {
-        int slot = ncon + lane;
-        int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
-        if (slot < kMaxCon) {
-          V3 v = ld3(V + 3 * vi);
-          float dist = dot(nb, v) + c0;
-          V3 pw = mat_vec(R, v) + xp;
-          s.c_info[slot] = info_pack(g, -1, b, 0); s.c_D[slot] = dist;
-          st3(s.c_r[slot], (pw - (0.5f * dist) * n) - o);
-        } else overflow = 1;
-      }
-      ncon += nsel;
     }
+    if (lane < nsel && nh + lane < kMaxCon) {
+      const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
+      const V3 v = ld3(V + 3 * vi);
+      const float dist = dot(nb, v) + c0;
+      const V3 pw = mat_vec(R, v) + xp;
+      X.info[nh + lane] = g | (lane << 8) | (b << 12);
+      X.dist[nh + lane] = dist;
+      st3(X.r[nh + lane], (pw - (0.5f * dist) * n) - o);
+    }
+    if (lane == g) cnt = nsel;
+    nh += nsel;
   }
-  overflow = __any(overflow) ? 1 : 0;
-  if (ncon > kMaxCon) { ncon = kMaxCon; overflow = 1; }
-  if (lane == 0) { s.ncon = ncon; s.overflow = overflow; }
+  // ---- phase 3: contact slots in geom order.  cnt <= 4, so an exclusive prefix over lanes is three ballots.
+  const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int slot0 = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+  const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+  geom_slot0[lane] = slot0;
+  if (g_type == GEOM_CAPSULE && cnt > 0) {
+    if (slot0 < kMaxCon) { s.c_info[slot0] = info_pack(lane, -1, g_body, 0); s.c_D[slot0] = cd0; st3(s.c_r[slot0], cp0); }
+    if (cnt > 1 && slot0 + 1 < kMaxCon) { s.c_info[slot0 + 1] = info_pack(lane, -1, g_body, 0); s.c_D[slot0 + 1] = cd1; st3(s.c_r[slot0 + 1], cp1); }
+  }
+  WSYNC();
+  if (lane < nh && lane < kMaxCon) {
+    const int info = X.info[lane];
+    const int slot = geom_slot0[info & 0xff] + ((info >> 8) & 0xf);
+    if (slot < kMaxCon) { s.c_info[slot] = info_pack(info & 0xff, -1, (info >> 12) & 0xff, 0); s.c_D[slot] = X.dist[lane]; st3(s.c_r[slot], ld3(X.r[lane])); }
+  }
+  const int ncon = total > kMaxCon ? kMaxCon : total;
+  if (lane == 0) { s.ncon = ncon; s.overflow = total > kMaxCon ? 1 : 0; }
   WSYNC();
   for (int b = lane; b <= TP::NB; b += kWave) {
-    int cnt = 0;
-    for (int c = 0; c < ncon; ++c) cnt += info_body(s.c_info[c]) < b ? 1 : 0;
-    s.body_cstart[b] = cnt;
+    int c_before = 0;
+    for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
+    s.body_cstart[b] = c_before;
   }
   WSYNC();
 }
