@@ -443,6 +443,11 @@ def compile_world(world) -> CompiledModel:
 
     # adhesion: actuator index per leg order (simulation.py:387-404)
     m["plane"] = np.array([0.0, 0.0, 1.0, 0.0])  # ground plane n·x = d  (world.py:251-261)
+    # height map on top of the plane (0 flat, 1 gapped, 2 blocks, 3 mixed) + its maximum height (cull bound)
+    m["terrain_type"] = np.array([int(world.terrain_type)], dtype=np.int32)
+    tp = np.array(world.terrain_params, dtype=np.float64)
+    hmax = {0: 0.0, 1: 0.0, 2: tp[1], 3: 0.35}[int(world.terrain_type)]
+    m["terrain_params"] = np.concatenate([tp, [hmax]])
 
     # ---- invweight0 at qpos0 ---------------------------------------------------
     M0 = rigid.mass_matrix_from_jacobians(m, qpos0)

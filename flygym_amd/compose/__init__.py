@@ -1,9 +1,10 @@
 from .fly import ActuatorType, Fly, GeomFittingOption, MeshType
 from .physics import ContactParams
 from .pose import KinematicPose, KinematicPosePreset
-from .world import BaseWorld, FlatGroundWorld, TetheredWorld
+from .world import (BaseWorld, BlocksTerrainWorld, FlatGroundWorld, GappedTerrainWorld, MixedTerrainWorld,
+                    TetheredWorld)
 
 __all__ = [
     "Fly", "ActuatorType", "MeshType", "GeomFittingOption", "BaseWorld", "FlatGroundWorld",
-    "TetheredWorld", "KinematicPose", "KinematicPosePreset", "ContactParams",
+    "TetheredWorld", "GappedTerrainWorld", "BlocksTerrainWorld", "MixedTerrainWorld", "KinematicPose", "KinematicPosePreset", "ContactParams",
 ]

@@ -17,7 +17,8 @@ from ..utils.math import Rotation3D
 from .fly import Fly
 from .physics import ContactParams
 
-__all__ = ["BaseWorld", "FlatGroundWorld", "TetheredWorld"]
+__all__ = ["BaseWorld", "FlatGroundWorld", "TetheredWorld", "GappedTerrainWorld", "BlocksTerrainWorld",
+           "MixedTerrainWorld"]
 
 
 class BaseWorld(ABC):
@@ -33,6 +34,8 @@ class BaseWorld(ABC):
         self.add_ground_contact_sensors = False
         self.legpos_to_groundcontactsensors_by_fly = None
         self.fixed_base = False
+        self.terrain_type = 0                  # 0 flat, 1 gapped, 2 blocks, 3 mixed (see terrain_height)
+        self.terrain_params = (0.0, 0.0, 0.0, 0.0)
         self._compiled = None
 
     @property
@@ -107,6 +110,68 @@ class FlatGroundWorld(BaseWorld):
                 }
             }
         return f"{fly.name}/"
+
+
+class _TerrainWorld(FlatGroundWorld):
+    """Ground whose height is a piecewise-constant function of (x, y).
+
+    The reference snapshot has only the flat plane and the tether (flygym 1.x's terrains were
+    dropped); the terrains below are build-defined.  Collision treats the ground as a height map: every
+    collision vertex / capsule end is tested against the ground height under it with a vertical normal, so the
+    vertical faces of blocks and gap walls exert no force (the same simplification as a height field).
+    """
+
+    def terrain_height(self, x, y):
+        """numpy restatement of the height function shared by the oracle and the HIP kernel."""
+        import numpy as np
+
+        return _terrain_height(self.terrain_type, self.terrain_params, np.asarray(x, dtype=float), np.asarray(y, dtype=float))
+
+
+def _terrain_height(kind, p, x, y):
+    import numpy as np
+
+    if kind == 1:      # gapped: blocks of width p0 separated by gaps of width p1 and depth p2, perpendicular to x
+        u = x - np.floor(x / (p[0] + p[1])) * (p[0] + p[1])
+        return np.where(u < p[0], 0.0, -p[2])
+    if kind == 2:      # blocks: checkerboard of squares of side p0, every other square raised by p1
+        i, j = np.floor(x / p[0]), np.floor(y / p[0])
+        return np.where(np.mod(i + j, 2.0) != 0, p[1], 0.0)
+    if kind == 3:      # mixed: stripes of length p3 along x cycling flat -> gapped -> blocks
+        stripe = np.mod(np.floor(x / p[3]), 3.0)
+        gap = _terrain_height(1, (1.0, p[1], p[2], 0.0), x, y)
+        blk = _terrain_height(2, (p[0], 0.35, 0.0, 0.0), x, y)
+        return np.where(stripe == 1, gap, np.where(stripe == 2, blk, 0.0))
+    return np.zeros(np.broadcast(x, y).shape)
+
+
+class GappedTerrainWorld(_TerrainWorld):
+    """Blocks ``block_width`` mm wide separated by gaps ``gap_width`` mm wide and ``gap_depth`` mm deep, across x."""
+
+    def __init__(self, name: str = "gapped_terrain_world", *, block_width: float = 1.0, gap_width: float = 0.3,
+                 gap_depth: float = 2.0, half_size: float = 1000) -> None:
+        super().__init__(name, half_size=half_size)
+        self.terrain_type, self.terrain_params = 1, (float(block_width), float(gap_width), float(gap_depth), 0.0)
+
+
+class BlocksTerrainWorld(_TerrainWorld):
+    """Checkerboard of ``block_size`` mm squares, alternate squares raised by ``height`` mm."""
+
+    def __init__(self, name: str = "blocks_terrain_world", *, block_size: float = 1.3, height: float = 0.35,
+                 half_size: float = 1000) -> None:
+        super().__init__(name, half_size=half_size)
+        self.terrain_type, self.terrain_params = 2, (float(block_size), float(height), 0.0, 0.0)
+
+
+class MixedTerrainWorld(_TerrainWorld):
+    """Stripes ``stripe_length`` mm long along x cycling flat, gapped (1.0 / gap_width / gap_depth) and blocks
+    (block_size, 0.35 mm)."""
+
+    def __init__(self, name: str = "mixed_terrain_world", *, block_size: float = 1.3, gap_width: float = 0.3,
+                 gap_depth: float = 2.0, stripe_length: float = 4.0, half_size: float = 1000) -> None:
+        super().__init__(name, half_size=half_size)
+        self.terrain_type = 3
+        self.terrain_params = (float(block_size), float(gap_width), float(gap_depth), float(stripe_length))
 
 
 class TetheredWorld(BaseWorld):

@@ -199,6 +199,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   d.hull_skin = scalar("hull_skin", 0); d.meaninertia = scalar("stat_meaninertia", 0);
   for (int k = 0; k < 3; ++k) d.gravity[k] = scalar("opt_gravity", k);
   for (int k = 0; k < 4; ++k) d.plane[k] = scalar("plane", k);
+  for (int k = 0; k < 5; ++k) d.terrain[k] = scalar("terrain_params", k);
+  { const HostArray* tt = model->find("terrain_type"); d.terrain_type = tt && tt->is_int && !tt->i.empty() ? tt->i[0] : 0; }
   int rc = 0;
 #define UF(n) rc |= upload_f(b, #n, &d.n)
 #define UI(n) rc |= upload_i(b, #n, &d.n)

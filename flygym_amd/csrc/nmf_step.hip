@@ -239,6 +239,22 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
 }
 
 // ------------------------------------------------------------------ collision (geom vs ground plane)
+// piecewise-constant ground height under (x, y): build-defined terrains (oracle: terrain_height)
+__device__ __forceinline__ float terrain_kind(int kind, float p0, float p1, float p2, float x, float y) {
+  if (kind == 1) { const float period = p0 + p1; const float u = x - floorf(x / period) * period; return u < p0 ? 0.f : -p2; }
+  if (kind == 2) { const float i = floorf(x / p0), j = floorf(y / p0); const float sum = i + j;
+                   const float par = sum - 2.f * floorf(sum / 2.f); return par != 0.f ? p1 : 0.f; }
+  return 0.f;
+}
+__device__ __forceinline__ float terrain_height(const DevModel& m, float x, float y) {
+  const float* p = m.terrain;
+  if (m.terrain_type == 3) {
+    const float st = floorf(x / p[3]); const float k = st - 3.f * floorf(st / 3.f);
+    return k == 1.f ? terrain_kind(1, 1.0f, p[1], p[2], x, y) : (k == 2.f ? terrain_kind(2, p[0], 0.35f, 0.f, x, y) : 0.f);
+  }
+  return terrain_kind(m.terrain_type, p[0], p[1], p[2], x, y);
+}
+
 // Scratch of the collision stage, overlaid on the T..W region (free between steps)
 struct CollisionScratch {
   float r[kMaxCon][3], dist[kMaxCon];
@@ -270,11 +286,12 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     const V3 xp = ld3(s.xpos[g_body]);
     V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * lane]));
     float dc = dot(n, cw) + dot(n, xp) - pd;
-    near = dc - m.geom_bsphere[4 * lane + 3] <= g_margin;
+    near = dc - m.geom_bsphere[4 * lane + 3] - m.terrain[4] <= g_margin;
     if (near && g_type == GEOM_CAPSULE) {
       const float rad = m.geom_radius[lane];
       const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * lane])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * lane])) + xp;
-      const float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
+      float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
+      if (m.terrain_type) { d0 -= terrain_height(m, p0.x, p0.y); d1 -= terrain_height(m, p1.x, p1.y); }
       const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
       if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
       if (d1 <= g_margin) { if (cnt) { cd1 = d1; cp1 = q1; } else { cd0 = d1; cp0 = q1; } cnt++; }
@@ -295,9 +312,16 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     const V3 xp = ld3(s.xpos[b]);
     const V3 nb = matT_vec(R, n);
     const float c0 = dot(n, xp) - pd;
+    const bool rough = m.terrain_type != 0;
+    // distance of a hull vertex to the ground under it (flat ground: the plane distance)
+    auto vdist = [&](V3 v) {
+      float di = dot(nb, v) + c0;
+      if (rough) { const V3 pw = mat_vec(R, v) + xp; di -= terrain_height(m, pw.x, pw.y); }
+      return di;
+    };
     float best = INFINITY; int bi = 0x7fffffff;
     for (int i = lane; i < nvv; i += kWave) {
-      float di = dot(nb, ld3(V + 3 * i)) + c0;
+      float di = vdist(ld3(V + 3 * i));
       if (di < best) { best = di; bi = i; }
     }
     wave_argmin(best, bi);
@@ -310,7 +334,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     best = -INFINITY; bi = 0x7fffffff;
     for (int i = lane; i < nvv; i += kWave) {
       V3 vi = ld3(V + 3 * i);
-      float di = dot(nb, vi) + c0;
+      float di = vdist(vi);
       if (di > thr) continue;
       V3 e = vi - va; float sc = dot(e, e);
       if (sc > best) { best = sc; bi = i; }
@@ -323,7 +347,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
       best = -INFINITY; bi = 0x7fffffff;
       for (int i = lane; i < nvv; i += kWave) {
         V3 vi = ld3(V + 3 * i);
-        float di = dot(nb, vi) + c0;
+        float di = vdist(vi);
         if (di > thr) continue;
         V3 cr = cross(vi - va, ab); float sc = dot(cr, cr);
         if (sc > best) { best = sc; bi = i; }
@@ -336,7 +360,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
         best = -INFINITY; bi = 0x7fffffff;
         for (int i = lane; i < nvv; i += kWave) {
           V3 vi = ld3(V + 3 * i);
-          float di = dot(nb, vi) + c0;
+          float di = vdist(vi);
           if (di > thr) continue;
           float sc = sg * dot(cross(vi - va, ab), nb);
           if (sc > best) { best = sc; bi = i; }
@@ -348,7 +372,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
-      const float dist = dot(nb, v) + c0;
+      const float dist = vdist(v);
       const V3 pw = mat_vec(R, v) + xp;
       X.info[nh + lane] = g | (lane << 8) | (b << 12);
       X.dist[nh + lane] = dist;

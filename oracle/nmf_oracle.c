@@ -116,7 +116,8 @@ static int* blob_int(const uint8_t* blob, const char* name, int64_t* count) {
 /* ------------------------------------------------------------------ model */
 typedef struct {
   int nb, nv, nq, nu, ng, nseg, nsite, nhv, nsensor;
-  real timestep, gravity[3], tolerance, hull_skin, plane[4], meaninertia;
+  real timestep, gravity[3], tolerance, hull_skin, plane[4], meaninertia, terrain[5];
+  int terrain_type;
   int max_iter;
   int *body_parent, *body_dofadr, *body_dofnum;
   real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
@@ -224,6 +225,8 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   t = blob_real(blob, "opt_tolerance", NULL); m->tolerance = t[0]; free(t);
   t = blob_real(blob, "hull_skin", NULL); m->hull_skin = t[0]; free(t);
   t = blob_real(blob, "plane", NULL); memcpy(m->plane, t, 4 * sizeof(real)); free(t);
+  t = blob_real(blob, "terrain_params", NULL); memcpy(m->terrain, t, 5 * sizeof(real)); free(t);
+  { int* tt = blob_int(blob, "terrain_type", NULL); m->terrain_type = tt[0]; free(tt); }
   t = blob_real(blob, "stat_meaninertia", NULL); m->meaninertia = t[0]; free(t);
   int* it = blob_int(blob, "opt_solver", NULL); m->max_iter = it[0]; free(it);
   it = blob_int(blob, "n_sensor", NULL); m->nsensor = it[0]; free(it);
@@ -479,6 +482,33 @@ static void add_contact(const omodel* m, odata* d, int g, real dist, const real*
   d->con_mu[c] = m->pair_friction[5 * g];
 }
 
+/* piecewise-constant ground height under (x, y): build-defined terrains (flygym_amd/compose/world.py) */
+#ifdef NMF_REAL_IS_FLOAT
+#define R_FLOOR floorf
+#else
+#define R_FLOOR floor
+#endif
+static real terrain_kind(int kind, const real* p, real x, real y) {
+  if (kind == 1) { real period = p[0] + p[1]; real u = x - R_FLOOR(x / period) * period; return u < p[0] ? (real)0 : -p[2]; }
+  if (kind == 2) { real i = R_FLOOR(x / p[0]), j = R_FLOOR(y / p[0]); real sum = i + j; real par = sum - 2 * R_FLOOR(sum / 2);
+                   return par != 0 ? p[1] : (real)0; }
+  return 0;
+}
+static real terrain_height(const omodel* m, real x, real y) {
+  const real* p = m->terrain;
+  if (m->terrain_type == 3) {
+    real st = R_FLOOR(x / p[3]); real k = st - 3 * R_FLOOR(st / 3);
+    real gp[3] = {(real)1.0, p[1], p[2]}, bp[2] = {p[0], (real)0.35};
+    return k == 1 ? terrain_kind(1, gp, x, y) : (k == 2 ? terrain_kind(2, bp, x, y) : (real)0);
+  }
+  return terrain_kind(m->terrain_type, p, x, y);
+}
+
+static real vheight(const omodel* m, const real* R, const real* xp, const real* v) {
+  real pw[3]; mat_vec(pw, R, v);
+  return terrain_height(m, pw[0] + xp[0], pw[1] + xp[1]);
+}
+
 static void collide(const omodel* m, odata* d) {
   d->ncon = 0; d->overflow = 0;
   const real* n = m->plane; real pd = m->plane[3];
@@ -489,14 +519,14 @@ static void collide(const omodel* m, odata* d) {
     /* bounding sphere cull */
     real cw[3]; mat_vec(cw, R, m->geom_bsphere + 4 * g);
     real dc = dot3(n, cw) + dot3(n, xp) - pd;
-    if (dc - m->geom_bsphere[4 * g + 3] > margin) continue;
+    if (dc - m->geom_bsphere[4 * g + 3] - m->terrain[4] > margin) continue;
     if (m->geom_type[g] == GEOM_CAPSULE) {
       for (int e = 0; e < 2; e++) {
         const real* pl = (e == 0 ? m->geom_p0 : m->geom_p1) + 3 * g;
         real pw[3]; mat_vec(pw, R, pl);
         for (int k = 0; k < 3; k++) pw[k] += xp[k];
         real r = m->geom_radius[g];
-        real dist = dot3(n, pw) - pd - r;
+        real dist = dot3(n, pw) - pd - r - terrain_height(m, pw[0], pw[1]);
         if (dist > margin) continue;
         real ps[3] = {pw[0] - n[0] * r, pw[1] - n[1] * r, pw[2] - n[2] * r};
         add_contact(m, d, g, dist, ps, n);
@@ -506,9 +536,11 @@ static void collide(const omodel* m, odata* d) {
       real c0 = dot3(n, xp) - pd;
       const real* V = m->hull_vert + 3 * m->geom_hulladr[g];
       int nvv = m->geom_hullnum[g];
+      /* vertex distance to the ground under it (flat ground: the plane distance) */
+#define VDIST(i) (dot3(nb, V + 3 * (i)) + c0 - (m->terrain_type ? vheight(m, R, xp, V + 3 * (i)) : (real)0))
       int ia = -1; real dmin = 0;
       for (int i = 0; i < nvv; i++) {
-        real di = dot3(nb, V + 3 * i) + c0;
+        real di = VDIST(i);
         if (ia < 0 || di < dmin) { ia = i; dmin = di; }
       }
       if (ia < 0 || dmin > margin) continue;
@@ -518,7 +550,7 @@ static void collide(const omodel* m, odata* d) {
       /* b: farthest candidate from a */
       int ib = -1; real best = (real)1e-10;
       for (int i = 0; i < nvv; i++) {
-        real di = dot3(nb, V + 3 * i) + c0; if (di > thr) continue;
+        real di = VDIST(i); if (di > thr) continue;
         real e[3] = {V[3 * i] - va[0], V[3 * i + 1] - va[1], V[3 * i + 2] - va[2]};
         real s = dot3(e, e); if (s > best) { best = s; ib = i; }
       }
@@ -530,7 +562,7 @@ static void collide(const omodel* m, odata* d) {
         /* c: farthest from line ab */
         int ic = -1; best = (real)1e-10 * lab2; real side_c = 0;
         for (int i = 0; i < nvv; i++) {
-          real di = dot3(nb, V + 3 * i) + c0; if (di > thr) continue;
+          real di = VDIST(i); if (di > thr) continue;
           real e[3] = {V[3 * i] - va[0], V[3 * i + 1] - va[1], V[3 * i + 2] - va[2]};
           real cr[3]; cross3(cr, e, ab);
           real s = dot3(cr, cr); if (s > best) { best = s; ic = i; side_c = dot3(cr, nb); }
@@ -541,7 +573,7 @@ static void collide(const omodel* m, odata* d) {
           int id = -1; real sg = side_c > 0 ? (real)-1 : (real)1;
           best = R_SQRT((real)1e-10 * lab2);
           for (int i = 0; i < nvv; i++) {
-            real di = dot3(nb, V + 3 * i) + c0; if (di > thr) continue;
+            real di = VDIST(i); if (di > thr) continue;
             real e[3] = {V[3 * i] - va[0], V[3 * i + 1] - va[1], V[3 * i + 2] - va[2]};
             real cr[3]; cross3(cr, e, ab);
             real s = sg * dot3(cr, nb); if (s > best) { best = s; id = i; }
@@ -551,11 +583,12 @@ static void collide(const omodel* m, odata* d) {
       }
       for (int k = 0; k < nsel; k++) {
         const real* v = V + 3 * sel[k];
-        real dist = dot3(nb, v) + c0;
+        real dist = VDIST(sel[k]);
         real pw[3]; mat_vec(pw, R, v);
         for (int q = 0; q < 3; q++) pw[q] += xp[q];
         add_contact(m, d, g, dist, pw, n);
       }
+#undef VDIST
     }
   }
 }

@@ -259,3 +259,47 @@ def test_tethered_world_is_refused_loudly(torch_mod):
     world.add_fly(fly, (0, 0, 1.5), Rotation3D("quat", (1, 0, 0, 0)))
     with pytest.raises(NotImplementedError):
         HIPSimulation(world, n_worlds=2, device=0)
+
+
+@pytest.mark.parametrize("world_cls", ["GappedTerrainWorld", "BlocksTerrainWorld", "MixedTerrainWorld"])
+def test_terrain_worlds_parity(torch_mod, oracle_lib, world_cls):
+    """BASELINE config 4/5 terrains (build-defined height maps): CPG walking across them, HIP vs float64 oracle."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = C.Fly(name="t")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    fly.add_actuators(sk.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    world = getattr(C, world_cls)()
+    world.add_fly(fly, (0.3, 0.2, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    sim = HIPSimulation(world, n_worlds=4, device=0)
+    o = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+    o32 = oracle_lib.Oracle(sim.model.to_blob(), "f32")
+    order = fly.get_actuated_jointdofs_order(C.ActuatorType.POSITION)
+    table = TripodCPG(order, 1e-4).targets(1, 2500)
+    tdev = torch.as_tensor(np.repeat(table, 4, axis=0), device=sim.device)
+    ids = sim._ids_by_fly[fly.name]["actuators"][C.ActuatorType.POSITION]
+    sim.set_leg_adhesion_states(fly.name, np.ones((4, 6), dtype=np.float32))
+    for orc in (o, o32):
+        orc.ctrl[42:] = 1.0
+        orc.step(400)
+    sim.step(400)
+    # A height map is discontinuous: when a vertex sits on a block edge, float32 and float64 may pick different
+    # sides and the trajectories separate from there.  The engine must follow one of the two oracles closely
+    # (it computes in float32, so usually the float32 one) and stay near the float64 one.
+    for k in range(3):
+        sim.step_replay(tdev, ids, 100 * k, 100)
+        for orc in (o, o32):
+            orc.step_replay(table[0], np.arange(42), 100 * k, 100)
+        q = sim.field("qpos").cpu().numpy()
+        e64, e32 = np.abs(q - o.qpos[None]).max(), np.abs(q - o32.qpos[None]).max()
+        assert min(e64, e32) < 5e-5, f"{world_cls} after {400 + 100 * (k + 1)} steps: {e64:.2e} / {e32:.2e}"
+        assert e64 < 2e-2
+    assert int(sim.field("stats")[0, 0].item()) in (o.ints()["ncon"], o32.ints()["ncon"])
+    assert np.isfinite(q).all()
