@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--workload", choices=["cpg", "replay"], default="cpg",
                     help="cpg: BASELINE config 2 (position-actuated tripod CPG); replay: the reference benchmark's "
                          "kinematic replay of the Spotlight clip (world w <- partition w %% 20)")
+    ap.add_argument("--terrain", choices=["flat", "gapped", "blocks", "mixed"], default="flat",
+                    help="flat = BASELINE config 2; gapped/blocks = config 4; mixed = config 5 (build-defined height maps)")
+    ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200000)
@@ -110,7 +113,20 @@ def main():
     n_launches = args.steps // spl
 
     fly, world, _ = make_model(simplify_geom=args.simplify_geom)
+    if args.terrain != "flat":
+        import flygym_amd.compose as C
+        from flygym_amd.utils.math import Rotation3D
+
+        world = {"gapped": C.GappedTerrainWorld, "blocks": C.BlocksTerrainWorld, "mixed": C.MixedTerrainWorld}[args.terrain]()
+        world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n_local, device=local_rank)
+    odor = None
+    if args.odor:
+        from flygym_amd.sensors import OdorSensors
+
+        rng = np.random.default_rng(0)     # S = 3 sources, D = 2 dims, seeded within +-20 mm
+        src = rng.uniform(-20, 20, (3, 3)); src[:, 2] = rng.uniform(0.5, 3.0, 3)
+        odor = OdorSensors(sim, fly.name, src, rng.uniform(0.1, 1.0, (3, 2)))
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
     replay = ReplayTargetData(sim.timestep, order)
     if args.workload == "replay":
@@ -141,6 +157,8 @@ def main():
         ev0[k].record()
         sim.step_replay(table, act_ids, start, spl)
         ev1[k].record()
+        if odor is not None:
+            odor.get_odor_intensities()
         if use_dist:
             obs_local[:, 0:66] = sim.field("qpos")[:, 7:]
             obs_local[:, 66:132] = sim.field("qvel")[:, 6:]
@@ -183,7 +201,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "4096 flies/GPU, flat ground, LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
+                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + ", LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else
