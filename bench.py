@@ -195,6 +195,15 @@ def main():
         total_worlds = n_local * world_size
         value = total_worlds * args.steps / elapsed
         achieved = BYTES_PER_ENV_STEP * n_local * spl / (ms * 1e-3) / 1e9
+        # HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
+        # --pmc passes of this very command (profiles/hbm_traffic.json, written by scripts/summarize_profile.py)
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            rec = json.loads(tfile.read_text())
+            if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch"), rec.get("control")) == (n_local, spl, args.workload) \
+                    and args.terrain == "flat" and not args.odor:
+                traffic = rec["traffic_bytes_per_launch"]
         out = {
             "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
@@ -216,7 +225,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>>", "kernel_ms_per_launch": ms,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 "note": "the step is VALU/LDS-latency bound by construction (state crosses HBM once per launch); "

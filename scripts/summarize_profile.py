@@ -95,5 +95,11 @@ if sq:
     out.append("")
 (dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
 (dst / f"{tag}_bench.json").write_text(json.dumps(b, indent=1) + "\n")
+if traffic is not None:
+    (dst / "hbm_traffic.json").write_text(json.dumps({
+        "profile": tag, "traffic_bytes_per_launch": traffic, "worlds_per_gpu": b["config"]["worlds_per_gpu"],
+        "steps_per_launch": b["config"]["steps_per_launch"], "control": b["config"].get("control"),
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, FETCH_SIZE x2 (gfx950), "
+                  "mean over the timed-region launches"}, indent=1) + "\n")
 print("\n".join(out))
 print("traffic bytes per launch:", traffic)
