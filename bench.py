@@ -136,9 +136,12 @@ def main():
         from flygym_amd.controllers import TripodCPG
 
         table_steps = 2500  # three 12 Hz gait cycles: the table wraps around seamlessly
-        table_np = TripodCPG(order, sim.timestep).targets(n_local, table_steps, first_world=rank * n_local,
-                                                          total_worlds=n_local * world_size)
-    table = torch.as_tensor(table_np, device=sim.device)
+        cpg = TripodCPG(order, sim.timestep)
+        table_np = None
+        table = cpg.targets(n_local, table_steps, device=sim.device, first_world=rank * n_local,
+                            total_worlds=n_local * world_size)       # built on the GPU: no multi-GB host arrays
+    if table_np is not None:
+        table = torch.as_tensor(table_np, device=sim.device)
     act_ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
     maps = sim._ids_by_fly[fly.name]
 
@@ -233,7 +236,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), np.ascontiguousarray(table_np[0]),
+            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), np.ascontiguousarray(table[0].cpu().numpy()),
                                                np.arange(42, dtype=np.int32), args.warmup, args.cpu_steps)
     if use_dist:
         dist.barrier()

@@ -73,16 +73,32 @@ class TripodCPG:
 
     def targets(self, n_worlds: int, steps: int, start_step: int = 0, device=None, first_world: int = 0,
                 total_worlds: int | None = None):
-        """Target table ``(n_worlds, steps, n_act)`` float32 (torch tensor on ``device`` if given, else numpy)."""
-        ph = self.phases(n_worlds, steps, start_step, first_world, total_worlds)[..., self.leg_of_dof]   # (W, S, 42)
-        x = ph / (2 * np.pi) * self.n_bins
-        i0 = np.floor(x).astype(np.int64) % self.n_bins
-        frac = (x - np.floor(x)).astype(np.float32)
-        cols = np.arange(len(self.actuated_dofs))[None, None, :]
-        table = (1 - frac) * self.cycle[i0, cols] + frac * self.cycle[(i0 + 1) % self.n_bins, cols]
-        table = np.ascontiguousarray(table.astype(np.float32))
+        """Target table ``(n_worlds, steps, n_act)`` float32: a torch tensor built on ``device`` if given (no large
+        host arrays), else numpy."""
+        n_act = len(self.actuated_dofs)
+        bias = np.array([TRIPOD_PHASE_BIAS[leg] for leg in LEGS])[self.leg_of_dof]                 # (n_act,)
         if device is None:
-            return table
+            ph = self.phases(n_worlds, steps, start_step, first_world, total_worlds)[..., self.leg_of_dof]
+            x = ph / (2 * np.pi) * self.n_bins
+            i0 = np.floor(x).astype(np.int64) % self.n_bins
+            frac = (x - np.floor(x)).astype(np.float32)
+            cols = np.arange(n_act)[None, None, :]
+            table = (1 - frac) * self.cycle[i0, cols] + frac * self.cycle[(i0 + 1) % self.n_bins, cols]
+            return np.ascontiguousarray(table.astype(np.float32))
         import torch
 
-        return torch.as_tensor(table, device=device)
+        # phase in cycles, float64 on the device for the same rounding as the numpy path, world chunks bound memory
+        cyc = torch.as_tensor(self.cycle, device=device)                                            # (bins, n_act)
+        t = (start_step + torch.arange(steps, device=device, dtype=torch.float64)) * self.timestep * self.frequency
+        b = torch.as_tensor(bias / (2 * np.pi), device=device, dtype=torch.float64)
+        out = torch.empty((n_worlds, steps, n_act), dtype=torch.float32, device=device)
+        cols = torch.arange(n_act, device=device)[None, None, :]
+        chunk = max(1, (1 << 24) // max(1, steps * n_act))
+        for w0 in range(0, n_worlds, chunk):
+            w = torch.arange(w0, min(n_worlds, w0 + chunk), device=device, dtype=torch.float64)
+            world = (first_world + w) / float(total_worlds or n_worlds)
+            x = torch.remainder(t[None, :, None] + world[:, None, None] + b[None, None, :], 1.0) * self.n_bins
+            i0 = torch.floor(x).to(torch.int64) % self.n_bins
+            frac = (x - torch.floor(x)).to(torch.float32)
+            out[w0:w0 + len(w)] = (1 - frac) * cyc[i0, cols] + frac * cyc[(i0 + 1) % self.n_bins, cols]
+        return out
