@@ -303,3 +303,39 @@ def test_terrain_worlds_parity(torch_mod, oracle_lib, world_cls):
         assert e64 < 2e-2
     assert int(sim.field("stats")[0, 0].item()) in (o.ints()["ncon"], o32.ints()["ncon"])
     assert np.isfinite(q).all()
+
+
+def test_single_world_and_launch_splitting(torch_mod, bench_model, oracle_lib):
+    """Edge cases: n_worlds = 1; a fly dropped low with all leg targets at zero (body hulls touch the ground);
+    the same steps split into different launch sizes are bitwise identical."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.compose import ActuatorType
+
+    fly, world, _ = bench_model
+    a = HIPSimulation(world, n_worlds=1, device=0)
+    b = HIPSimulation(world, n_worlds=1, device=0)
+    o = oracle_lib.Oracle(a.model.to_blob(), "f32")
+    o64 = oracle_lib.Oracle(a.model.to_blob(), "f64")
+    zeros = np.zeros((1, 42), dtype=np.float32)
+    for sim in (a, b):
+        sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, zeros)      # fold the legs
+        sim.field("qpos")[:, 2] = 0.3
+    for orc in (o, o64):
+        orc.ctrl[:42] = 0.0
+        orc.qpos[2] = 0.3
+    a.step(600); o.step(600); o64.step(600)
+    for _ in range(10):
+        b.step(60)
+    torch.cuda.synchronize()
+    a.step(60); o.step(60); o64.step(60)
+    b.step(0 + 60)
+    # launch splitting: 600 + 60 in (1 + 1) launches vs (10 + 1) launches of 60
+    assert torch.equal(a.field("qpos"), b.field("qpos")) and torch.equal(a.field("qvel"), b.field("qvel"))
+    stats = a.field("stats").cpu().numpy()[0]
+    ncon = int(stats[0])
+    assert ncon >= 1 and stats[2] == 0
+    assert ncon in (o.ints()["ncon"], o64.ints()["ncon"])
+    q = a.field("qpos").cpu().numpy()[0]
+    assert min(np.abs(q - o.qpos).max(), np.abs(q - o64.qpos).max()) < 2e-3   # contact-rich, 660 steps
+    assert np.isfinite(q).all()
