@@ -465,6 +465,13 @@ def compile_world(world) -> CompiledModel:
     m["seg_invweight0"] = seg_invw
     m["geom_invweight0"] = seg_invw[contact_segs, 0].reshape(ng) if ng else np.zeros(0)
 
+    # tether weld (TetheredWorld): six bilateral rows holding the root body at its spawn pose.  The reference welds
+    # the thorax with solref (2e-4, 1), solimp (0.98, 0.99, 1e-5, 0.5, 3) (world.py:358-365); the regulariser uses
+    # the thorax body's invweight0 (translational, rotational).
+    root_seg = seg_index[fly.root_segment.name]
+    m["weld_active"] = np.array([1 if world.fixed_base else 0], dtype=np.int32)
+    m["weld_params"] = np.concatenate([qpos[0:3], qpos[3:7], [2e-4, 1.0], _solimp5((0.98, 0.99, 1e-5, 0.5, 3.0)),
+                                       seg_invw[root_seg]])
     # structure summary for the star-of-chains fast path
     m["star"] = _star_structure(m)
     m.meta = {

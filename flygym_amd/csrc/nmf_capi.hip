@@ -200,6 +200,12 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   for (int k = 0; k < 3; ++k) d.gravity[k] = scalar("opt_gravity", k);
   for (int k = 0; k < 4; ++k) d.plane[k] = scalar("plane", k);
   for (int k = 0; k < 5; ++k) d.terrain[k] = scalar("terrain_params", k);
+  { const HostArray* wa = model->find("weld_active"); d.weld_active = wa && wa->is_int && !wa->i.empty() ? wa->i[0] : 0;
+    for (int k = 0; k < 3; ++k) d.weld_pos[k] = scalar("weld_params", k);
+    for (int k = 0; k < 4; ++k) d.weld_quat[k] = scalar("weld_params", 3 + k);
+    for (int k = 0; k < 2; ++k) d.weld_solref[k] = scalar("weld_params", 7 + k);
+    for (int k = 0; k < 5; ++k) d.weld_solimp[k] = scalar("weld_params", 9 + k);
+    for (int k = 0; k < 2; ++k) d.weld_invweight[k] = scalar("weld_params", 14 + k); }
   { const HostArray* tt = model->find("terrain_type"); d.terrain_type = tt && tt->is_int && !tt->i.empty() ? tt->i[0] : 0; }
   int rc = 0;
 #define UF(n) rc |= upload_f(b, #n, &d.n)

@@ -55,6 +55,8 @@ struct DevModel {
   float timestep, tolerance, hull_skin, meaninertia;
   float gravity[3];
   float plane[4];
+  int weld_active;          // tether: soft weld of the root body to weld_pos / weld_quat (TetheredWorld)
+  float weld_pos[3], weld_quat[4], weld_solref[2], weld_solimp[5], weld_invweight[2];
   int terrain_type;         // 0 flat, 1 gapped, 2 blocks, 3 mixed
   float terrain[5];         // parameters + maximum height (see flygym_amd/compose/world.py)
   const float *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;

@@ -63,6 +63,7 @@ struct __align__(16) FlyLds {
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];   // c_D holds the distance until setup
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
+  float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
   int body_cstart[TP::NB + 1];
   int ncon, overflow, iters;
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
@@ -578,7 +579,11 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     float row[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
-    if (withK) for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+    if (withK) {
+      for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+      // tether weld: its six rows are the components of the root twist -> a diagonal term per row
+      static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
+    }
     pA = 0.f;
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
@@ -657,9 +662,13 @@ __device__ __forceinline__ void rows_of_twist(const ContactRegs& c, const Frame&
   out[0] = jn + j1; out[1] = jn - j1; out[2] = jn + j2; out[3] = jn - j2;
 }
 
+// One row of the tether weld (TetheredWorld): lanes 48..53 own the six bilateral rows, which are the components
+// (w; v) of the root twist, so J x is a component of T[0] and JT f a component of the root wrench.
+struct WeldRow { bool on; int comp; float D, aref, jar, jv; };
+
 template <class TP>
-__device__ float constraint_cost(const ContactRegs& c) {
-  float v = 0.f;
+__device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
+  float v = wr.on ? 0.5f * wr.D * wr.jar * wr.jar : 0.f;
   if (c.on) {
 #pragma unroll
     for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) v += 0.5f * c.D * c.jar[k] * c.jar[k];
@@ -671,8 +680,9 @@ __device__ float constraint_cost(const ContactRegs& c) {
 // publishes its world wrench (about the root origin) in c_w, then the leg groups suffix-sum the
 // wrenches of their bodies' contacts (contacts are sorted by body) and the dofs project.
 template <class TP, class Emit>
-__device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const Frame& fr, float sign,
-                                                const DevModel& m, int lane, Emit&& emit) {
+__device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const WeldRow& wr, const Frame& fr,
+                                                float sign, const DevModel& m, int lane, Emit&& emit) {
+  if (wr.on) s.weld_w[wr.comp] = sign * (-wr.D * wr.jar);
   if (c.on) {
     float f[4]; int act = 0;
 #pragma unroll
@@ -697,7 +707,7 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
   });
   WSYNC();
   if (lane < 6) {
-    float a0 = 0.f;
+    float a0 = s.weld_w[lane];
     for (int cc = s.body_cstart[0]; cc < s.body_cstart[1]; ++cc) a0 += s.c_w[cc][lane];
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[1 + k * TP::NBL][lane];
@@ -749,6 +759,31 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_info[lane] = c.info;
   }
 
+  // ---- tether weld rows (lanes 48..53); without a tether their stiffness and wrench are zero
+  WeldRow wr;
+  wr.comp = lane - 48;
+  wr.on = m.weld_active != 0 && wr.comp >= 0 && wr.comp < 6;
+  wr.D = 0.f; wr.aref = 0.f; wr.jar = 0.f; wr.jv = 0.f;
+  float weld_res = 0.f, weld_KI = 0.f, weld_B = 0.f;
+  if (wr.comp >= 0 && wr.comp < 6) {
+    if (wr.on) {
+      const Q4 qe = qmul(qnorm(ldq(&s.qpos[3])), Q4{m.weld_quat[0], -m.weld_quat[1], -m.weld_quat[2], -m.weld_quat[3]});
+      const float sg = qe.w < 0.f ? -2.f : 2.f;
+      const float res6[6] = {sg * qe.x, sg * qe.y, sg * qe.z, s.qpos[0] - m.weld_pos[0], s.qpos[1] - m.weld_pos[1], s.qpos[2] - m.weld_pos[2]};
+#pragma unroll
+      for (int i = 0; i < 6; i++) weld_res = wr.comp == i ? res6[i] : weld_res;
+      const float imp = impedance(m.weld_solimp, weld_res);
+      const float dA = m.weld_invweight[wr.comp < 3 ? 1 : 0];
+      wr.D = 1.0f / fmaxf((1.f - imp) * dA / imp, kMinVal);
+      float tc = m.weld_solref[0], dr = m.weld_solref[1], K;
+      const float dmax = m.weld_solimp[1];
+      if (tc > 0.f) { tc = fmaxf(tc, 2.f * m.timestep); K = 1.0f / (dmax * dmax * tc * tc * dr * dr); weld_B = 2.0f / (dmax * tc); }
+      else { K = -tc / (dmax * dmax); weld_B = -dr / dmax; }
+      weld_KI = K * imp;
+    }
+    s.weldD[wr.comp] = wr.D;
+    s.weld_w[wr.comp] = 0.f;
+  }
   STAGE(4);
   // ---- velocities and bias accelerations: three passes over the chains
   {
@@ -778,6 +813,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
 #pragma unroll
       for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
     }
+    if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
     for (int j = 3 + lane; j < TP::NV; j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
     WSYNC();
@@ -840,7 +876,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
-  if (ncon == 0) {
+  if (ncon == 0 && !m.weld_active) {
     for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
@@ -854,16 +890,20 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
-    float cost = wave_sum(g) + constraint_cost<TP>(c);
+    if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
+    float cost = wave_sum(g) + constraint_cost<TP>(c, wr);
     // candidate 2: unconstrained acceleration
     sweep_twists(s, s.qacc_smooth, s.T, m, lane);
     ContactRegs c2 = c;
     if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c2.jar);
 #pragma unroll
       for (int k = 0; k < 4; k++) c2.jar[k] -= c.aref[k]; }
-    float cost_sm = constraint_cost<TP>(c2);
+    WeldRow wr2 = wr;
+    if (wr.on) wr2.jar = s.T[0][wr.comp] - wr.aref;
+    float cost_sm = constraint_cost<TP>(c2, wr2);
     if (cost_sm < cost) {
       cost = cost_sm;
+      wr.jar = wr2.jar;
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] = c2.jar[k];
       for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Ma[j] = s.qfrc_smooth[j]; }
@@ -874,7 +914,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     for (int iter = 0; iter < m.max_iter; ++iter) {
       // gradient = Ma − qfrc_smooth − Jᵀ f
       float gn = 0.f, gm = 0.f;
-      contact_project(s, c, fr, -1.0f, m, lane, [&](int j, float jtf) {
+      contact_project(s, c, wr, fr, -1.0f, m, lane, [&](int j, float jtf) {
         float gj = jtf + Ma[j] - s.qfrc_smooth[j];
         float mag = fabsf(Ma[j]) + fabsf(s.qfrc_smooth[j]) + fabsf(jtf);
         grad[j] = -gj;   // store the right-hand side of the Newton system
@@ -888,6 +928,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       contact_reload(c, s, lane);
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
+      if (wr.on) wr.jv = s.T[0][wr.comp];
       float g1 = 0.f, g2 = 0.f;
       mul_M(s, search, m, lane, true, [&](int j, float v) {
         Mv[j] = v;
@@ -906,6 +947,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
             if (x < 0.f) { d1 += c.D * x * c.jv[k]; d2 += c.D * c.jv[k] * c.jv[k]; }
           }
         }
+        if (wr.on) { const float x = wr.jar + alpha * wr.jv; d1 += wr.D * x * wr.jv; d2 += wr.D * wr.jv * wr.jv; }
         d1 = wave_sum(d1) + g1 + alpha * g2;
         d2 = wave_sum(d2) + g2;
         if (d2 <= 0.f || d1 == 0.f) break;
@@ -931,10 +973,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) c.jar[k] += alpha * c.jv[k];
       }
+      if (wr.on) wr.jar += alpha * wr.jv;
       WSYNC();
       float gq = 0.f;
       for (int j = lane; j < TP::NV; j += kWave) gq += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
-      float newcost = wave_sum(gq) + constraint_cost<TP>(c);
+      float newcost = wave_sum(gq) + constraint_cost<TP>(c, wr);
       iters = iter + 1;
       STAGE(13);
       float improvement = cost - newcost;
@@ -943,7 +986,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     STAGE(9);
     // constraint forces
-    contact_project(s, c, fr, 1.0f, m, lane, [&](int j, float v) { s.vD[j] = v; });   // qfrc_constraint lives in vD until the Euler step
+    contact_project(s, c, wr, fr, 1.0f, m, lane, [&](int j, float v) { s.vD[j] = v; });   // qfrc_constraint lives in vD until the Euler step
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);

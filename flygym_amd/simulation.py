@@ -42,10 +42,6 @@ class HIPSimulation:
 
         if len(world.fly_lookup) == 0:
             raise ValueError("The world must contain at least one fly.")
-        if getattr(world, "fixed_base", False):
-            raise NotImplementedError(
-                "TetheredWorld (fixed base) is not built into the MI355X engine yet; use FlatGroundWorld"
-            )
         self._strip_unsupported_options(world)
         self.world = world
         self.n_worlds = int(n_worlds)

@@ -63,6 +63,7 @@ typedef float real;
 #define NMF_NOISE_FACTOR 8
 #endif
 #define NMF_MINVAL 1e-15
+#define NMF_MAXEFC (4 * NMF_MAXCON + 6)   /* contact rows + the 6 rows of the tether weld */
 #define GEOM_CAPSULE 0
 #define GEOM_HULL 1
 #define ACT_POSITION 0
@@ -118,6 +119,8 @@ typedef struct {
   int nb, nv, nq, nu, ng, nseg, nsite, nhv, nsensor;
   real timestep, gravity[3], tolerance, hull_skin, plane[4], meaninertia, terrain[5];
   int terrain_type;
+  /* tether: soft weld of the root body to its spawn pose (reference compose/world.py:358-365) */
+  int weld_active; real weld_pos[3], weld_quat[4], weld_solref[2], weld_solimp[5], weld_invweight[2];
   int max_iter;
   int *body_parent, *body_dofadr, *body_dofnum;
   real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
@@ -152,8 +155,9 @@ typedef struct {
   real con_mu[NMF_MAXCON];
   real *J;                             /* (4*MAXCON) x nv */
   real *Jc;                            /* (3*MAXCON) x nv: normal, t1, t2 Jacobians */
-  real efc_D[4 * NMF_MAXCON], efc_aref[4 * NMF_MAXCON], efc_force[4 * NMF_MAXCON];
-  real efc_R[4 * NMF_MAXCON], efc_KBI[4 * NMF_MAXCON][3];
+  real efc_D[NMF_MAXEFC], efc_aref[NMF_MAXEFC], efc_force[NMF_MAXEFC];
+  real efc_R[NMF_MAXEFC], efc_KBI[NMF_MAXEFC][3], efc_pos[NMF_MAXEFC];
+  int efc_bilateral[NMF_MAXEFC];
   /* velocity / force */
   real *cvel, *cacc, *cfrc;            /* nb x 6 */
   real *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qfrc_constraint;
@@ -227,6 +231,11 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   t = blob_real(blob, "plane", NULL); memcpy(m->plane, t, 4 * sizeof(real)); free(t);
   t = blob_real(blob, "terrain_params", NULL); memcpy(m->terrain, t, 5 * sizeof(real)); free(t);
   { int* tt = blob_int(blob, "terrain_type", NULL); m->terrain_type = tt[0]; free(tt); }
+  { int* wa = blob_int(blob, "weld_active", NULL); m->weld_active = wa[0]; free(wa);
+    t = blob_real(blob, "weld_params", NULL);    /* pos3 quat4 solref2 solimp5 invweight2 */
+    memcpy(m->weld_pos, t, 3 * sizeof(real)); memcpy(m->weld_quat, t + 3, 4 * sizeof(real));
+    memcpy(m->weld_solref, t + 7, 2 * sizeof(real)); memcpy(m->weld_solimp, t + 9, 5 * sizeof(real));
+    memcpy(m->weld_invweight, t + 14, 2 * sizeof(real)); free(t); }
   t = blob_real(blob, "stat_meaninertia", NULL); m->meaninertia = t[0]; free(t);
   int* it = blob_int(blob, "opt_solver", NULL); m->max_iter = it[0]; free(it);
   it = blob_int(blob, "n_sensor", NULL); m->nsensor = it[0]; free(it);
@@ -250,14 +259,14 @@ EXPORT void* SFX(nmfo_data_create)(const void* mv) {
   d->S = ALLOC(nv * 6); d->daxis = ALLOC(nv * 3); d->danchor = ALLOC(nv * 3);
   d->Ib = ALLOC(nb * 10); d->Ic = ALLOC(nb * 10);
   d->M = ALLOC(nv * nv); d->L = ALLOC(nv * nv); d->Ld = ALLOC(nv); d->H = ALLOC(nv * nv);
-  d->J = ALLOC(4 * NMF_MAXCON * nv); d->Jc = ALLOC(3 * NMF_MAXCON * nv);
+  d->J = ALLOC(NMF_MAXEFC * nv); d->Jc = ALLOC(3 * NMF_MAXCON * nv);
   d->cvel = ALLOC(nb * 6); d->cacc = ALLOC(nb * 6); d->cfrc = ALLOC(nb * 6);
   d->qfrc_passive = ALLOC(nv); d->qfrc_bias = ALLOC(nv); d->qfrc_actuator = ALLOC(nv);
   d->qfrc_smooth = ALLOC(nv); d->qfrc_constraint = ALLOC(nv); d->qacc_smooth = ALLOC(nv);
   d->qacc = ALLOC(nv); d->actuator_force = ALLOC(m->nu); d->act_moment = ALLOC(m->nu * nv);
   d->sensordata = ALLOC(16 * 6);
   d->seg_xpos = ALLOC(m->nseg * 3); d->seg_xquat = ALLOC(m->nseg * 4); d->site_xpos = ALLOC(m->nsite * 3);
-  d->w1 = ALLOC(nv); d->w2 = ALLOC(nv); d->w3 = ALLOC(nv); d->w4 = ALLOC(nv); d->w5 = ALLOC(4 * NMF_MAXCON + nv);
+  d->w1 = ALLOC(nv); d->w2 = ALLOC(nv); d->w3 = ALLOC(nv); d->w4 = ALLOC(nv); d->w5 = ALLOC(NMF_MAXEFC + nv);
   return d;
 }
 
@@ -659,7 +668,33 @@ static void make_constraints(const omodel* m, odata* d) {
       int i = 4 * c + k;
       d->efc_R[i] = Rpy; d->efc_D[i] = (real)1 / Rpy;
       d->efc_KBI[i][0] = K; d->efc_KBI[i][1] = B; d->efc_KBI[i][2] = imp;
+      d->efc_pos[i] = r; d->efc_bilateral[i] = 0;
     }
+  }
+  if (m->weld_active) {
+    /* six bilateral rows = the components (w; v) of the root twist; residual = pose error of the root body */
+    real qt[4] = {m->weld_quat[0], -m->weld_quat[1], -m->weld_quat[2], -m->weld_quat[3]}, qe[4];
+    quat_mul(qe, d->xquat, qt);
+    real sg = qe[0] < 0 ? (real)-2 : (real)2;
+    real res[6] = {sg * qe[1], sg * qe[2], sg * qe[3],
+                   d->xpos[0] - m->weld_pos[0], d->xpos[1] - m->weld_pos[1], d->xpos[2] - m->weld_pos[2]};
+    for (int r = 0; r < 6; r++) {
+      int i = d->nefc + r;
+      real* row = d->J + (size_t)i * nv;
+      memset(row, 0, sizeof(real) * (size_t)nv);
+      for (int j = 0; j < 6; j++) row[j] = d->S[6 * j + r];
+      real imp = impedance(m->weld_solimp, res[r]);
+      real dA = m->weld_invweight[r < 3 ? 1 : 0];
+      real R = ((real)1 - imp) * dA / imp; if (R < (real)NMF_MINVAL) R = (real)NMF_MINVAL;
+      real tc = m->weld_solref[0], dr = m->weld_solref[1], K, B;
+      if (tc > 0) { if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+        K = (real)1 / (m->weld_solimp[1] * m->weld_solimp[1] * tc * tc * dr * dr); B = (real)2 / (m->weld_solimp[1] * tc);
+      } else { K = -tc / (m->weld_solimp[1] * m->weld_solimp[1]); B = -dr / m->weld_solimp[1]; }
+      d->efc_R[i] = R; d->efc_D[i] = (real)1 / R;
+      d->efc_KBI[i][0] = K; d->efc_KBI[i][1] = B; d->efc_KBI[i][2] = imp;
+      d->efc_pos[i] = res[r]; d->efc_bilateral[i] = 1;
+    }
+    d->nefc += 6;
   }
 }
 
@@ -737,9 +772,9 @@ static void actuation(const omodel* m, odata* d) {
 }
 
 /* ------------------------------------------------------------------ stage: Newton solve */
-static real constraint_cost(int nefc, const real* D, const real* jar) {
+static real constraint_cost_b(int nefc, const real* D, const real* jar, const int* bil) {
   real c = 0;
-  for (int i = 0; i < nefc; i++) if (jar[i] < 0) c += (real)0.5 * D[i] * jar[i] * jar[i];
+  for (int i = 0; i < nefc; i++) if (bil[i] || jar[i] < 0) c += (real)0.5 * D[i] * jar[i] * jar[i];
   return c;
 }
 
@@ -747,7 +782,7 @@ static void solve_constraints(const omodel* m, odata* d) {
   int nv = m->nv, nefc = d->nefc;
   real* qacc = d->qacc; real* Ma = d->w1; real* grad = d->w2; real* search = d->w3; real* Mv = d->w4;
   real* jar = d->w5; /* nefc */
-  real jv[4 * NMF_MAXCON];
+  real jv[NMF_MAXEFC];
   d->solver_iter = 0;
   memset(d->qfrc_constraint, 0, sizeof(real) * (size_t)nv);
   memset(d->efc_force, 0, sizeof(d->efc_force));
@@ -756,9 +791,7 @@ static void solve_constraints(const omodel* m, odata* d) {
   for (int i = 0; i < nefc; i++) {
     const real* row = d->J + (size_t)i * nv; real vel = 0;
     for (int j = 0; j < nv; j++) vel += row[j] * d->qvel[j];
-    int c = i / 4; int g = d->con_geom[c];
-    real r = d->con_dist[c] - m->pair_margin[g];
-    d->efc_aref[i] = -d->efc_KBI[i][1] * vel - d->efc_KBI[i][0] * d->efc_KBI[i][2] * r;
+    d->efc_aref[i] = -d->efc_KBI[i][1] * vel - d->efc_KBI[i][0] * d->efc_KBI[i][2] * d->efc_pos[i];
   }
   /* warm start: pick the cheaper of qacc_warmstart and qacc_smooth */
   real cost_ws, cost_sm;
@@ -768,11 +801,11 @@ static void solve_constraints(const omodel* m, odata* d) {
     real g = 0; for (int j = 0; j < nv; j++) g += (real)0.5 * (qacc[j] - d->qacc_smooth[j]) * (Ma[j] - d->qfrc_smooth[j]);
     for (int i = 0; i < nefc; i++) { real s = 0; const real* row = d->J + (size_t)i * nv;
       for (int j = 0; j < nv; j++) s += row[j] * qacc[j]; jar[i] = s - d->efc_aref[i]; }
-    cost_ws = g + constraint_cost(nefc, d->efc_D, jar);
-    real js[4 * NMF_MAXCON];
+    cost_ws = g + constraint_cost_b(nefc, d->efc_D, jar, d->efc_bilateral);
+    real js[NMF_MAXEFC];
     for (int i = 0; i < nefc; i++) { real s = 0; const real* row = d->J + (size_t)i * nv;
       for (int j = 0; j < nv; j++) s += row[j] * d->qacc_smooth[j]; js[i] = s - d->efc_aref[i]; }
-    cost_sm = constraint_cost(nefc, d->efc_D, js);
+    cost_sm = constraint_cost_b(nefc, d->efc_D, js, d->efc_bilateral);
     if (cost_sm < cost_ws) {
       memcpy(qacc, d->qacc_smooth, sizeof(real) * (size_t)nv);
       memcpy(Ma, d->qfrc_smooth, sizeof(real) * (size_t)nv);
@@ -786,7 +819,7 @@ static void solve_constraints(const omodel* m, odata* d) {
     /* gradient and Hessian */
     for (int j = 0; j < nv; j++) grad[j] = Ma[j] - d->qfrc_smooth[j];
     memcpy(d->H, d->M, sizeof(real) * (size_t)nv * nv);
-    for (int i = 0; i < nefc; i++) if (jar[i] < 0) {
+    for (int i = 0; i < nefc; i++) if (d->efc_bilateral[i] || jar[i] < 0) {
       const real* row = d->J + (size_t)i * nv; real Di = d->efc_D[i]; real f = -Di * jar[i];
       for (int j = 0; j < nv; j++) if (row[j] != 0) {
         grad[j] -= row[j] * f;
@@ -817,7 +850,7 @@ static void solve_constraints(const omodel* m, odata* d) {
     for (int ls = 0; ls < 30; ls++) {
       real d1 = g1 + alpha * g2, d2 = g2;
       for (int i = 0; i < nefc; i++) { real x = jar[i] + alpha * jv[i];
-        if (x < 0) { d1 += d->efc_D[i] * x * jv[i]; d2 += d->efc_D[i] * jv[i] * jv[i]; } }
+        if (d->efc_bilateral[i] || x < 0) { d1 += d->efc_D[i] * x * jv[i]; d2 += d->efc_D[i] * jv[i] * jv[i]; } }
       if (d2 <= 0 || d1 == 0) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       real next = alpha - d1 / d2;
@@ -825,7 +858,8 @@ static void solve_constraints(const omodel* m, odata* d) {
       if (hi >= 0 && (next <= lo || next >= hi)) { next = (real)0.5 * (lo + hi); bisected = 1; }
       /* phi' is linear while the active set does not change: then `next` is the exact minimiser */
       int same = !bisected;
-      for (int i = 0; same && i < nefc; i++) same = ((jar[i] + alpha * jv[i]) < 0) == ((jar[i] + next * jv[i]) < 0);
+      for (int i = 0; same && i < nefc; i++)
+        same = d->efc_bilateral[i] || (((jar[i] + alpha * jv[i]) < 0) == ((jar[i] + next * jv[i]) < 0));
       real change = R_FABS(next - alpha);
       alpha = next;
       if (same || change <= (real)8 * R_EPS * R_FABS(next)) break;
@@ -834,7 +868,7 @@ static void solve_constraints(const omodel* m, odata* d) {
     for (int j = 0; j < nv; j++) { qacc[j] += alpha * search[j]; Ma[j] += alpha * Mv[j]; }
     for (int i = 0; i < nefc; i++) jar[i] += alpha * jv[i];
     real gq = 0; for (int j = 0; j < nv; j++) gq += (real)0.5 * (qacc[j] - d->qacc_smooth[j]) * (Ma[j] - d->qfrc_smooth[j]);
-    real newcost = gq + constraint_cost(nefc, d->efc_D, jar);
+    real newcost = gq + constraint_cost_b(nefc, d->efc_D, jar, d->efc_bilateral);
     d->solver_iter = iter + 1;
     real improvement = cost - newcost;
     cost = newcost;
@@ -842,7 +876,7 @@ static void solve_constraints(const omodel* m, odata* d) {
   }
   d->solver_cost = cost;
   for (int i = 0; i < nefc; i++) {
-    real f = jar[i] < 0 ? -d->efc_D[i] * jar[i] : 0;
+    real f = (d->efc_bilateral[i] || jar[i] < 0) ? -d->efc_D[i] * jar[i] : 0;
     d->efc_force[i] = f;
     if (f != 0) { const real* row = d->J + (size_t)i * nv; for (int j = 0; j < nv; j++) d->qfrc_constraint[j] += row[j] * f; }
   }
