@@ -229,7 +229,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>>", "kernel_ms_per_launch": ms,
+                "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>, false>", "kernel_ms_per_launch": ms,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 "note": "the step is VALU/LDS-latency bound by construction (state crosses HBM once per launch); "
                         "see DESIGN.md for the instruction-side analysis",

@@ -159,10 +159,11 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
-  if (b->topo == 0)
-    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopo>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode);
-  else
-    hipLaunchKernelGGL((nmf::nmf_step_kernel<nmf::FlyTopoActive>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode);
+  const bool weld = b->dm.weld_active != 0;
+#define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode)
+  if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
+  else { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
+#undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
 }

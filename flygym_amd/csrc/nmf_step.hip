@@ -529,7 +529,7 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
   Uout = mask * U; uout = u; invDout = invD;
 }
 
-template <class TP>
+template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
                           const DevModel& m, int lane) {
   const float* tau = s.vec(tau_id);
@@ -582,7 +582,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if (withK) {
       for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
-      static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
+      if constexpr (WELD) static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
     }
     pA = 0.f;
 #pragma unroll
@@ -719,7 +719,7 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
 }
 
 // ------------------------------------------------------------------ the step
-template <class TP>
+template <class TP, bool WELD>
 __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   stage_kinematics(s, m, lane);
@@ -762,7 +762,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   // ---- tether weld rows (lanes 48..53); without a tether their stiffness and wrench are zero
   WeldRow wr;
   wr.comp = lane - 48;
-  wr.on = m.weld_active != 0 && wr.comp >= 0 && wr.comp < 6;
+  wr.on = WELD && wr.comp >= 0 && wr.comp < 6;
   wr.D = 0.f; wr.aref = 0.f; wr.jar = 0.f; wr.jv = 0.f;
   float weld_res = 0.f, weld_KI = 0.f, weld_B = 0.f;
   if (wr.comp >= 0 && wr.comp < 6) {
@@ -870,13 +870,13 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   });
   STAGE(6);
   // ---- unconstrained acceleration
-  aba_solve(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane);
+  aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane);
   contact_reload(c, s, lane);
   STAGE(7);
 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
-  if (ncon == 0 && !m.weld_active) {
+  if (ncon == 0 && !WELD) {
     for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
@@ -924,7 +924,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       STAGE(9);
-      aba_solve(s, V_A, V_B, true, 0.f, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
+      aba_solve<TP, WELD>(s, V_A, V_B, true, 0.f, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
       contact_reload(c, s, lane);
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
@@ -1024,13 +1024,13 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   STAGE(17);
 }
 
-template <class TP>
+template <class TP, bool WELD>
 __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
   WSYNC();
-  aba_solve(s, V_A, V_B, false, h, m, lane);
+  aba_solve<TP, WELD>(s, V_A, V_B, false, h, m, lane);
   for (int j = lane; j < TP::NV; j += kWave) s.qvel[j] += h * s.vB[j];
   WSYNC();
   if (lane == 0) {
@@ -1082,7 +1082,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
 }
 
 // mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
-template <class TP>
+template <class TP, bool WELD>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
   const DevModel& m = *mp;
@@ -1117,8 +1117,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
         WSYNC();
       }
       STAGE(0);
-      physics_forward(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);
-      physics_integrate(s, m, lane STAGE_PASS);
+      physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);
+      physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
       STAGE(15);
       time += m.timestep;
     }
@@ -1151,7 +1151,9 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
 using FlyTopo = Topo<6, 3, 2, 1, 1, 1, 1, 1, 1>;   // LEGS_ONLY skeleton: 49 bodies, 72 dofs
 using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
-template __global__ void nmf_step_kernel<FlyTopo>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoActive>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int, int);
 
 }  // namespace nmf

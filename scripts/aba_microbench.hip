@@ -21,7 +21,7 @@ aba_bench_kernel(const DevModel* mp, DevState st, unsigned long long* cycles, in
   __syncthreads();
   unsigned long long t0 = clock64();
   for (int r = 0; r < reps; ++r) {
-    aba_solve(s, V_A, V_B, withK != 0, 0.f, m, lane);
+    aba_solve<TP, false>(s, V_A, V_B, withK != 0, 0.f, m, lane);
     for (int j = lane; j < TP::NV; j += kWave) s.vA[j] += 1e-3f * s.vB[j];
     __syncthreads();
   }
