@@ -547,6 +547,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
   }
   float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[TP::NDL];   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j
+  int cs[TP::NBL + 1], cs_root0 = 0, cs_root1 = 0;                         // contact ranges of the leg's bodies / the root
+  static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK ? s.body_cstart[b0 + l] : 0; });
+  if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
   float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float pA = 0.f;
   // ---- backward sweep along the leg
@@ -558,7 +561,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       float row[6];
 #pragma unroll
       for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
-      if (withK) for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
 #pragma unroll
       for (int i = 0; i < 6; i++) IA[i] += row[i];
     }
@@ -580,7 +583,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
     for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
     if (withK) {
-      for (int c = s.body_cstart[0]; c < s.body_cstart[1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+      for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, L.rr, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
       if constexpr (WELD) static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
     }
@@ -697,12 +700,11 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = 1 + L.lg * TP::NBL;
   float acc = 0.f;
-  int cend = s.body_cstart[b0 + TP::NBL];
+  int cs[TP::NBL + 1];                       // contact ranges of the leg's bodies, fetched in one batch
+  static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = s.body_cstart[b0 + l]; });
   static_for<TP::NBL>([&](auto I) {
     constexpr int l = TP::NBL - 1 - decltype(I)::value;
-    const int cbeg = s.body_cstart[b0 + l];
-    for (int cc = cbeg; cc < cend; ++cc) acc += s.c_w[cc][L.rr];
-    cend = cbeg;
+    for (int cc = cs[l]; cc < cs[l + 1]; ++cc) acc += s.c_w[cc][L.rr];
     s.W[b0 + l][L.rr] = acc;
   });
   WSYNC();
