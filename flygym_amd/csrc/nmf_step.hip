@@ -679,21 +679,23 @@ __device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
   return wave_sum(v);
 }
 
-// out = sign * JT f  for the contact forces f_k = −D jar_k on the active rows: every contact lane
-// publishes its world wrench (about the root origin) in c_w, then the leg groups suffix-sum the
-// wrenches of their bodies' contacts (contacts are sorted by body) and the dofs project.
-template <class TP, class Emit>
+// emit(j, (JT rows)_j [+ seed_scale * (subtree sum of W)_j])  for per-contact row forces `rows` (pyramid rows of the
+// lane's contact) and the tether row force `weld_row`: every contact lane publishes its world wrench (about the
+// root origin) in c_w, then the leg groups suffix-sum the wrenches of their bodies' contacts (contacts are sorted by
+// body) and the dofs project.  SEEDED: W already holds per-body wrenches (I_b T_b of the search direction) that ride
+// the same sweep, so  alpha M search − JT df  costs one pass.  The active-row mask of c.jar goes to c_info for the ABA.
+template <class TP, bool SEEDED, class Emit>
 __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const WeldRow& wr, const Frame& fr,
-                                                float sign, const DevModel& m, int lane, Emit&& emit) {
-  if (wr.on) s.weld_w[wr.comp] = sign * (-wr.D * wr.jar);
+                                                const float* rows, float weld_row, float seed_scale,
+                                                const DevModel& m, int lane, Emit&& emit) {
+  if (wr.on) s.weld_w[wr.comp] = weld_row;
   if (c.on) {
-    float f[4]; int act = 0;
+    int act = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { f[k] = c.jar[k] < 0.f ? -c.D * c.jar[k] : 0.f; act |= (c.jar[k] < 0.f ? 1 : 0) << k; }
-    float fn = f[0] + f[1] + f[2] + f[3], f1 = c.mu * (f[0] - f[1]), f2 = c.mu * (f[2] - f[3]);
+    for (int k = 0; k < 4; k++) act |= (c.jar[k] < 0.f ? 1 : 0) << k;
+    float fn = rows[0] + rows[1] + rows[2] + rows[3], f1 = c.mu * (rows[0] - rows[1]), f2 = c.mu * (rows[2] - rows[3]);
     V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
-    SV w = SV{cross(c.r, F), F};
-    stsv(s.c_w[lane], sign * w);
+    stsv(s.c_w[lane], SV{cross(c.r, F), F});
     s.c_info[lane] = c.info | (act << 20);
   }
   WSYNC();
@@ -704,12 +706,14 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
   static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = s.body_cstart[b0 + l]; });
   static_for<TP::NBL>([&](auto I) {
     constexpr int l = TP::NBL - 1 - decltype(I)::value;
+    if (SEEDED) acc += seed_scale * s.W[b0 + l][L.rr];
     for (int cc = cs[l]; cc < cs[l + 1]; ++cc) acc += s.c_w[cc][L.rr];
     s.W[b0 + l][L.rr] = acc;
   });
   WSYNC();
   if (lane < 6) {
     float a0 = s.weld_w[lane];
+    if (SEEDED) a0 += seed_scale * s.W[0][lane];
     for (int cc = s.body_cstart[0]; cc < s.body_cstart[1]; ++cc) a0 += s.c_w[cc][lane];
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[1 + k * TP::NBL][lane];
@@ -718,6 +722,12 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)])));
   WSYNC();
+}
+
+// row forces f_k = −D jar_k on the active (jar < 0) pyramid rows, times `sign`
+__device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float sign, float* f) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) f[k] = c.jar[k] < 0.f ? -sign * c.D * c.jar[k] : 0.f;
 }
 
 // ------------------------------------------------------------------ the step
@@ -882,47 +892,58 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
-    float* Ma = s.vC; float* grad = s.vA; float* search = s.vB; float* Mv = s.vD;
+    // The loop carries the gradient itself:  grad += alpha M search − JT (f_new − f_old)  after every move, one merged
+    // leaf-to-root sweep (body wrenches alpha I_b T_b and the contact wrenches of −df together) instead of a product
+    // with M plus a fresh JT f.  vA holds the Newton right-hand side −grad, vD the magnitude of the summed terms.
+    float* Gv = s.vC; float* rhs = s.vA; float* search = s.vB; float* magv = s.vD;
     // candidate 1: warm start
     float g = 0.f;
     mul_M(s, s.qacc, m, lane, false, [&](int j, float v) {      // qacc still holds the warm start
-      Ma[j] = v;
-      g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (v - s.qfrc_smooth[j]);
+      const float gv = v - s.qfrc_smooth[j];
+      Gv[j] = gv;
+      g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * gv;
     });
     if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
 #pragma unroll
       for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
     if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
-    float cost = wave_sum(g) + constraint_cost<TP>(c, wr);
+    float gauss = wave_sum(g), ccost = constraint_cost<TP>(c, wr);
     // candidate 2: unconstrained acceleration
     sweep_twists(s, s.qacc_smooth, s.T, m, lane);
-    ContactRegs c2 = c;
-    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c2.jar);
+    {
+      float j0[4] = {0.f, 0.f, 0.f, 0.f}, w0 = 0.f;
+      float v = 0.f;
+      if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), j0);
 #pragma unroll
-      for (int k = 0; k < 4; k++) c2.jar[k] -= c.aref[k]; }
-    WeldRow wr2 = wr;
-    if (wr.on) wr2.jar = s.T[0][wr.comp] - wr.aref;
-    float cost_sm = constraint_cost<TP>(c2, wr2);
-    if (cost_sm < cost) {
-      cost = cost_sm;
-      wr.jar = wr2.jar;
+        for (int k = 0; k < 4; k++) { j0[k] -= c.aref[k]; if (j0[k] < 0.f) v += 0.5f * c.D * j0[k] * j0[k]; } }
+      if (wr.on) { w0 = s.T[0][wr.comp] - wr.aref; v += 0.5f * wr.D * w0 * w0; }
+      const float cost_sm = wave_sum(v);
+      if (cost_sm < gauss + ccost) {
+        gauss = 0.f; ccost = cost_sm;
+        wr.jar = w0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) c.jar[k] = c2.jar[k];
-      for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Ma[j] = s.qfrc_smooth[j]; }
+        for (int k = 0; k < 4; k++) c.jar[k] = j0[k];
+        for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Gv[j] = 0.f; }
+      }
     }
     WSYNC();
     const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
-    STAGE(8);
-    for (int iter = 0; iter < m.max_iter; ++iter) {
-      // gradient = Ma − qfrc_smooth − Jᵀ f
-      float gn = 0.f, gm = 0.f;
-      contact_project(s, c, wr, fr, -1.0f, m, lane, [&](int j, float jtf) {
-        float gj = jtf + Ma[j] - s.qfrc_smooth[j];
-        float mag = fabsf(Ma[j]) + fabsf(s.qfrc_smooth[j]) + fabsf(jtf);
-        grad[j] = -gj;   // store the right-hand side of the Newton system
+    // gradient = (M qacc − qfrc_smooth) − JT f
+    float gn = 0.f, gm = 0.f;
+    {
+      float f0[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c.on) contact_row_forces(c, -1.f, f0);
+      contact_project<TP, false>(s, c, wr, fr, f0, wr.D * wr.jar, 0.f, m, lane, [&](int j, float proj) {
+        const float gv = Gv[j], qs = s.qfrc_smooth[j];
+        const float gj = gv + proj;
+        const float mag = fabsf(gv + qs) + fabsf(qs) + fabsf(proj);
+        rhs[j] = -gj; magv[j] = mag;
         gn += gj * gj; gm += mag * mag;
       });
       gn = wave_sum(gn); gm = wave_sum(gm);
+    }
+    STAGE(8);
+    for (int iter = 0; iter < m.max_iter; ++iter) {
       // converged, or the gradient is at its float32 rounding-noise floor (oracle: NMF_NOISE_FACTOR)
       if (scale * sqrtf(gn) < m.tolerance || sqrtf(gn) <= kNoiseFactor * 1.1920929e-07f * sqrtf(gm)) break;
       STAGE(9);
@@ -931,11 +952,20 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       STAGE(10);
       if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
       if (wr.on) wr.jv = s.T[0][wr.comp];
+      // g1 = search·(M qacc − qfrc_smooth) = search·grad + (J search)·f ;  g2 = search·M·search as twice the kinetic
+      // energy of the twists the ABA left in T (a sum of positive terms).  W keeps I_b T_b for the update sweep.
       float g1 = 0.f, g2 = 0.f;
-      mul_M(s, search, m, lane, true, [&](int j, float v) {
-        Mv[j] = v;
-        g1 += search[j] * (Ma[j] - s.qfrc_smooth[j]); g2 += search[j] * v;
-      });
+      for (int j = lane; j < TP::NV; j += kWave) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; }
+      for (int b = lane; b < TP::NB; b += kWave) {
+        const SV tb = ldsv(s.T[b]), wb = inert_mul(s.Ib[b], tb);
+        stsv(s.W[b], wb);
+        g2 += dot(tb, wb);
+      }
+      if (c.on) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) g1 -= c.D * c.jar[k] * c.jv[k];
+      }
+      if (wr.on) g1 -= wr.D * wr.jar * wr.jv;
       g1 = wave_sum(g1); g2 = wave_sum(g2);
       STAGE(11);
       // exact line search
@@ -970,25 +1000,44 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       }
       STAGE(12);
       if (alpha <= 0.f) break;
-      for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] += alpha * search[j]; Ma[j] += alpha * Mv[j]; }
+      // move:  qacc += alpha search;  grad += alpha M search − JT (f_new − f_old)
+      float df[4] = {0.f, 0.f, 0.f, 0.f};
       if (c.on) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) c.jar[k] += alpha * c.jv[k];
+        for (int k = 0; k < 4; k++) {
+          const float fo = c.jar[k] < 0.f ? c.D * c.jar[k] : 0.f;      // −f_old
+          c.jar[k] += alpha * c.jv[k];
+          df[k] = (c.jar[k] < 0.f ? c.D * c.jar[k] : 0.f) - fo;        // −(f_new − f_old)
+        }
       }
-      if (wr.on) wr.jar += alpha * wr.jv;
-      WSYNC();
-      float gq = 0.f;
-      for (int j = lane; j < TP::NV; j += kWave) gq += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * (Ma[j] - s.qfrc_smooth[j]);
-      float newcost = wave_sum(gq) + constraint_cost<TP>(c, wr);
+      float dfw = 0.f;
+      if (wr.on) { dfw = wr.D * alpha * wr.jv; wr.jar += alpha * wr.jv; }
+      gn = 0.f; gm = 0.f;
+      contact_project<TP, true>(s, c, wr, fr, df, dfw, alpha, m, lane, [&](int j, float x) {
+        const float sj = search[j];
+        x += alpha * s.arm[j] * sj;
+        s.qacc[j] += alpha * sj;
+        const float r = rhs[j] - x, mag = magv[j] + fabsf(x);
+        rhs[j] = r; magv[j] = mag;
+        gn += r * r; gm += mag * mag;
+      });
+      gn = wave_sum(gn); gm = wave_sum(gm);
+      // the Gauss term is quadratic along the search direction: its change is exact from g1, g2
+      const float dgauss = alpha * (g1 + 0.5f * alpha * g2);
+      const float newccost = constraint_cost<TP>(c, wr);
       iters = iter + 1;
       STAGE(13);
-      float improvement = cost - newcost;
-      cost = newcost;
-      if (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(cost)) break;
+      const float improvement = (ccost - newccost) - dgauss;
+      gauss += dgauss; ccost = newccost;
+      if (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost)) break;
     }
     STAGE(9);
     // constraint forces
-    contact_project(s, c, wr, fr, 1.0f, m, lane, [&](int j, float v) { s.vD[j] = v; });   // qfrc_constraint lives in vD until the Euler step
+    {
+      float ff[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c.on) contact_row_forces(c, 1.f, ff);
+      contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, [&](int j, float v) { s.vD[j] = v; });
+    }   // qfrc_constraint lives in vD until the Euler step
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);
