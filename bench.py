@@ -52,6 +52,8 @@ def parse_args():
                          "kinematic replay of the Spotlight clip (world w <- partition w %% 20)")
     ap.add_argument("--terrain", choices=["flat", "gapped", "blocks", "mixed"], default="flat",
                     help="flat = BASELINE config 2; gapped/blocks = config 4; mixed = config 5 (build-defined height maps)")
+    ap.add_argument("--cpg-adhesion", type=float, default=0.0, metavar="ON",
+                    help="drive leg adhesion from the CPG: control ON in stance, 1 (the reference's minimum) in swing (config 5)")
     ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,11 +140,12 @@ def main():
         table_steps = 2500  # three 12 Hz gait cycles: the table wraps around seamlessly
         cpg = TripodCPG(order, sim.timestep)
         table_np = None
+        adhesion = (cpg.stance_bins(sim.model, fly), args.cpg_adhesion, 1.0) if args.cpg_adhesion > 0 else None
         table = cpg.targets(n_local, table_steps, device=sim.device, first_world=rank * n_local,
-                            total_worlds=n_local * world_size)       # built on the GPU: no multi-GB host arrays
+                            total_worlds=n_local * world_size, adhesion=adhesion)   # built on the GPU: no multi-GB host arrays
     if table_np is not None:
         table = torch.as_tensor(table_np, device=sim.device)
-    act_ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
+    act_ids = sim.replay_ids(fly.name, with_adhesion=args.workload == "cpg" and args.cpg_adhesion > 0)
     maps = sim._ids_by_fly[fly.name]
 
     sim.set_leg_adhesion_states(fly.name, np.ones((n_local, 6), dtype=np.float32))
@@ -205,7 +208,7 @@ def main():
         if tfile.exists():
             rec = json.loads(tfile.read_text())
             if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch"), rec.get("control")) == (n_local, spl, args.workload) \
-                    and args.terrain == "flat" and not args.odor:
+                    and args.terrain == "flat" and not args.odor and not args.cpg_adhesion:
                 traffic = rec["traffic_bytes_per_launch"]
         out = {
             "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
@@ -213,7 +216,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + ", LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
+                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else

@@ -63,6 +63,7 @@ def lib():
             "nmf_batch_destroy": (None, [vp]),
             "nmf_batch_n_worlds": (ci, [vp]),
             "nmf_reset": (ci, [vp, vp]),
+            "nmf_reset_worlds": (ci, [vp, vp, vp]),
             "nmf_step": (ci, [vp, ci, vp]),
             "nmf_step_replay": (ci, [vp, vp, ci, ci, vp, ci, ci, vp]),
             "nmf_field_ptr": (vp, [vp, ci, ctypes.POINTER(ctypes.c_int32)]),

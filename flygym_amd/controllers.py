@@ -12,6 +12,11 @@ no CPG (flygym 2.0.1 dropped flygym 1.x's controllers), 
 
 The controller emits a ``(n_worlds, steps, 42)`` float32 target table on the GPU, i.e. exactly the input of
 ``HIPSimulation.step_replay`` / ``nmf_step_replay``: the CPG runs inside the stepping kernel's control-load stage.
+
+Leg adhesion driven by the gait (BASELINE config 5): ``stance_bins`` marks, per leg, the part of the step cycle in
+which the claw is near its lowest point (forward kinematics of the cycle in the thorax frame); with
+``adhesion=(stance, on, off)`` the table gets six more columns holding the adhesion control ``on`` in stance and
+``off`` in swing.  The reference clamps adhesion controls to [1, 100] (``compose/fly.py:434-440``), so "off" is 1.
 """
 
 from __future__ import annotations
@@ -71,10 +76,54 @@ class TripodCPG:
         ph = 2 * np.pi * self.frequency * t[None, :, None] + world[:, None, None] + bias[None, None, :]
         return np.mod(ph, 2 * np.pi)
 
+    def stance_bins(self, model, fly, threshold: float = 0.3) -> np.ndarray:
+        """``(n_bins, 6)`` bool: leg ``l`` is in stance in phase bin ``i`` when the origin of its last tarsal segment,
+        computed by forward kinematics of the step cycle with the thorax at the identity pose, lies within
+        ``threshold`` of its height range above its lowest point.  ``model`` is the compiled model of a world
+        holding ``fly`` (``HIPSimulation.model``)."""
+        from .compiler.rigid import forward_kinematics
+
+        pos_ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == "position"]
+        if len(pos_ids) != len(self.actuated_dofs):
+            raise ValueError("the fly's position actuators do not match the controller's actuated dofs")
+        qadr = np.asarray(model["act_trn"])[pos_ids] + 1
+        segs = [s.name for s in fly.get_bodysegs_order()]
+        claw_body = [int(model["seg_body"][segs.index(f"{leg}_tarsus5")]) for leg in LEGS]
+        q = np.array(model["key_qpos"], dtype=np.float64)
+        q[:7] = (0, 0, 0, 1, 0, 0, 0)
+        z = np.zeros((self.n_bins, 6))
+        for i in range(self.n_bins):
+            q[qadr] = self.cycle[i]
+            xpos, _, _ = forward_kinematics(model, q)
+            z[i] = xpos[claw_body, 2]
+        lo, hi = z.min(axis=0), z.max(axis=0)
+        return z <= lo + threshold * (hi - lo)
+
     def targets(self, n_worlds: int, steps: int, start_step: int = 0, device=None, first_world: int = 0,
-                total_worlds: int | None = None):
+                total_worlds: int | None = None, adhesion=None):
         """Target table ``(n_worlds, steps, n_act)`` float32: a torch tensor built on ``device`` if given (no large
-        host arrays), else numpy."""
+        host arrays), else numpy.  ``adhesion=(stance_bins, on, off)`` appends six adhesion-control columns
+        (legs in ``LEGS`` order): ``on`` while the leg's phase bin is a stance bin, else ``off``."""
+        if adhesion is not None:
+            stance, on, off = adhesion
+            pos = self.targets(n_worlds, steps, start_step, device, first_world, total_worlds)
+            legbias = np.array([TRIPOD_PHASE_BIAS[leg] for leg in LEGS])
+            if device is None:
+                ph = self.phases(n_worlds, steps, start_step, first_world, total_worlds)
+                idx = np.floor(ph / (2 * np.pi) * self.n_bins).astype(np.int64) % self.n_bins
+                adh = np.where(np.asarray(stance)[idx, np.arange(6)[None, None, :]], on, off).astype(np.float32)
+                return np.ascontiguousarray(np.concatenate([pos, adh], axis=2))
+            import torch
+
+            st = torch.as_tensor(np.asarray(stance), device=device)
+            t = (start_step + torch.arange(steps, device=device, dtype=torch.float64)) * self.timestep * self.frequency
+            w = (first_world + torch.arange(n_worlds, device=device, dtype=torch.float64)) / float(total_worlds or n_worlds)
+            b = torch.as_tensor(legbias / (2 * np.pi), device=device, dtype=torch.float64)
+            x = torch.remainder(t[None, :, None] + w[:, None, None] + b[None, None, :], 1.0) * self.n_bins
+            idx = torch.floor(x).to(torch.int64) % self.n_bins
+            adh = torch.where(st[idx, torch.arange(6, device=device)[None, None, :]],
+                              torch.tensor(float(on), device=device), torch.tensor(float(off), device=device))
+            return torch.cat([pos, adh.to(torch.float32)], dim=2).contiguous()
         n_act = len(self.actuated_dofs)
         bias = np.array([TRIPOD_PHASE_BIAS[leg] for leg in LEGS])[self.leg_of_dof]                 # (n_act,)
         if device is None:

@@ -262,15 +262,22 @@ extern "C" int nmf_batch_n_worlds(const nmf_batch* b) { return b ? b->n_worlds :
 
 extern "C" int nmf_reset(nmf_batch* b, void* stream) {
   if (!b) return fail("nmf_reset: null batch");
-  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, nullptr};
   b->steps = 0;
+  return launch(b, rp, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int nmf_reset_worlds(nmf_batch* b, const uint8_t* mask_dev, void* stream) {
+  if (!b) return fail("nmf_reset_worlds: null batch");
+  if (!mask_dev) return fail("nmf_reset_worlds: null mask");
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, mask_dev};
   return launch(b, rp, 0, 1, (hipStream_t)stream);
 }
 
 extern "C" int nmf_step(nmf_batch* b, int n_steps, void* stream) {
   if (!b) return fail("nmf_step: null batch");
   if (n_steps <= 0) return fail("nmf_step: n_steps must be positive");
-  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, nullptr};
   b->steps += n_steps;
   return launch(b, rp, n_steps, 0, (hipStream_t)stream);
 }
@@ -281,7 +288,7 @@ extern "C" int nmf_step_replay(nmf_batch* b, const float* table_dev, int table_s
   if (n_steps <= 0) return fail("nmf_step_replay: n_steps must be positive");
   if (!table_dev || !act_ids_dev || table_steps <= 0 || n_act <= 0 || n_act > b->model->nu)
     return fail("nmf_step_replay: bad replay table arguments");
-  nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps};
+  nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps, nullptr};
   b->steps += n_steps;
   return launch(b, rp, n_steps, 0, (hipStream_t)stream);
 }

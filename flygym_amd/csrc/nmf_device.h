@@ -84,6 +84,7 @@ struct ReplayArgs {
   const float* table;   // [n_worlds][table_steps][n_act] or nullptr
   const int* act_ids;   // [n_act]
   int table_steps, n_act, start;
+  const unsigned char* reset_mask;   // mode 1 only: reset world w iff reset_mask[w] != 0 (nullptr = all worlds)
 };
 
 // ---------------------------------------------------------------- small math

@@ -1139,6 +1139,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   const DevModel& m = *mp;
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= st.n_worlds) return;
+  if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
   STAGE_INIT();
   for (int j = lane; j < TP::NV; j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
   float time;

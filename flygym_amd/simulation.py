@@ -160,6 +160,16 @@ class HIPSimulation:
         self._total_physics_time_ns = 0
         self._total_render_time_ns = 0
 
+    def reset_worlds(self, mask) -> None:
+        """Reset only the worlds where ``mask`` (``(n_worlds,)`` bool, numpy or torch) is set: keyframe pose, zero
+        velocity, clock at 0.  The other worlds keep their state.  Stream-ordered device work (no host sync)."""
+        t = self._torch
+        m = t.as_tensor(mask, device=self.device)
+        if tuple(m.shape) != (self.n_worlds,):
+            raise ValueError(f"Expected a reset mask of shape ({self.n_worlds},), but got {tuple(m.shape)}")
+        m = (m != 0).to(t.uint8).contiguous()
+        _native.check(self._lib.nmf_reset_worlds(self._batch_h, m.data_ptr(), self._stream()))
+
     def step(self, n_steps: int = 1) -> None:
         """Advance all worlds by one timestep (``n_steps`` > 1 fuses several into one launch)."""
         _native.check(self._lib.nmf_step(self._batch_h, int(n_steps), self._stream()))
@@ -169,6 +179,14 @@ class HIPSimulation:
         _native.check(self._lib.nmf_step_replay(
             self._batch_h, table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr(),
             int(start), int(n_steps), self._stream()))
+
+    def replay_ids(self, fly_name: str, with_adhesion: bool = False):
+        """Engine control ids (device int32) of the columns of a replay / CPG target table: the fly's position actuators
+        in ``get_actuated_jointdofs_order`` order, then (optionally) its six adhesion actuators in ``LEGS`` order."""
+        ids = self._ids_by_fly[fly_name]["actuators"][ActuatorType.POSITION]
+        if with_adhesion:
+            ids = self._torch.cat([ids, self._ids_by_fly[fly_name]["adhesion"]])
+        return ids
 
     def step_with_profile(self) -> None:
         t0 = perf_counter_ns()

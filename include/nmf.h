@@ -63,6 +63,10 @@ int nmf_batch_n_worlds(const nmf_batch* batch);
  * and refresh the pose outputs.  Replaces GPUSimulation.reset (warp/simulation.py:64-71). */
 int nmf_reset(nmf_batch* batch, void* stream);
 
+/* Same for the worlds with mask_dev[w] != 0 only (uint8 per world, device memory); the others keep their state and
+ * their own clock.  No reference counterpart (its reset re-uploads every world): episode resets for RL loops. */
+int nmf_reset_worlds(nmf_batch* batch, const uint8_t* mask_dev, void* stream);
+
 /* Advance all worlds by n_steps physics steps in ONE kernel launch, controls held constant.
  * Replaces n_steps calls of GPUSimulation.step (warp/simulation.py:260-263). */
 int nmf_step(nmf_batch* batch, int n_steps, void* stream);

@@ -30,8 +30,8 @@ steps = 500
 sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
 L.nmf_debug_stage_cycles(buf, 24, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
-         "ABA smooth", "solver init", "newton: wrench+grad", "newton: ABA(H)", "newton: M*search+jv", "newton: linesearch",
-         "newton: update+cost", "final forces", "integrate (ABA Euler)", "write outputs", "sensors"]
+         "ABA smooth", "solver init + first grad", "newton: test/exit", "newton: ABA(H)", "newton: jv, g1, g2", "newton: linesearch",
+         "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
 tot = cyc.sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")

@@ -31,3 +31,39 @@ def test_tripod_cpg_tables(bench_model, oracle_lib):
     x0 = o.qpos[0]
     o.step_replay(t[0], np.arange(42), 0, 2500)
     assert o.qpos[0] - x0 > 1.0 and np.isfinite(o.qpos).all()
+
+
+def test_cpg_driven_adhesion_columns(bench_model, oracle_lib):
+    """BASELINE config 5: adhesion follows the gait.  Stance = claw near its lowest point of the step cycle."""
+    import torch
+
+    fly, _, m = bench_model
+    order = fly.get_actuated_jointdofs_order("position")
+    cpg = TripodCPG(order, 1e-4)
+    stance = cpg.stance_bins(m, fly)
+    assert stance.shape == (256, 6) and stance.dtype == bool
+    frac = stance.mean(axis=0)
+    assert ((frac > 0.35) & (frac < 0.75)).all()                       # every leg spends a good part of the cycle on the ground
+    for leg in range(6):                                              # one contiguous stance phase per cycle
+        assert (np.roll(stance[:, leg], 1) != stance[:, leg]).sum() <= 4
+    legs = {leg: i for i, leg in enumerate(LEGS)}
+    t = cpg.targets(4, 2500, adhesion=(stance, 20.0, 1.0))
+    assert t.shape == (4, 2500, 48)
+    np.testing.assert_array_equal(t[..., :42], cpg.targets(4, 2500))
+    assert set(np.unique(t[..., 42:])) == {1.0, 20.0}
+    # tripod A and tripod B alternate: lf and rf are never both in swing for long, and their stance is out of phase
+    both = (t[0, :, 42 + legs["lf"]] == 20.0) & (t[0, :, 42 + legs["rf"]] == 20.0)
+    assert both.mean() < 0.45
+    # the torch builder (used on the GPU) gives the same table
+    tt = cpg.targets(4, 2500, device="cpu", adhesion=(stance, 20.0, 1.0)).numpy()
+    np.testing.assert_allclose(tt[..., :42], t[..., :42], atol=2e-6)
+    assert (tt[..., 42:] != t[..., 42:]).mean() < 1e-3              # bin edges may round differently
+    # walking with gait-driven adhesion on the CPU oracle: stays finite and moves forward
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.ctrl[42:] = 1.0
+    o.step(500)
+    x0 = o.qpos[0]
+    pos_ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == "position"]
+    adh_ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == "adhesion"]
+    o.step_replay(t[0], np.array(pos_ids + adh_ids), 0, 2500)
+    assert np.isfinite(o.qpos).all() and o.qpos[0] - x0 > 0.5

@@ -360,3 +360,68 @@ def test_single_world_and_launch_splitting(torch_mod, bench_model, oracle_lib):
     q = a.field("qpos").cpu().numpy()[0]
     assert min(np.abs(q - o.qpos).max(), np.abs(q - o64.qpos).max()) < 2e-3   # contact-rich, 660 steps
     assert np.isfinite(q).all()
+
+
+def test_reset_worlds_mask(torch_mod, bench_model):
+    """Per-world episode reset (nmf_reset_worlds): masked worlds go back to the keyframe with their clock at zero and
+    then follow the same trajectory as a freshly reset batch, bit for bit; unmasked worlds are not touched."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+
+    fly, world, _ = bench_model
+    sim = HIPSimulation(world, n_worlds=6, device=0)
+    ref = HIPSimulation(world, n_worlds=6, device=0)
+    for s in (sim, ref):
+        s.set_leg_adhesion_states(fly.name, np.ones((6, 6), dtype=np.float32))
+    sim.step(300)
+    before = {k: sim.field(k).clone() for k in ("qpos", "qvel", "qacc_warmstart", "time", "seg_xpos")}
+    mask = np.array([1, 0, 0, 1, 0, 1], dtype=bool)
+    sim.reset_worlds(mask)
+    on, off = torch.as_tensor(mask, device=sim.device), torch.as_tensor(~mask, device=sim.device)
+    for k in before:
+        assert torch.equal(sim.field(k)[off], before[k][off]), k
+        assert torch.equal(sim.field(k)[on], ref.field(k)[on]), k
+    assert float(sim.field("time")[0]) == 0.0 and abs(float(sim.field("time")[1]) - 0.03) < 1e-6
+    # adhesion controls are part of the keyframe reset; put them back on, then step both batches
+    sim.set_leg_adhesion_states(fly.name, np.ones((6, 6), dtype=np.float32))
+    sim.step(200); ref.step(200)
+    for k in ("qpos", "qvel", "time"):
+        assert torch.equal(sim.field(k)[on], ref.field(k)[on]), k
+    with pytest.raises(ValueError):
+        sim.reset_worlds(np.ones(5, dtype=bool))
+
+
+def test_cpg_adhesion_replay_parity(torch_mod, bench_model, oracle_lib):
+    """BASELINE config 5 control: a 48-column table (42 joint targets + 6 gait-driven adhesion controls) replayed inside
+    the kernel follows the oracle."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world, _ = bench_model
+    sim = HIPSimulation(world, n_worlds=4, device=0)
+    o, o32 = _oracles(oracle_lib, sim)
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    adhesion = (cpg.stance_bins(sim.model, fly), 20.0, 1.0)
+    table = cpg.targets(4, 2500, adhesion=adhesion)
+    tdev = cpg.targets(4, 2500, device=sim.device, adhesion=adhesion)
+    np.testing.assert_allclose(tdev.cpu().numpy()[..., :42], table[..., :42], atol=2e-6)
+    tdev = torch.as_tensor(table, device=sim.device)           # identical inputs for the comparison
+    ids = sim.replay_ids(fly.name, with_adhesion=True)
+    assert ids.numel() == 48
+    sim.set_leg_adhesion_states(fly.name, np.ones((4, 6), dtype=np.float32))
+    for orc in (o, o32):
+        orc.ctrl[42:] = 1.0
+        orc.step(300)
+    sim.step(300)
+    ids_np = ids.cpu().numpy()
+    for k in range(3):
+        sim.step_replay(tdev, ids, 100 * k, 100)
+        for orc in (o, o32):
+            orc.step_replay(table[2], ids_np, 100 * k, 100)
+        q = sim.field("qpos").cpu().numpy()[2]
+        assert np.abs(q - o.qpos).max() < 5e-5, f"after {300 + 100 * (k + 1)} steps"
+    c = sim.field("ctrl").cpu().numpy()
+    np.testing.assert_array_equal(c[2][ids_np], table[2, 299])
+    f = sim.get_actuator_forces(fly.name, "position").cpu().numpy()
+    assert np.isfinite(f).all()
