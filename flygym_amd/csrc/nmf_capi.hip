@@ -347,17 +347,34 @@ extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int ta
   return (double)ms / reps;
 }
 
-extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const uint8_t* pale_dev,
-                                   const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
-                                   float* out_dev, void* stream) {
+extern "C" int nmf_retina_plan(const int16_t* id_map_dev, int n_pixels, void* plan_dev, void* stream) {
+  if (!id_map_dev || !plan_dev) return fail("nmf_retina_plan: null buffer");
+  if (n_pixels <= 0 || n_pixels % 16) return fail("nmf_retina_plan: n_pixels must be a positive multiple of 16");
+  if (reinterpret_cast<uintptr_t>(plan_dev) & 15u) return fail("nmf_retina_plan: plan must be 16-byte aligned");
+  const int n_chunk = n_pixels / 16;
+  hipLaunchKernelGGL(nmf::nmf_retina_plan_kernel, dim3((unsigned)((n_chunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     id_map_dev, n_chunk, reinterpret_cast<nmf::u32x4*>(plan_dev));
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const void* plan_dev,
+                                   const uint8_t* pale_dev, const float* inv_norm_dev, int n_images, int n_pixels,
+                                   int n_ommatidia, float* out_dev, void* stream) {
   if (!images_dev || !id_map_dev || !pale_dev || !inv_norm_dev || !out_dev) return fail("nmf_retina_resample: null buffer");
   if (n_images <= 0) return 0;
   if (n_pixels <= 0 || n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia)
     return fail("nmf_retina_resample: need 0 < n_ommatidia <= 1024 and n_pixels > 0");
-  if ((reinterpret_cast<uintptr_t>(images_dev) | reinterpret_cast<uintptr_t>(id_map_dev)) & 15u || (n_pixels * 3) % 16)
-    return fail("nmf_retina_resample: images / id map must be 16-byte aligned and image size a multiple of 16 bytes");
-  hipLaunchKernelGGL(nmf::nmf_retina_kernel, dim3((unsigned)n_images), dim3(nmf::kRetinaThreads), 0, (hipStream_t)stream,
-                     images_dev, id_map_dev, pale_dev, inv_norm_dev, n_pixels, n_ommatidia, out_dev);
+  if ((reinterpret_cast<uintptr_t>(images_dev) | reinterpret_cast<uintptr_t>(id_map_dev) | reinterpret_cast<uintptr_t>(plan_dev)) & 15u ||
+      (n_pixels * 3) % 16)
+    return fail("nmf_retina_resample: images / id map / plan must be 16-byte aligned and image size a multiple of 16 bytes");
+  if (plan_dev && n_pixels % 1024 == 0)
+    hipLaunchKernelGGL(nmf::nmf_retina_stream_kernel, dim3((unsigned)n_images), dim3(nmf::kRetinaThreads), 0, (hipStream_t)stream,
+                       images_dev, id_map_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev), pale_dev, inv_norm_dev, n_pixels,
+                       n_ommatidia, out_dev);
+  else
+    hipLaunchKernelGGL(nmf::nmf_retina_kernel, dim3((unsigned)n_images), dim3(nmf::kRetinaThreads), 0, (hipStream_t)stream,
+                       images_dev, id_map_dev, pale_dev, inv_norm_dev, n_pixels, n_ommatidia, out_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }

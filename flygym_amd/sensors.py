@@ -93,8 +93,14 @@ class Retina:
         if self._dev is None or self._dev[0] != device:
             ids = self.id_map.ravel().astype(np.int64)
             typed = ids | (np.where(ids > 0, self.pale_mask[np.maximum(ids, 1) - 1], 0).astype(np.int64) << 15)
-            self._dev = (device, torch.as_tensor(typed.astype(np.uint16).view(np.int16), device=device),
-                         torch.as_tensor(self.pale_mask, device=device), torch.as_tensor(self.inv_norm, device=device))
+            id_dev = torch.as_tensor(typed.astype(np.uint16).view(np.int16), device=device)
+            plan = None
+            if typed.size % 16 == 0:      # run plan of the id map (streaming kernel); built once per device
+                plan = torch.empty((typed.size // 16, 4), dtype=torch.int32, device=device)
+                stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                _native.check(_native.lib().nmf_retina_plan(id_dev.data_ptr(), typed.size, plan.data_ptr(), stream))
+            self._dev = (device, id_dev, torch.as_tensor(self.pale_mask, device=device),
+                         torch.as_tensor(self.inv_norm, device=device), plan)
         return self._dev[1:]
 
     def raw_image_to_hex_pxls(self, images):
@@ -109,11 +115,12 @@ class Retina:
         images = images.contiguous()
         lead = tuple(images.shape[:-3])
         n = int(np.prod(lead)) if lead else 1
-        id_map, pale, inv_norm = self._device_constants(torch, images.device)
+        id_map, pale, inv_norm, plan = self._device_constants(torch, images.device)
         out = torch.empty(lead + (self.num_ommatidia, 2), dtype=torch.float32, device=images.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(images.device).cuda_stream)
         _native.check(_native.lib().nmf_retina_resample(
-            images.data_ptr(), id_map.data_ptr(), pale.data_ptr(), inv_norm.data_ptr(), n,
+            images.data_ptr(), id_map.data_ptr(), plan.data_ptr() if plan is not None else None, pale.data_ptr(),
+            inv_norm.data_ptr(), n,
             self.height * self.width, self.num_ommatidia, out.data_ptr(), stream))
         return out
 

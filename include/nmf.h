@@ -106,8 +106,12 @@ double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_ste
 /* Hex-ommatidia resample of raw eye images.  images[n_images][n_pixels][3] uint8 RGB; id_map[n_pixels] 16-bit:
  * bits 0..14 = 0 (no ommatidium) or k (ommatidium k-1), bit 15 = that ommatidium is pale; shared by all images;
  * pale[n_ommatidia] uint8 (1 = pale type, reads blue; 0 = yellow type, reads green); inv_norm[k] = 1 / (255 * pixels of ommatidium k);
- * out[n_images][n_ommatidia][2] float32 (channel 0 yellow, 1 pale).  Buffers 16-byte aligned. */
-int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const uint8_t* pale_dev,
+ * out[n_images][n_ommatidia][2] float32 (channel 0 yellow, 1 pale).  Buffers 16-byte aligned.
+ * plan: NULL, or the run plan of the id map written by nmf_retina_plan (n_pixels / 16 entries of 16 bytes): with a plan
+ * and n_pixels a multiple of 1024 the frames are streamed with fully coalesced loads; the results
+ * are identical either way (integer sums). */
+int nmf_retina_plan(const int16_t* id_map_dev, int n_pixels, void* plan_dev, void* stream);
+int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev,
                         const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
                         float* out_dev, void* stream);
 

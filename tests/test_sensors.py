@@ -61,6 +61,20 @@ def test_retina_hip_is_bit_exact():
     img = rng.integers(0, 256, size=(5, 1, 32, 3), dtype=np.uint8)
     got = small.raw_image_to_hex_pxls(torch.as_tensor(img, device="cuda:0")).cpu().numpy()
     np.testing.assert_array_equal(got, so.retina_resample(img, small.id_map, small.pale_mask, small.inv_norm))
+    # streaming kernel on a hostile map (2048 pixels, a multiple of 1024): runs of 1..9 pixels, so most 16-pixel chunks
+    # have more than three runs (per-pixel path) and the others exercise the three-run plan, background runs included
+    ids, k = [], 0
+    while len(ids) < 2048:
+        run = int(rng.integers(1, 10)) if k % 3 else int(rng.integers(8, 30))
+        ids += [int(rng.integers(0, 41))] * run
+        k += 1
+    id_map = np.array(ids[:2048], dtype=np.int16).reshape(32, 64)
+    id_map[0, :41] = np.arange(1, 42)[:41] % 41 + 0                      # every id 1..40 occurs at least once
+    id_map[0, :40] = np.arange(1, 41)
+    hostile = Retina(id_map=id_map, pale_mask=rng.integers(0, 2, 40))
+    img = rng.integers(0, 256, size=(7, 32, 64, 3), dtype=np.uint8)
+    got = hostile.raw_image_to_hex_pxls(torch.as_tensor(img, device="cuda:0")).cpu().numpy()
+    np.testing.assert_array_equal(got, so.retina_resample(img, hostile.id_map, hostile.pale_mask, hostile.inv_norm))
     with pytest.raises(ValueError):
         r.raw_image_to_hex_pxls(torch.zeros((2, 10, 10, 3), dtype=torch.uint8, device="cuda:0"))
 
