@@ -425,3 +425,43 @@ def test_cpg_adhesion_replay_parity(torch_mod, bench_model, oracle_lib):
     np.testing.assert_array_equal(c[2][ids_np], table[2, 299])
     f = sim.get_actuator_forces(fly.name, "position").cpu().numpy()
     assert np.isfinite(f).all()
+
+
+def test_step_and_setters_are_graph_capturable(torch_mod, bench_model):
+    """SURVEY §8(b) threading: setters and step are pure stream-ordered device work, so the reference's captured loop
+    {set_actuator_inputs, step} (time_gpu_simulation.py:137-146) can be a hipGraph.  Replaying the graph must give the
+    same states as the eager calls."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+
+    fly, world, _ = bench_model
+    n = 16
+    eager = HIPSimulation(world, n_worlds=n, device=0)
+    graphed = HIPSimulation(world, n_worlds=n, device=0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = eager.field("ctrl")[:, :42].clone()
+    targets = [base + 0.05 * torch.randn((n, 42), device="cuda", generator=g) for _ in range(6)]
+    adh = torch.ones((n, 6), device="cuda")
+    for sim in (eager, graphed):
+        sim.set_leg_adhesion_states(fly.name, adh)
+        sim.step(50)
+    for tg in targets:
+        eager.set_actuator_inputs(fly.name, "position", tg)
+        eager.step(5)
+    static_in = targets[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm the capture stream once, then rewind the state
+        graphed.set_actuator_inputs(fly.name, "position", static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        graphed.set_actuator_inputs(fly.name, "position", static_in)
+        graphed.step(5)
+    # the capture itself does not execute; state is still the post-warm-up one
+    for tg in targets:
+        static_in.copy_(tg)
+        graph.replay()
+    torch.cuda.synchronize()
+    for k in ("qpos", "qvel", "ctrl"):
+        assert torch.equal(eager.field(k), graphed.field(k)), k
