@@ -71,8 +71,10 @@ def lib():
             "nmf_scatter": (ci, [vp, ci, vp, ci, vp, vp]),
             "nmf_step_count": (ctypes.c_int64, [vp]),
             "nmf_time_launches": (ctypes.c_double, [vp, vp, ci, ci, vp, ci, ci, vp]),
+            "nmf_retina_plan_bytes": (ctypes.c_size_t, [ci]),
             "nmf_retina_plan": (ci, [vp, ci, vp, vp]),
             "nmf_retina_resample": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+            "nmf_eye_render": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
             "nmf_odor_intensity": (ci, [vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
         }
         for name, (res, args) in sig.items():

@@ -5,6 +5,7 @@
 // stepping path.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include "nmf.h"
 #include "nmf_step.hip"
 #include "nmf_sensors.hip"
+#include "nmf_eyes.hip"
 
 namespace {
 
@@ -347,6 +349,12 @@ extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int ta
   return (double)ms / reps;
 }
 
+extern "C" size_t nmf_retina_plan_bytes(int n_pixels) {
+  if (n_pixels <= 0 || n_pixels % 16) return 0;
+  const size_t n_chunk = (size_t)n_pixels / 16;
+  return n_chunk * 16 + ((n_chunk * 4 + 4 + 15) / 16) * 16;
+}
+
 extern "C" int nmf_retina_plan(const int16_t* id_map_dev, int n_pixels, void* plan_dev, void* stream) {
   if (!id_map_dev || !plan_dev) return fail("nmf_retina_plan: null buffer");
   if (n_pixels <= 0 || n_pixels % 16) return fail("nmf_retina_plan: n_pixels must be a positive multiple of 16");
@@ -354,6 +362,8 @@ extern "C" int nmf_retina_plan(const int16_t* id_map_dev, int n_pixels, void* pl
   const int n_chunk = n_pixels / 16;
   hipLaunchKernelGGL(nmf::nmf_retina_plan_kernel, dim3((unsigned)((n_chunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      id_map_dev, n_chunk, reinterpret_cast<nmf::u32x4*>(plan_dev));
+  hipLaunchKernelGGL(nmf::nmf_retina_active_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, id_map_dev, n_chunk,
+                     reinterpret_cast<int*>(static_cast<char*>(plan_dev) + (size_t)n_chunk * 16));
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -375,6 +385,51 @@ extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_
   else
     hipLaunchKernelGGL(nmf::nmf_retina_kernel, dim3((unsigned)n_images), dim3(nmf::kRetinaThreads), 0, (hipStream_t)stream,
                        images_dev, id_map_dev, pale_dev, inv_norm_dev, n_pixels, n_ommatidia, out_dev);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int16_t* id_map_dev,
+                              const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
+                              uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {
+  if (!b || !p) return fail("nmf_eye_render: null batch / params");
+  if (!id_map_dev || !plan_dev || !pale_dev || !inv_norm_dev) return fail("nmf_eye_render: id map, plan, pale and inv_norm are required");
+  if (!frames_out_dev && !omm_out_dev) return fail("nmf_eye_render: nothing to write");
+  if (p->height <= 0 || p->width <= 0 || (p->height * p->width) % 16) return fail("nmf_eye_render: height * width must be a positive multiple of 16");
+  if (n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia) return fail("nmf_eye_render: need 0 < n_ommatidia <= 1024");
+  if (p->n_spheres < 0 || p->n_spheres > nmf::kMaxSpheres || (p->n_spheres > 0 && !spheres_dev)) return fail("nmf_eye_render: bad sphere list");
+  if (!(p->checker_size > 0.f) || !(p->fov_deg > 0.f) || p->fov_deg > 360.f) return fail("nmf_eye_render: bad checker size / field of view");
+  const nmf_model* m = b->model;
+  if (b->dm.plane[0] != 0.f || b->dm.plane[1] != 0.f || b->dm.plane[2] != 1.f) return fail("nmf_eye_render: the ground plane must be z-up");
+  if ((reinterpret_cast<uintptr_t>(plan_dev) | reinterpret_cast<uintptr_t>(frames_out_dev)) & 15u)
+    return fail("nmf_eye_render: plan / frames must be 16-byte aligned");
+  nmf::EyeArgs A{};
+  A.height = p->height; A.width = p->width;
+  A.half_fov = 0.5f * p->fov_deg * 3.14159265358979323846f / 180.f;
+  for (int e = 0; e < 2; ++e) {
+    if (p->eye_seg[e] < 0 || p->eye_seg[e] >= m->nseg) return fail("nmf_eye_render: eye segment out of range");
+    A.eye_seg[e] = p->eye_seg[e];
+    for (int i = 0; i < 3; ++i) A.rel_pos[e][i] = p->rel_pos[e][i];
+    double w = p->rel_quat[e][0], x = p->rel_quat[e][1], y = p->rel_quat[e][2], z = p->rel_quat[e][3];
+    const double n = std::sqrt(w * w + x * x + y * y + z * z);
+    if (!(n > 0.0)) return fail("nmf_eye_render: zero camera quaternion");
+    w /= n; x /= n; y /= n; z /= n;
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 9; ++i) A.rel_mat[e][i] = (float)R[i];
+  }
+  A.checker_size = p->checker_size; A.ground_z = b->dm.plane[3];
+  A.n_spheres = p->n_spheres; A.sphere_stride = p->spheres_per_world ? 4 * p->n_spheres : 0;
+  for (int c = 0; c < 4; ++c) {
+    A.rgb[0][c] = c < 3 ? p->sky_rgb[c] : 0; A.rgb[1][c] = c < 3 ? p->ground_rgb[0][c] : 0; A.rgb[2][c] = c < 3 ? p->ground_rgb[1][c] : 0;
+    for (int s = 0; s < nmf::kMaxSpheres; ++s) A.rgb[3 + s][c] = c < 3 ? p->sphere_rgb[s][c] : 0;
+  }
+  hipLaunchKernelGGL(nmf::nmf_eye_kernel, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A,
+                     b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,
+                     reinterpret_cast<const nmf::u32x4*>(plan_dev),
+                     reinterpret_cast<const int*>(static_cast<const char*>(plan_dev) + (size_t)(p->height * p->width / 16) * 16),
+                     id_map_dev, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -126,6 +126,33 @@ __global__ void nmf_retina_plan_kernel(const int16_t* __restrict__ id_map, int n
   plan[ch] = u32x4{ida | (idb << 16), idc | ((bad ? 1u : 0u) << 16), palebits, m1 | (m2 << 16)};
 }
 
+// The chunks that touch at least one ommatidium, in ascending order, after the plan entries:
+// plan blob = [n_chunk x 16 B run plan][n_chunk x int32 active chunk indices][int32 count, padded to 16 B].
+// One workgroup; order-preserving compaction by ballot prefix sums.
+__global__ void __launch_bounds__(256) nmf_retina_active_kernel(const int16_t* __restrict__ id_map, int n_chunk, int* __restrict__ list) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n_chunk; c0 += 256) {
+    const int ch = c0 + threadIdx.x;
+    bool on = false;
+    if (ch < n_chunk)
+      for (int k = 0; k < 16; ++k) on |= (id_map[(size_t)ch * 16 + k] & 0x7fff) != 0;
+    const unsigned long long bal = __ballot(on);
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (ln == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < wv; ++q) off += wave_cnt[q];
+    if (on) list[off + __popcll(bal & ((1ull << ln) - 1ull))] = ch;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) list[n_chunk] = base;
+}
+
 // 4 bits -> 4 bytes of 0/1
 __device__ __forceinline__ unsigned int nib_to_bytes(unsigned int nib) { return (nib * 0x00204081u) & 0x01010101u; }
 

@@ -96,7 +96,7 @@ class Retina:
             id_dev = torch.as_tensor(typed.astype(np.uint16).view(np.int16), device=device)
             plan = None
             if typed.size % 16 == 0:      # run plan of the id map (streaming kernel); built once per device
-                plan = torch.empty((typed.size // 16, 4), dtype=torch.int32, device=device)
+                plan = torch.empty(_native.lib().nmf_retina_plan_bytes(typed.size), dtype=torch.uint8, device=device)
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
                 _native.check(_native.lib().nmf_retina_plan(id_dev.data_ptr(), typed.size, plan.data_ptr(), stream))
             self._dev = (device, id_dev, torch.as_tensor(self.pale_mask, device=device),

@@ -107,13 +107,40 @@ double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_ste
  * bits 0..14 = 0 (no ommatidium) or k (ommatidium k-1), bit 15 = that ommatidium is pale; shared by all images;
  * pale[n_ommatidia] uint8 (1 = pale type, reads blue; 0 = yellow type, reads green); inv_norm[k] = 1 / (255 * pixels of ommatidium k);
  * out[n_images][n_ommatidia][2] float32 (channel 0 yellow, 1 pale).  Buffers 16-byte aligned.
- * plan: NULL, or the run plan of the id map written by nmf_retina_plan (n_pixels / 16 entries of 16 bytes): with a plan
+ * plan: NULL, or the run plan of the id map written by nmf_retina_plan into a buffer of nmf_retina_plan_bytes(n_pixels)
+ * bytes (16 bytes per 16-pixel chunk, then the list of chunks that touch an ommatidium): with a plan
  * and n_pixels a multiple of 1024 the frames are streamed with fully coalesced loads; the results
  * are identical either way (integer sums). */
+size_t nmf_retina_plan_bytes(int n_pixels);
 int nmf_retina_plan(const int16_t* id_map_dev, int n_pixels, void* plan_dev, void* stream);
 int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev,
                         const float* inv_norm_dev, int n_images, int n_pixels, int n_ommatidia,
                         float* out_dev, void* stream);
+
+/* Compound-eye renderer fused with the ommatidia resample (no reference counterpart in this snapshot: the eye cameras,
+ * like the resample, survive only as constants in src/flygym/assets/model/legacy/flygym1_config.yaml:141-173; the
+ * reference's image path is rendering.py / warp/rendering.py -> MuJoCo / MJWarp renderers).  Build-defined (DESIGN.md
+ * section 7): each eye is an equidistant-fisheye camera attached to a body segment; the scene is the ground plane with a
+ * checker texture, a uniform sky and up to 8 spheres.  Reads the segment poses of the last nmf_step / nmf_reset. */
+typedef struct nmf_eye_params {
+  int32_t height, width;        /* raw frame size in pixels; height * width a multiple of 16                           */
+  float fov_deg;                /* full angle seen along the vertical image axis (ray angle is proportional to radius)   */
+  int32_t eye_seg[2];           /* parent segment of each eye camera (index into the batch's segment order)             */
+  float rel_pos[2][3];          /* camera position in the parent segment frame                                           */
+  float rel_quat[2][4];         /* camera orientation in the parent frame (w,x,y,z); the camera looks along -z, +y is up */
+  float checker_size;           /* side of a ground checker square                                                       */
+  uint8_t sky_rgb[4], ground_rgb[2][4], sphere_rgb[8][4];   /* colours (4th byte unused)                                */
+  int32_t n_spheres;            /* 0..8                                                                                  */
+  int32_t spheres_per_world;    /* 1: spheres_dev is [n_worlds][n_spheres][4]; 0: [n_spheres][4] shared by all worlds   */
+} nmf_eye_params;
+
+/* spheres_dev: (x, y, z, radius) per sphere, float32.  id_map / plan / pale / inv_norm as for nmf_retina_resample (the
+ * plan is required).  frames_out_dev: NULL or uint8 [n_worlds][2][height*width][3] raw eye frames;
+ * omm_out_dev: NULL or float32 [n_worlds][2][n_ommatidia][2].  Rendering frames and resampling them with
+ * nmf_retina_resample gives bit-identical ommatidia readings (integer sums). */
+int nmf_eye_render(nmf_batch* batch, const nmf_eye_params* params, const float* spheres_dev,
+                   const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev,
+                   int n_ommatidia, uint8_t* frames_out_dev, float* omm_out_dev, void* stream);
 
 /* Odor intensity at n_sensors points rigidly attached to named segments (sensor_seg = index into the
  * batch's segment order, sensor_rel = offset in the segment frame): out[w][d][k] = sum_s peak[s][d] / dist^2.

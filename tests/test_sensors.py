@@ -103,3 +103,86 @@ def test_odor_sensors_match_numpy(bench_model):
     assert got.shape == (5, 2, 4)
     np.testing.assert_allclose(got, want, rtol=2e-5)                   # float32 vs float64, tolerance 2e-5
     assert np.abs(got[0] - got[1]).max() > 0                           # worlds moved apart
+
+
+def test_eye_render_oracle_known_answers():
+    """The renderer's specification (oracle/sensors_oracle.py::render_eye_frames) against geometry worked by hand."""
+    import sensors_oracle as so
+
+    H, W, fov, h = 512, 450, 157.0, 2.0
+    sky, ground = (140, 178, 230), ((77, 77, 77), (102, 102, 102))
+    down = np.eye(3)                                                    # camera axes = world axes: looks along -z (down)
+    fr = so.render_eye_frames((0.5, 0.5, h), down, H, W, fov, 4.0, 0.0, sky, ground)
+    assert fr.shape == (H, W, 3) and fr.dtype == np.uint8
+    # straight below (0.5, 0.5): square (0, 0) -> parity 0 -> colour A; the image centre is between 4 pixels
+    assert (fr[255:257, 224:226] == ground[0]).all()
+    # along the middle row a pixel at rho sees the ground at x = 0.5 + h tan(rho * fov / 2): check a few columns
+    for col in (260, 300, 330, 360, 400):
+        rho = (col + 0.5 - W / 2) * 2 / H
+        x = 0.5 + h * np.tan(rho * np.radians(fov / 2))
+        want = ground[(int(np.floor(x / 4.0)) + 0) & 1]
+        if abs(x / 4.0 - round(x / 4.0)) > 1e-3:                         # not on a checker edge
+            assert tuple(fr[256, col]) == want, col
+    # the horizon is at rho = 90 / 78.5 > 1 along the axes but inside the corners: sky only there
+    rho_corner = np.hypot(W / H, 1.0)
+    assert rho_corner * fov / 2 > 90
+    assert tuple(fr[0, 0]) == sky and tuple(fr[0, W // 2]) != sky
+    # a sphere right below: angular radius asin(r / d) -> a disc of that many pixels
+    fr2 = so.render_eye_frames((0.5, 0.5, h), down, H, W, fov, 4.0, 0.0, sky, ground, [(0.5, 0.5, 1.0, 0.4)], [(10, 20, 30)])
+    n_sphere = int((fr2 == (10, 20, 30)).all(axis=-1).sum())
+    r_pix = np.arcsin(0.4 / 1.0) / np.radians(fov / 2) * H / 2
+    assert abs(n_sphere - np.pi * r_pix ** 2) < 0.03 * np.pi * r_pix ** 2
+    # the legacy eye orientations, read as extrinsic x-y-z rotations, look forward-sideways with +z up
+    L = so.euler_xyz_extrinsic_to_mat((1.57, 0.0, -0.47))
+    Rr = so.euler_xyz_extrinsic_to_mat((-1.57, 3.14, 0.47))
+    np.testing.assert_allclose(L @ [0, 0, -1], [np.sin(0.47), np.cos(0.47), 0], atol=2e-3)
+    np.testing.assert_allclose(Rr @ [0, 0, -1], [np.sin(0.47), -np.cos(0.47), 0], atol=2e-3)
+    assert (L @ [0, 1, 0])[2] > 0.999 and (Rr @ [0, 1, 0])[2] > 0.999
+
+
+@pytest.mark.gpu
+def test_eye_renderer_matches_oracle_and_resample(bench_model):
+    """HIP eye renderer: raw frames vs the numpy specification (ray-exact up to float32 rounding at material edges),
+    and the fused ommatidia readings vs resampling those frames (bit-exact: integer sums)."""
+    import torch
+    import sensors_oracle as so
+    from flygym_amd import HIPSimulation
+    from flygym_amd.vision import EyeRenderer, Scene
+
+    fly, world, _ = bench_model
+    n = 3
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    sim.field("qvel")[:, :6] = torch.as_tensor(np.random.default_rng(5).normal(0, 20, (n, 6)), dtype=torch.float32, device=sim.device)
+    sim.step(60)                                                       # three different head poses
+    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0), (5.0, -6.0, 0.8, 0.8)], sphere_rgb=[(0.05, 0.05, 0.05), (0.9, 0.2, 0.1)])
+    eyes = EyeRenderer(sim, fly.name, scene)
+    frames, omm = eyes.render_frames(with_readings=True)
+    assert frames.shape == (n, 2, 512, 450, 3) and omm.shape == (n, 2, 721, 2)
+    # fused readings == resample of the rendered frames, and == the readings-only call
+    assert torch.equal(omm, eyes.retina.raw_image_to_hex_pxls(frames))
+    assert torch.equal(omm, eyes.render())
+    names = [s.name for s in fly.get_bodysegs_order()]
+    xpos = sim.field("seg_xpos").cpu().numpy().reshape(n, 69, 3).astype(np.float64)
+    xquat = sim.field("seg_xquat").cpu().numpy().reshape(n, 69, 4).astype(np.float64)
+    fr = frames.cpu().numpy()
+    for w in range(n):
+        for e, (seg, pos, quat) in enumerate(eyes.cameras):
+            Rs = so.quat_to_mat(xquat[w, names.index(seg)])
+            cam = xpos[w, names.index(seg)] + Rs @ pos
+            want = so.render_eye_frames(cam, Rs @ so.quat_to_mat(quat), 512, 450, 157.0, 4.0, 0.0, scene.sky_rgb, scene.ground_rgb,
+                                        scene.spheres, scene.sphere_rgb)
+            diff = (fr[w, e] != want).any(axis=-1).mean()
+            assert diff < 2e-3, f"world {w} eye {e}: {diff:.2e} of the pixels differ"    # float32 rounding at edges only
+            got = omm[w, e].cpu().numpy()
+            ref = so.retina_resample(want, eyes.retina.id_map, eyes.retina.pale_mask, eyes.retina.inv_norm)
+            assert np.abs(got - ref).max() < 5e-3
+    assert (fr[0, 0] != fr[0, 1]).any() and (fr[0] != fr[1]).any()       # eyes and worlds see different things
+    assert ((fr == np.array(scene.sphere_rgb[0], dtype=np.uint8)).all(axis=-1)).any()   # the dark sphere is in view somewhere
+    # per-world spheres
+    per_world = np.repeat(scene.spheres[None], n, axis=0).copy()
+    per_world[1, 0, :3] = (6.0, 40.0, 1.5)
+    eyes.set_spheres(per_world)
+    fr2 = eyes.render_frames().cpu().numpy()
+    assert np.array_equal(fr2[0], fr[0]) and not np.array_equal(fr2[1], fr[1])
+    with pytest.raises(ValueError):
+        eyes.set_spheres(np.zeros((5, 4)))
