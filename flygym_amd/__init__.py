@@ -7,7 +7,7 @@ hand-written HIP kernels for gfx950 behind the reference's Python surface.
 from . import anatomy, compose
 from .models import make_model
 
-__all__ = ["anatomy", "compose", "make_model", "HIPSimulation"]
+__all__ = ["anatomy", "compose", "make_model", "HIPSimulation", "Simulation"]
 __version__ = "0.1.0"
 
 
@@ -16,4 +16,8 @@ def __getattr__(name):
         from .simulation import HIPSimulation
 
         return HIPSimulation
+    if name == "Simulation":
+        from .simulation import Simulation
+
+        return Simulation
     raise AttributeError(name)

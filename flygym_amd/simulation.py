@@ -294,3 +294,97 @@ def _tensor_from_ptr(torch, ptr: int, shape, device):
     }
     t = torch.as_tensor(h, device=device)
     return t[:n].reshape(shape)
+
+
+class Simulation:
+    """Single-world simulation with the reference's CPU ``Simulation`` surface (``src/flygym/simulation.py:16-480``):
+    unbatched numpy in, unbatched float64 numpy out — the physics still runs in the HIP engine (one wavefront).
+
+    For user loops written against ``flygym.Simulation``; throughput work belongs on :class:`HIPSimulation`
+    (a single world is launch-latency bound: ≈ 0.1 ms per ``step()``; use ``step(n)`` to fuse steps).  Differences:
+    no ``mj_model`` / ``mj_data`` (the engine arrays are reachable through ``batch.field(name)``), no noslip
+    post-pass (as on the reference's batched path), rendering handed off.
+    """
+
+    def __init__(self, world: BaseWorld, device: int | None = None) -> None:
+        self.batch = HIPSimulation(world, 1, device=device)
+        self.world = world
+        self.renderer = None
+
+    # -- stepping
+    def reset(self) -> None:
+        self.batch.reset()
+
+    def step(self, n_steps: int = 1) -> None:
+        self.batch.step(n_steps)
+
+    def step_with_profile(self) -> None:
+        self.batch.step_with_profile()
+
+    def warmup(self, duration_s: float = 0.05) -> None:
+        self.batch.warmup(duration_s)
+
+    # -- state (fly order, as the reference)
+    @staticmethod
+    def _np(t):
+        return t[0].cpu().numpy().astype(np.float64)
+
+    def get_joint_angles(self, fly_name: str) -> np.ndarray:
+        return self._np(self.batch.get_joint_angles(fly_name))
+
+    def get_joint_velocities(self, fly_name: str) -> np.ndarray:
+        return self._np(self.batch.get_joint_velocities(fly_name))
+
+    def get_body_positions(self, fly_name: str) -> np.ndarray:
+        return self._np(self.batch.get_body_positions(fly_name))
+
+    def get_body_rotations(self, fly_name: str) -> np.ndarray:
+        return self._np(self.batch.get_body_rotations(fly_name))
+
+    def get_site_positions(self, fly_name: str) -> np.ndarray:
+        return self._np(self.batch.get_site_positions(fly_name))
+
+    def get_actuator_forces(self, fly_name: str, actuator_type) -> np.ndarray:
+        return self._np(self.batch.get_actuator_forces(fly_name, actuator_type))
+
+    def get_ground_contact_info(self, fly_name: str):
+        """(active (6,), force (6, 3), torque, pos, normal, tangent) as in ``simulation.py:210-243``."""
+        return tuple(self._np(x) for x in self.batch.get_ground_contact_info(fly_name))
+
+    # -- controls
+    def set_actuator_inputs(self, fly_name: str, actuator_type, inputs) -> None:
+        ids = self.batch._ids_by_fly[fly_name]["actuators"][ActuatorType(actuator_type)]
+        if len(inputs) != int(ids.numel()):
+            raise ValueError(
+                f"Expected {int(ids.numel())} inputs for actuator type '{ActuatorType(actuator_type).name}', but got {len(inputs)}"
+            )
+        self.batch.set_actuator_inputs(fly_name, actuator_type, np.asarray(inputs, dtype=np.float32)[None, :])
+
+    def set_leg_adhesion_states(self, fly_name: str, leg_to_adhesion_state) -> None:
+        ids = self.batch._ids_by_fly[fly_name]["adhesion"]
+        if len(leg_to_adhesion_state) != int(ids.numel()):
+            raise ValueError(
+                f"Unexpected number of adhesion states: expected {int(ids.numel())}, got {len(leg_to_adhesion_state)}"
+            )
+        self.batch.set_leg_adhesion_states(fly_name, np.asarray(leg_to_adhesion_state, dtype=np.float32)[None, :])
+
+    # -- rendering is handed off, as on HIPSimulation
+    def set_renderer(self, *args, **kwargs):
+        return self.batch.set_renderer(*args, **kwargs)
+
+    def render_as_needed(self) -> bool:
+        return self.batch.render_as_needed()
+
+    def render_as_needed_with_profile(self) -> bool:
+        return self.batch.render_as_needed()
+
+    def print_performance_report(self) -> None:
+        self.batch.print_performance_report()
+
+    @property
+    def time(self) -> float:
+        return self.batch.time
+
+    @property
+    def timestep(self) -> float:
+        return self.batch.timestep

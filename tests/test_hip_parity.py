@@ -465,3 +465,43 @@ def test_step_and_setters_are_graph_capturable(torch_mod, bench_model):
     torch.cuda.synchronize()
     for k in ("qpos", "qvel", "ctrl"):
         assert torch.equal(eager.field(k), graphed.field(k)), k
+
+
+def test_single_world_simulation_mirrors_the_cpu_class(torch_mod, bench_model, oracle_lib):
+    """flygym_amd.Simulation: the reference's CPU ``Simulation`` surface (unbatched numpy) over the HIP engine —
+    the reference's own invariants (tests/core/test_simulation.py: time advance, unit quaternions, zero velocity at
+    reset, wrong-length errors) plus parity of a short driven rollout with the oracle (BASELINE config 1)."""
+    from flygym_amd import Simulation
+    from flygym_amd.replay import ReplayTargetData
+
+    fly, world, _ = bench_model
+    sim = Simulation(world, device=0)
+    assert sim.time == 0.0 and abs(sim.timestep - 1e-4) < 1e-12
+    q0 = sim.get_joint_angles(fly.name)
+    assert q0.shape == (66,) and q0.dtype == np.float64
+    assert sim.get_joint_velocities(fly.name).shape == (66,) and not sim.get_joint_velocities(fly.name).any()
+    assert sim.get_body_positions(fly.name).shape == (69, 3)
+    quat = sim.get_body_rotations(fly.name)
+    assert quat.shape == (69, 4) and np.allclose(np.linalg.norm(quat, axis=1), 1.0, atol=1e-5)
+    assert sim.get_actuator_forces(fly.name, "position").shape == (42,)
+    order = fly.get_actuated_jointdofs_order("position")
+    targets = ReplayTargetData(sim.timestep, order).make_target_angles_all_worlds(1, 200)[0]
+    o = oracle_lib.Oracle(sim.batch.model.to_blob(), "f64")
+    sim.set_leg_adhesion_states(fly.name, np.ones(6))
+    o.ctrl[42:] = 1.0
+    sim.warmup(); o.step(500)
+    assert abs(sim.time - 0.05) < 1e-6
+    for k in range(200):
+        sim.set_actuator_inputs(fly.name, "position", targets[k])
+        sim.step()
+    o.step_replay(targets, np.arange(42), 0, 200)
+    assert np.abs(sim.batch.field("qpos")[0].cpu().numpy() - o.qpos).max() < 5e-5
+    active, force, torque, pos, normal, tangent = sim.get_ground_contact_info(fly.name)
+    assert active.shape == (6,) and force.shape == (6, 3) and tangent.shape == (6, 3)
+    assert active.sum() >= 3 and force[:, 2].sum() > 0                     # standing on at least a tripod
+    with pytest.raises(ValueError, match="Expected 42 inputs"):
+        sim.set_actuator_inputs(fly.name, "position", np.zeros(41))
+    with pytest.raises(ValueError, match="Unexpected number of adhesion states"):
+        sim.set_leg_adhesion_states(fly.name, np.ones(5))
+    sim.reset()
+    assert sim.time == 0.0 and np.allclose(sim.get_joint_angles(fly.name), q0)
