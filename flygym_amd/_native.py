@@ -29,11 +29,14 @@ class NativeError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_device.h", INCLUDE / "nmf.h"]
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_device.h",
+            INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
+    # -fno-slp-vectorize: the SLP vectoriser packs the 6-vector arithmetic into v_pk_* pairs and pays for it in v_mov
+    # shuffles and register pressure (12 spilled VGPRs); scalar code is 9 % faster on the step kernel
     cmd = [
-        "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
         f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(LIB_PATH),
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)
