@@ -5,7 +5,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 lib_path = ROOT / "flygym_amd" / "libnmf_hip_aba.so"
 if "--build" in sys.argv or not lib_path.exists():
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{ROOT/'flygym_amd/csrc'}",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{ROOT/'flygym_amd/csrc'}",
                     "-x", "hip", str(ROOT / "scripts/aba_microbench.hip"), "-o", str(lib_path)], check=True)
     if "--build" in sys.argv: sys.exit(0)
 import numpy as np, torch
