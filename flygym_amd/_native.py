@@ -17,7 +17,7 @@ INCLUDE = PKG.parent / "include"
 
 FIELDS = dict(
     qpos=0, qvel=1, ctrl=2, qacc_warmstart=3, seg_xpos=4, seg_xquat=5, site_xpos=6,
-    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11,
+    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12,
 )
 
 _lib = None

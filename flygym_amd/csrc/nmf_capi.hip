@@ -65,6 +65,9 @@ struct nmf_batch {
   float* fields[NMF_FIELD_COUNT] = {};
   int widths[NMF_FIELD_COUNT] = {};
   int64_t steps = 0;
+  int* order_buf = nullptr;      // block -> world order of the next stepping launch (see nmf_order_kernel)
+  nmf::SchedState* sched_buf = nullptr;
+  int resident_waves = 0;        // step-kernel waves the device holds at once
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -161,6 +164,12 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
+  // more worlds than resident waves: the launch runs in rounds; start the costliest worlds first
+  b->st.order = nullptr; b->st.sched = nullptr;
+  if (mode == 0 && b->order_buf && b->sched_buf && b->n_worlds > b->resident_waves) {
+    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps);
+    b->st.order = b->order_buf; b->st.sched = b->sched_buf;
+  }
   const bool weld = b->dm.weld_active != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode)
   if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
@@ -244,6 +253,21 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   rc |= alloc_field(b, NMF_TIME, 1, &st.time);
   rc |= alloc_field(b, NMF_STATS, 4, &st.stats);
   rc |= alloc_field(b, NMF_QACC, model->nv, &st.qacc);
+  rc |= alloc_field(b, NMF_COST, 1, &st.cost);
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(int) * (size_t)n_worlds) == hipSuccess) { b->allocs.push_back(p); b->order_buf = (int*)p; }
+    else rc |= fail("nmf_batch_create: out of device memory");
+    p = nullptr;
+    if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
+      (void)hipMemset(p, 0, sizeof(nmf::SchedState));
+      b->allocs.push_back(p); b->sched_buf = (nmf::SchedState*)p;
+    } else rc |= fail("nmf_batch_create: out of device memory");
+    st.sched = nullptr;
+    st.order = nullptr;
+    hipDeviceProp_t prop;
+    b->resident_waves = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 8 : 2048;   // 2 waves x 4 SIMDs per CU
+  }
   if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
     std::string keep = g_err.empty() ? std::string("nmf_batch_create: device initialisation failed") : g_err;
     nmf_batch_destroy(b);

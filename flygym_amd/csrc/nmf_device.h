@@ -78,6 +78,16 @@ struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
       *sensordata, *time, *stats, *qacc;
+  float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
+  const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
+  struct SchedState* sched;   // launch-duration bookkeeping of the block-order policy (nullptr: off)
+};
+
+// Device-resident state of the block-order policy (see nmf_order_kernel)
+struct SchedState {
+  unsigned long long t_first, t_last;   // earliest block start / latest block end of the last stepping launch (s_memrealtime)
+  float ema[2];                          // smoothed launch duration per physics step, per policy (0 in-order, 1 costliest first)
+  int last_policy, launches, last_steps, pad;
 };
 
 struct ReplayArgs {

@@ -39,7 +39,8 @@ enum nmf_field {
   NMF_TIME = 9,         /* [1]                                                                 */
   NMF_STATS = 10,       /* [4]       ncon, solver iterations, overflow flag, nefc (as floats)  */
   NMF_QACC = 11,        /* [nv]                                                                */
-  NMF_FIELD_COUNT = 12
+  NMF_COST = 12,        /* [1]       shader cycles the world took in the last stepping launch (load metric) */
+  NMF_FIELD_COUNT = 13
 };
 
 /* Text of the last error raised on the calling thread ("" if none). */
