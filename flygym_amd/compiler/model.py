@@ -403,7 +403,14 @@ def compile_world(world) -> CompiledModel:
         else:
             hv = (T_mat @ md.hull_vertices.T).T + T_pos
             g_type.append(GEOM_HULL)
-            g_p0.append(np.zeros(3)); g_p1.append(np.zeros(3)); g_rad.append(0.0)
+            # bounding cylinder of the hull (broad phase only; the fields are unused for hulls otherwise): axis = first
+            # principal direction, ends at the extreme projections, radius = largest distance from the axis, inflated a
+            # little so the bound stays conservative in float32
+            cen = hv.mean(axis=0)
+            ax = np.linalg.svd(hv - cen, full_matrices=False)[2][0]
+            tpar = (hv - cen) @ ax
+            rad = np.linalg.norm((hv - cen) - np.outer(tpar, ax), axis=1).max()
+            g_p0.append(cen + tpar.min() * ax); g_p1.append(cen + tpar.max() * ax); g_rad.append(float(rad * (1 + 1e-4) + 1e-6))
             g_hadr.append(hadr); g_hnum.append(len(hv))
             hull_chunks.append(hv)
             hadr += len(hv)

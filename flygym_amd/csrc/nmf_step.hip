@@ -288,10 +288,13 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * lane]));
     float dc = dot(n, cw) + dot(n, xp) - pd;
     near = dc - m.geom_bsphere[4 * lane + 3] - m.terrain[4] <= g_margin;
+    const float rad = m.geom_radius[lane];
+    const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * lane])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * lane])) + xp;
+    float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
+    // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's
+    // reach but above its own thickness needs no vertex scan
+    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - m.terrain[4] <= g_margin;
     if (near && g_type == GEOM_CAPSULE) {
-      const float rad = m.geom_radius[lane];
-      const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * lane])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * lane])) + xp;
-      float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
       if (m.terrain_type) { d0 -= terrain_height(m, p0.x, p0.y); d1 -= terrain_height(m, p1.x, p1.y); }
       const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
       if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
