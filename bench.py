@@ -208,8 +208,11 @@ def main():
     if args.warmup > 0:
         sim.step(args.warmup)   # reference: sim.warmup() = 500 steps at the neutral targets
 
-    obs_local = torch.empty((n_local, OBS_DIM), dtype=torch.float32, device=sim.device)
-    obs_all = torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) if use_dist else None
+    # observation gather: double-buffered so that the RCCL all-gather of tick k runs on RCCL's stream while the
+    # stepping kernel of tick k + 1 already runs on the compute stream (the only exchange of the path)
+    obs_local = [torch.empty((n_local, OBS_DIM), dtype=torch.float32, device=sim.device) for _ in range(2)]
+    obs_all = [torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) for _ in range(2)] if use_dist else None
+    pending = [None, None]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
@@ -222,11 +225,15 @@ def main():
         if odor is not None:
             odor.get_odor_intensities()
         if use_dist:
-            obs_local[:, 0:66] = sim.field("qpos")[:, 7:]
-            obs_local[:, 66:132] = sim.field("qvel")[:, 6:]
-            obs_local[:, 132:174] = sim.field("actuator_force")[:, :42]
-            obs_local[:, 174:270] = sim.field("sensordata")
-            dist.all_gather_into_tensor(obs_all, obs_local)
+            slot = k & 1
+            if pending[slot] is not None:
+                pending[slot].wait()          # the gather that last used this buffer pair (two ticks ago)
+            ol = obs_local[slot]
+            ol[:, 0:66] = sim.field("qpos")[:, 7:]
+            ol[:, 66:132] = sim.field("qvel")[:, 6:]
+            ol[:, 132:174] = sim.field("actuator_force")[:, :42]
+            ol[:, 174:270] = sim.field("sensordata")
+            pending[slot] = dist.all_gather_into_tensor(obs_all[slot], ol, async_op=True)
 
     # untimed: one tick to settle allocator / RCCL channels
     control_tick(0)
@@ -237,6 +244,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(n_launches):
         control_tick(spl * (k + 1), k)
+    for w in pending:
+        if w is not None:
+            w.wait()                          # every gather is inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -304,6 +314,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio buffers: push it out first
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
 
 
