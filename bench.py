@@ -269,13 +269,14 @@ def main():
         achieved = BYTES_PER_ENV_STEP * n_local * spl / (ms * 1e-3) / 1e9
         # HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
         # --pmc passes of this very command (profiles/hbm_traffic.json, written by scripts/summarize_profile.py)
-        traffic = None
+        traffic = issue = None
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             rec = json.loads(tfile.read_text())
             if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch"), rec.get("control")) == (n_local, spl, args.workload) \
                     and args.terrain == "flat" and not args.odor and not args.cpg_adhesion:
                 traffic = rec["traffic_bytes_per_launch"]
+                issue = rec.get("issue") or None
         out = {
             "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
@@ -300,7 +301,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>, false>", "kernel_ms_per_launch": ms,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                "note": "the step is VALU/LDS-latency bound by construction (state crosses HBM once per launch); "
+                # instruction-issue side of the same kernel, from the SQ counters of the committed profile (profiles/*_summary.md)
+                "issue": issue,
+                "note": "the step is VALU-issue bound by construction (state crosses HBM once per launch); "
                         "see DESIGN.md for the instruction-side analysis",
             },
         }

@@ -78,6 +78,7 @@ def lib():
             "nmf_retina_plan_bytes": (ctypes.c_size_t, [ci]),
             "nmf_retina_plan": (ci, [vp, ci, vp, vp]),
             "nmf_retina_resample": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+            "nmf_eye_params_size": (ctypes.c_size_t, []),
             "nmf_eye_render": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
             "nmf_odor_intensity": (ci, [vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
         }

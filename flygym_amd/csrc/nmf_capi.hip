@@ -413,6 +413,8 @@ extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_
   return 0;
 }
 
+extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
+
 extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int16_t* id_map_dev,
                               const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
                               uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {

@@ -135,6 +135,9 @@ typedef struct nmf_eye_params {
   int32_t spheres_per_world;    /* 1: spheres_dev is [n_worlds][n_spheres][4]; 0: [n_spheres][4] shared by all worlds   */
 } nmf_eye_params;
 
+/* sizeof(nmf_eye_params) as this library was compiled: lets a foreign-language binding verify its struct layout. */
+size_t nmf_eye_params_size(void);
+
 /* spheres_dev: (x, y, z, radius) per sphere, float32.  id_map / plan / pale / inv_norm as for nmf_retina_resample (the
  * plan is required).  frames_out_dev: NULL or uint8 [n_worlds][2][height*width][3] raw eye frames;
  * omm_out_dev: NULL or float32 [n_worlds][2][n_ommatidia][2].  Rendering frames and resampling them with

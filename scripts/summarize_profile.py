@@ -96,9 +96,19 @@ if sq:
 (dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
 (dst / f"{tag}_bench.json").write_text(json.dumps(b, indent=1) + "\n")
 if traffic is not None:
+    env_steps = b["config"]["worlds_per_gpu"] * b["config"]["steps_per_launch"]
+    issue = {}
+    if sq.get("SQ_WAVE_CYCLES"):
+        issue = {"valu_insts_per_env_step": sq.get("SQ_INSTS_VALU", 0.0) / env_steps,
+                 "salu_insts_per_env_step": sq.get("SQ_INSTS_SALU", 0.0) / env_steps,
+                 "lds_insts_per_env_step": sq.get("SQ_INSTS_LDS", 0.0) / env_steps,
+                 # a wave issues VALU in this fraction of its cycles; two waves share a SIMD
+                 "valu_active_per_wave": sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_WAVE_CYCLES"],
+                 "valu_busy_per_simd": 2.0 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_WAVE_CYCLES"],
+                 "wait_any_per_wave": sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]}
     (dst / "hbm_traffic.json").write_text(json.dumps({
         "profile": tag, "traffic_bytes_per_launch": traffic, "worlds_per_gpu": b["config"]["worlds_per_gpu"],
-        "steps_per_launch": b["config"]["steps_per_launch"], "control": b["config"].get("control"),
+        "steps_per_launch": b["config"]["steps_per_launch"], "control": b["config"].get("control"), "issue": issue,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, FETCH_SIZE x2 (gfx950), "
                   "mean over the timed-region launches"}, indent=1) + "\n")
 print("\n".join(out))

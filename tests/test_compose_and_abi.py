@@ -94,6 +94,17 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libnmf_hip.so does not export {name}"
 
 
+def test_abi_struct_layout_and_plan_size():
+    """The ctypes mirror of nmf_eye_params has the layout the library was compiled with; plan buffer sizing."""
+    from flygym_amd.vision import _EyeParams
+
+    L = _native.lib()
+    assert ctypes.sizeof(_EyeParams) == L.nmf_eye_params_size()
+    n_pix = 512 * 450
+    assert L.nmf_retina_plan_bytes(n_pix) >= (n_pix // 16) * 20 + 4 and L.nmf_retina_plan_bytes(n_pix) % 16 == 0
+    assert L.nmf_retina_plan_bytes(17) == 0                 # not a multiple of 16 pixels: no plan
+
+
 def test_abi_model_parse_and_loud_failure_without_gpu(bench_model):
     import torch
 
