@@ -84,3 +84,80 @@ def test_hull_manifold_gives_up_to_four_contacts(bench_model, oracle_lib):
     assert np.isfinite(o.qpos).all()
     per_geom = np.bincount(i["con_geom"], minlength=55)
     assert per_geom.max() <= 4
+
+
+def test_constraint_solution_matches_an_independent_dense_optimiser(bench_model, oracle_lib):
+    """MuJoCo's constraint problem (documentation, "Computation / Constraint solver"): qacc minimises
+    1/2 (a - a0)^T M (a - a0) + sum_i 1/2 D_i min(J_i a - aref_i, 0)^2.  The oracle solves it matrix-free (articulated-body
+    sweeps with the active rows folded in); here the same convex problem, assembled densely from the oracle's M, J, D,
+    aref, is minimised by a plain semismooth Newton iteration in numpy — no code shared with the oracle's solver — on
+    several walking states with different contact sets."""
+    _, _, m = bench_model
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.ctrl[42:] = 1.0
+    o.step(400)
+    rng = np.random.default_rng(11)
+    seen = set()
+    for k in range(6):
+        o.ctrl[:42] = np.asarray(m["key_ctrl"])[:42] + rng.normal(0, 0.3, 42)
+        o.step(45)
+        o.qvel[:] += rng.normal(0, 0.3, o.nv) * (k % 2)       # every other state: off the solver's warm-start track
+        o.forward()
+        i = o.ints()
+        nefc, nv = i["nefc"], o.nv
+        assert nefc >= 4
+        seen.add(tuple(i["con_geom"]))
+        M = o.arr("M").reshape(nv, nv); M = np.tril(M) + np.tril(M, -1).T
+        J = o.arr("J").reshape(nefc, nv)
+        D, aref, a0 = o.arr("efc_D").copy(), o.arr("efc_aref").copy(), o.arr("qacc_smooth").copy()
+        a = a0.copy()
+        for it in range(200):
+            jar = J @ a - aref
+            act = jar < 0
+            grad = M @ (a - a0) + J.T @ (D * np.minimum(jar, 0))
+            if np.abs(grad).max() < 1e-9 * max(1.0, np.abs(M @ a0).max()):
+                break
+            H = M + (J[act].T * D[act]) @ J[act]
+            step = -np.linalg.solve(H, grad)
+            cost = lambda x: 0.5 * (x - a0) @ M @ (x - a0) + 0.5 * (D * np.minimum(J @ x - aref, 0) ** 2).sum()
+            t, c0 = 1.0, cost(a)
+            while cost(a + t * step) > c0 and t > 1e-8:           # backtracking (the problem is convex, C1)
+                t *= 0.5
+            a = a + t * step
+        else:
+            raise AssertionError("the dense reference iteration did not converge")
+        scale = np.abs(o.arr("qacc")).max()
+        np.testing.assert_allclose(o.arr("qacc"), a, atol=2e-7 * scale, rtol=0)
+        np.testing.assert_allclose(o.arr("efc_force"), -D * np.minimum(J @ a - aref, 0), atol=1e-6 * max(1.0, np.abs(D * aref).max()), rtol=0)
+    assert len(seen) >= 3                                         # different contact sets were exercised
+
+
+def test_reference_acceleration_follows_the_documented_spring_damper(settled):
+    """MuJoCo documentation ("Computation / Constraint model"): aref = -b (J v) - k d(r) r with, for solref = (timeconst,
+    dampratio) and solimp = (d0, dmax, width, midpoint, power):  b = 2 / (dmax timeconst),
+    k = 1 / (dmax^2 timeconst^2 dampratio^2),  r = distance - margin for all four pyramid rows of a contact, and the
+    impedance d(r) rising from d0 to dmax over `width` along a power-law sigmoid split at `midpoint`.  Numbers from the
+    reference's ContactParams (physics.py:79-111): solref (2e-4, 1), solimp (0.98, 0.99, 0.5, 3.0 -> 0.9999, 2), margin 1e-3."""
+    m, o = settled
+    o = o.clone_data()
+    o.qvel[:] += np.random.default_rng(4).normal(0, 0.5, o.nv)      # moving contacts: the damping term matters
+    o.forward()                                                       # constraint rows of exactly this state
+    i = o.ints()
+    nefc = i["nefc"]
+    assert nefc >= 12
+    J = o.arr("J").reshape(nefc, o.nv)
+    aref, dist = o.arr("efc_aref"), o.arr("con_dist")
+    tc, dr = 2e-4, 1.0
+    d0, dmax, width, mid, power = 0.98, 0.99, 0.5, 0.9999, 2.0
+    b = 2.0 / (dmax * tc)
+    k = 1.0 / (dmax ** 2 * tc ** 2 * dr ** 2)
+    r = np.repeat(dist - 1e-3, 4)
+    x = np.minimum(np.abs(r) / width, 1.0)
+    y = np.where(x <= mid, x ** power / mid ** (power - 1), 1 - (1 - x) ** power / (1 - mid) ** (power - 1))
+    imp = d0 + y * (dmax - d0)
+    np.testing.assert_allclose(aref, -b * (J @ o.qvel) - k * imp * r, rtol=1e-9, atol=1e-9 * np.abs(aref).max())
+    # regularisation: R = (1 - d) / d * (approximate inverse inertia), the same for the four rows of a contact
+    D = o.arr("efc_D").reshape(-1, 4)
+    assert np.allclose(D, D[:, :1]) and (D > 0).all()
+    ratio = (1.0 / D[:, 0]) / ((1 - imp[::4]) / imp[::4])
+    assert (ratio > 0).all()                                 # the inverse-inertia factor: positive, geometry dependent
