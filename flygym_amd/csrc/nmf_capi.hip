@@ -5,6 +5,7 @@
 // stepping path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -173,7 +174,8 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
   const bool weld = b->dm.weld_active != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode)
   if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
-  else { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
+  else if (b->topo == 1) { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
+  else { if (weld) NMF_LAUNCH(nmf::TreeTopo, true); else NMF_LAUNCH(nmf::TreeTopo, false); }
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -188,8 +190,41 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   int topo = -1;
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 11 && model->star[3] == 8) topo = 0;
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 7 && model->star[3] == 4) topo = 1;
-  if (topo < 0) { fail("nmf_batch_create: the HIP engine supports the LEGS_ONLY (6x8 bodies, 6x11 dofs) and LEGS_ACTIVE_ONLY (6x4, 6x7) skeletons"); return nullptr; }
-  {  // the kernels hard-wire the per-leg hinge layout; refuse anything else
+  // anything else (ALL_BIOLOGICAL, ALL_POSSIBLE, custom skeletons): the general-tree kernel, up to 72 bodies / 216 dofs
+  std::vector<int> tree_body, child_start, child_count, lvl_start;
+  if (topo < 0) {
+    topo = 2;
+    const HostArray* bp = model->find("body_parent");
+    const HostArray* dn = model->find("body_dofnum");
+    const HostArray* gb = model->find("geom_body");
+    if (!bp || !dn || !gb || model->nb > nmf::TreeTopo::NB || model->nv > nmf::TreeTopo::NV || dn->i.empty() || dn->i[0] != 6) {
+      fail("nmf_batch_create: the general-tree kernel takes a free-floating root and up to 72 bodies / 216 dofs"); return nullptr;
+    }
+    const int nb = model->nb;
+    for (int bb = 1; bb < nb; ++bb)
+      if (bp->i[(size_t)bb] < 0 || bp->i[(size_t)bb] >= bb) { fail("nmf_batch_create: bodies must be ordered parents first"); return nullptr; }
+    for (size_t g = 1; g < gb->i.size(); ++g)
+      if (gb->i[g] < gb->i[g - 1]) { fail("nmf_batch_create: contact geoms must be ordered by body"); return nullptr; }
+    // breadth-first order: level by level, the children of a body contiguous
+    std::vector<int> depth((size_t)nb, 0);
+    int maxd = 0;
+    for (int bb = 1; bb < nb; ++bb) { depth[(size_t)bb] = depth[(size_t)bp->i[(size_t)bb]] + 1; maxd = std::max(maxd, depth[(size_t)bb]); }
+    if (maxd + 2 > 18) { fail("nmf_batch_create: kinematic tree deeper than 16 levels"); return nullptr; }
+    tree_body.push_back(0); lvl_start.push_back(0);
+    child_start.assign((size_t)nb, 0); child_count.assign((size_t)nb, 0);
+    for (int lv = 0; lv <= maxd; ++lv) {
+      const int k0 = lvl_start[(size_t)lv], k1 = (int)tree_body.size();
+      lvl_start.push_back(k1);
+      for (int k = k0; k < k1; ++k) {
+        const int par = tree_body[(size_t)k];
+        child_start[(size_t)par] = (int)tree_body.size();
+        for (int bb = 1; bb < nb; ++bb) if (bp->i[(size_t)bb] == par) { tree_body.push_back(bb); child_count[(size_t)par]++; }
+      }
+      if (k1 - k0 > nmf::kWave) { fail("nmf_batch_create: more than 64 bodies on one tree level"); return nullptr; }
+    }
+    // lvl_start has maxd + 2 entries: starts of levels 0..maxd and the end
+  }
+  if (topo < 2) {  // the chain-star kernels hard-wire the per-leg hinge layout; refuse anything else
     const HostArray* dn = model->find("body_dofnum");
     const int pat0[8] = {3, 2, 1, 1, 1, 1, 1, 1}, pat1[4] = {3, 2, 1, 1};
     const int* pat = topo == 0 ? pat0 : pat1;
@@ -199,7 +234,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     if (!ok) { fail("nmf_batch_create: unexpected hinge layout along the legs"); return nullptr; }
   }
   if (model->ng > nmf::kWave) { fail("nmf_batch_create: more than 64 contact geoms"); return nullptr; }
-  if (model->nu > nmf::kMaxCtrl) { fail("nmf_batch_create: more than 48 actuators"); return nullptr; }
+  if (model->nu > (topo == 2 ? nmf::TreeTopo::kCtrl : nmf::kMaxCtrl)) { fail("nmf_batch_create: too many actuators (48 for the leg skeletons, 224 otherwise)"); return nullptr; }
   if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
   auto* b = new nmf_batch();
   b->model = model; b->n_worlds = n_worlds; b->device = device; b->topo = topo;
@@ -233,6 +268,17 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   UF(pair_friction); UF(pair_solref); UF(pair_solimp); UF(pair_margin);
 #undef UF
 #undef UI
+  if (topo == 2) {
+    const HostArray* bp = model->find("body_parent");
+    rc |= upload(b, bp->i, &d.body_parent);
+    rc |= upload(b, tree_body, &d.tree_body);
+    rc |= upload(b, child_start, &d.tree_child_start);
+    rc |= upload(b, child_count, &d.tree_child_count);
+    d.tree_nlevel = (int)lvl_start.size() - 1;
+    for (size_t k = 0; k < 18; ++k) d.tree_lvl_start[k] = k < lvl_start.size() ? lvl_start[k] : (int)tree_body.size();
+  } else {
+    d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0;
+  }
   if (rc == 0) {
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::DevModel)) != hipSuccess ||

@@ -27,6 +27,8 @@ enum { ACT_POSITION = 0, ACT_ADHESION = 1, ACT_MOTOR = 2 };
 // completely and never load structure from memory.
 template <int NLEG_, int... DOFS>
 struct Topo {
+  static constexpr bool kStar = true;
+  static constexpr int kCtrl = kMaxCtrl;
   static constexpr int NLEG = NLEG_;
   static constexpr int NBL = sizeof...(DOFS);
   static constexpr int NDL = (DOFS + ...);
@@ -38,6 +40,14 @@ struct Topo {
   static constexpr int lbody(int d) { int a = 0; for (int l = 0; l < NBL; ++l) { a += dofs(l); if (d < a) return l; } return NBL - 1; }
   static constexpr bool is_last(int d) { return d == first_dof(lbody(d)) + dofs(lbody(d)) - 1; }
   static constexpr bool is_first(int d) { return d == first_dof(lbody(d)); }
+};
+
+// A general kinematic tree (nmf_tree.h): LDS arrays sized for the largest fly skeleton (ALL_POSSIBLE: 69 bodies, 210
+// dofs), the actual counts are run-time values of the model.
+struct TreeTopo {
+  static constexpr bool kStar = false;
+  static constexpr int NB = 72, NV = 216, NQ = NV + 1;
+  static constexpr int kCtrl = 224;          // every dof actuated + adhesion
 };
 
 template <int... I, class F>
@@ -61,6 +71,9 @@ struct DevModel {
   float terrain[5];         // parameters + maximum height (see flygym_amd/compose/world.py)
   const float *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
   const int *body_dofadr, *body_dofnum, *dof_body;
+  // general-tree kernel only: bodies in breadth-first order (level by level, children of a body contiguous)
+  const int *body_parent, *tree_body, *tree_child_start, *tree_child_count;   // child ranges index tree_body
+  int tree_nlevel, tree_lvl_start[18];
   const float *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
   const int* seg_body;
   const float *seg_pos, *seg_quat;

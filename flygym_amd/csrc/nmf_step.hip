@@ -45,14 +45,28 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_FLUSH()
 #endif
 
+// LDS used by the general-tree sweeps only (nmf_tree.h)
+template <class TP, bool STAR = TP::kStar>
+struct TreeLds {};
 template <class TP>
-struct __align__(16) FlyLds {
+struct TreeLds<TP, false> {
+  float fact[TP::NV][8];      // articulated-body factors per dof: U (6), u, 1/D — written going up, read going down
+  float slot[TP::NB][27];     // articulated inertia (symmetric, 21) + bias wrench (6) a body hands to its parent
+  int rt_nb, rt_nv;
+};
+
+template <class TP>
+struct __align__(16) FlyLds : TreeLds<TP> {
+  // sizes: compile-time constants for the chain-star kernels, run-time values of the model for the tree kernel
+  __device__ __forceinline__ int nv() const { if constexpr (TP::kStar) return TP::NV; else return this->rt_nv; }
+  __device__ __forceinline__ int nb() const { if constexpr (TP::kStar) return TP::NB; else return this->rt_nb; }
+  __device__ __forceinline__ int nq() const { return nv() + 1; }
   float qpos[TP::NQ + 3];
   float qvel[TP::NV], qacc[TP::NV];      // qacc doubles as the warm start
   // qacc_smooth .. vD are contiguous (6 NV floats): the velocity stage borrows them as one buffer
   float qacc_smooth[TP::NV], qfrc_smooth[TP::NV];
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
-  float ctrl[kMaxCtrl];
+  float ctrl[TP::kCtrl];
   float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products)
@@ -133,6 +147,15 @@ __device__ __forceinline__ LaneRole lane_role(int lane) {
   return L;
 }
 
+// general-tree sweeps (nmf_tree.h, included at the end of this file)
+template <class TP> __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]);
+template <class TP> __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane);
+template <class TP, class Extra, class Emit>
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit);
+template <class TP, bool WELD>
+__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane);
+
 // ------------------------------------------------------------------ kinematics
 template <class TP>
 __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
@@ -142,7 +165,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.T[0][0]) - 1;    // bodies 1..NB-1: (NB-1) x 12 floats in T..W
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.Ib[0][0]);          // NV x 3 floats (Ib is rebuilt afterwards)
   static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
-  for (int j = 6 + lane; j < TP::NV; j += kWave) {
+  for (int j = 6 + lane; j < s.nv(); j += kWave) {
     float sn, cs;
     sincosf(0.5f * s.qpos[j + 1], &sn, &cs);
     jq[j][0] = cs; jq[j][1] = m.dof_axis[3 * j] * sn; jq[j][2] = m.dof_axis[3 * j + 1] * sn;
@@ -154,10 +177,13 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
     qmat(s.xmat[0], q);
   }
   WSYNC();
-  for (int b = 1 + lane; b < TP::NB; b += kWave) {
-    const int lb = (b - 1) % TP::NBL;
-    int adr = 6 + ((b - 1) / TP::NBL) * TP::NDL, num = 0;
-    static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
+  for (int b = 1 + lane; b < s.nb(); b += kWave) {
+    int adr, num;
+    if constexpr (TP::kStar) {
+      const int lb = (b - 1) % TP::NBL;
+      adr = 6 + ((b - 1) / TP::NBL) * TP::NDL; num = 0;
+      static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
+    } else { adr = m.body_dofadr[b]; num = m.body_dofnum[b]; }
     Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
     for (int j = adr + num - 1; j >= adr; --j) {
       st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
@@ -167,7 +193,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
     st3(&relm[b][9], ld3(&m.body_pos[3 * b]));
   }
   WSYNC();
-  {
+  if constexpr (!TP::kStar) tree_kinematics_chain(s, m, lane, relm);
+  else {
     // chain of rigid transforms down each leg: lane (leg, r < 3) carries row r of the rotation and
     // component r of the position:  R_b = R_parent * Rrel_b ,  p_b = p_parent + R_parent * off_b
     const LaneRole L = lane_role<TP>(lane);
@@ -188,7 +215,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
     });
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) {
+  for (int j = lane; j < s.nv(); j += kWave) {
     SV S;
     if (j < 3) {
       S.a = v3(0.f, 0.f, 0.f);
@@ -198,7 +225,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       S.a = v3(s.xmat[0][c], s.xmat[0][3 + c], s.xmat[0][6 + c]);
       S.l = v3(0.f, 0.f, 0.f);
     } else {
-      int b = dof_body_of<TP>(j);
+      int b;
+      if constexpr (TP::kStar) b = dof_body_of<TP>(j); else b = m.dof_body[j];
       V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
       V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
       S.a = a;
@@ -211,7 +239,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
 
 template <class TP>
 __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
-  for (int b = lane; b < TP::NB; b += kWave) {
+  for (int b = lane; b < s.nb(); b += kWave) {
     const float* R = s.xmat[b];
     const float* q = &m.body_inertia[6 * b];
     float Il[9] = {q[0], q[3], q[4], q[3], q[1], q[5], q[4], q[5], q[2]};
@@ -404,7 +432,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   const int ncon = total > kMaxCon ? kMaxCon : total;
   if (lane == 0) { s.ncon = ncon; s.overflow = total > kMaxCon ? 1 : 0; }
   WSYNC();
-  for (int b = lane; b <= TP::NB; b += kWave) {
+  for (int b = lane; b <= s.nb(); b += kWave) {
     int c_before = 0;
     for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
     s.body_cstart[b] = c_before;
@@ -421,6 +449,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
 // T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
 template <class TP>
 __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+  if constexpr (!TP::kStar) { tree_sweep_twists(s, x, T, m, lane); return; } else {
   const LaneRole L = lane_role<TP>(lane);
   float t = 0.f;
 #pragma unroll
@@ -433,12 +462,14 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
     if constexpr (TP::is_last(d)) T[b0 + TP::lbody(d)][L.rr] = t;
   });
   WSYNC();
+  }
 }
 
 // W[b] <- sum of W over the subtree of b (in place), then emit(j, S_j · W[body(j)]) for every dof j
 // (the projection and whatever the caller does with it share one pass: no intermediate vector, no extra sync)
 template <class TP, class Emit>
 __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Emit&& emit) {
+  if constexpr (!TP::kStar) { tree_sweep_project(s, W, m, lane, [](int, SV w) { return w; }, emit); return; } else {
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = 1 + L.lg * TP::NBL;
   float acc = 0.f;
@@ -458,6 +489,7 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[dof_body_of<TP>(j)])));
   WSYNC();
+  }
 }
 
 // y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x).
@@ -465,7 +497,7 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
 template <class TP, class Emit>
 __device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const DevModel& m, int lane, bool have_twists, Emit&& emit) {
   if (!have_twists) sweep_twists(s, x, s.T, m, lane);
-  for (int b = lane; b < TP::NB; b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
+  for (int b = lane; b < s.nb(); b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) { emit(j, v + s.arm[j] * x[j]); });
 }
@@ -535,6 +567,7 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
 template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
                           const DevModel& m, int lane) {
+  if constexpr (!TP::kStar) { tree_aba_solve<TP, WELD>(s, tau_id, x_id, withK, hdamp, m, lane); return; } else {
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
@@ -627,6 +660,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
   });
   WSYNC();
+  }
 }
 
 // ------------------------------------------------------------------ contact rows held in registers
@@ -702,6 +736,15 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     s.c_info[lane] = c.info | (act << 20);
   }
   WSYNC();
+  if constexpr (!TP::kStar) {
+    tree_sweep_project(s, s.W, m, lane, [&](int b, SV w) {
+      SV own = SEEDED ? seed_scale * w : SV{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+      if (b == 0) own = own + ldsv(s.weld_w);
+      for (int cc = s.body_cstart[b]; cc < s.body_cstart[b + 1]; ++cc) own = own + ldsv(s.c_w[cc]);
+      return own;
+    }, emit);
+    return;
+  } else {
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = 1 + L.lg * TP::NBL;
   float acc = 0.f;
@@ -725,6 +768,7 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)])));
   WSYNC();
+  }
 }
 
 // row forces f_k = −D jar_k on the active (jar < 0) pyramid rows, times `sign`
@@ -801,7 +845,17 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   }
   STAGE(4);
   // ---- velocities and bias accelerations: three passes over the chains
-  {
+  if constexpr (!TP::kStar) {
+    tree_velocity_bias(s, m, lane);
+    if (c.on) {
+      float velrow[4];
+      rows_of_twist(c, fr, ldsv(s.W[c.body]), velrow);
+      const float rr0 = c.dist - c.margin;
+#pragma unroll
+      for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
+    }
+    if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
+  } else {
     const LaneRole L = lane_role<TP>(lane);
     const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
     float(*vb)[6] = reinterpret_cast<float(*)[6]>(&s.qacc_smooth[0]);   // NV x 6 floats: qacc_smooth .. vD
@@ -830,7 +884,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
-    for (int j = 3 + lane; j < TP::NV; j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
+    for (int j = 3 + lane; j < s.nv(); j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
     WSYNC();
     // pass 3: component-wise prefix of bias accelerations (root parent acceleration = -gravity)
     float a = L.rr >= 3 ? -m.gravity[L.rr - 3] : 0.f;
@@ -844,12 +898,12 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     });
   }
   WSYNC();
-  for (int b = lane; b < TP::NB; b += kWave) {
+  for (int b = lane; b < s.nb(); b += kWave) {
     SV v = ldsv(s.W[b]);
     SV f = inert_mul(s.Ib[b], ldsv(s.T[b])) + cross_force(v, inert_mul(s.Ib[b], v));
     stsv(s.W[b], -1.0f * f);
   }
-  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = 0.f;  // direct actuator forces
+  for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = 0.f;  // direct actuator forces
   WSYNC();
   STAGE(5);
   // ---- actuation
@@ -892,7 +946,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
   if (ncon == 0 && !WELD) {
-    for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
+    for (int j = lane; j < s.nv(); j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
     // The loop carries the gradient itself:  grad += alpha M search − JT (f_new − f_old)  after every move, one merged
@@ -926,11 +980,11 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
         wr.jar = w0;
 #pragma unroll
         for (int k = 0; k < 4; k++) c.jar[k] = j0[k];
-        for (int j = lane; j < TP::NV; j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Gv[j] = 0.f; }
+        for (int j = lane; j < s.nv(); j += kWave) { s.qacc[j] = s.qacc_smooth[j]; Gv[j] = 0.f; }
       }
     }
     WSYNC();
-    const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
+    const float scale = 1.0f / (m.meaninertia * (float)s.nv());
     // gradient = (M qacc − qfrc_smooth) − JT f
     float gn = 0.f, gm = 0.f;
     {
@@ -958,8 +1012,8 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       // g1 = search·(M qacc − qfrc_smooth) = search·grad + (J search)·f ;  g2 = search·M·search as twice the kinetic
       // energy of the twists the ABA left in T (a sum of positive terms).  W keeps I_b T_b for the update sweep.
       float g1 = 0.f, g2 = 0.f;
-      for (int j = lane; j < TP::NV; j += kWave) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; }
-      for (int b = lane; b < TP::NB; b += kWave) {
+      for (int j = lane; j < s.nv(); j += kWave) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; }
+      for (int b = lane; b < s.nb(); b += kWave) {
         const SV tb = ldsv(s.T[b]), wb = inert_mul(s.Ib[b], tb);
         stsv(s.W[b], wb);
         g2 += dot(tb, wb);
@@ -1082,10 +1136,10 @@ template <class TP, bool WELD>
 __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
-  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
+  for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
   WSYNC();
   aba_solve<TP, WELD>(s, V_A, V_B, false, h, m, lane);
-  for (int j = lane; j < TP::NV; j += kWave) s.qvel[j] += h * s.vB[j];
+  for (int j = lane; j < s.nv(); j += kWave) s.qvel[j] += h * s.vB[j];
   WSYNC();
   if (lane == 0) {
     for (int k = 0; k < 3; k++) s.qpos[k] += h * s.qvel[k];
@@ -1100,17 +1154,17 @@ __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STA
     }
     stq(&s.qpos[3], qnorm(q));
   }
-  for (int j = 6 + lane; j < TP::NV; j += kWave) s.qpos[j + 1] += h * s.qvel[j];
+  for (int j = 6 + lane; j < s.nv(); j += kWave) s.qpos[j + 1] += h * s.qvel[j];
   WSYNC();
 }
 
 template <class TP>
 __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time) {
-  for (int i = lane; i < TP::NQ; i += kWave) st.qpos[(size_t)w * TP::NQ + i] = s.qpos[i];
-  for (int i = lane; i < TP::NV; i += kWave) {
-    st.qvel[(size_t)w * TP::NV + i] = s.qvel[i];
-    st.qacc_ws[(size_t)w * TP::NV + i] = s.qacc[i];
-    st.qacc[(size_t)w * TP::NV + i] = s.qacc[i];
+  for (int i = lane; i < s.nq(); i += kWave) st.qpos[(size_t)w * s.nq() + i] = s.qpos[i];
+  for (int i = lane; i < s.nv(); i += kWave) {
+    st.qvel[(size_t)w * s.nv() + i] = s.qvel[i];
+    st.qacc_ws[(size_t)w * s.nv() + i] = s.qacc[i];
+    st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
   }
   for (int i = lane; i < m.nu; i += kWave) {
     st.ctrl[(size_t)w * m.nu + i] = s.ctrl[i];
@@ -1140,6 +1194,7 @@ template <class TP, bool WELD>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
   const DevModel& m = *mp;
+  if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= st.n_worlds) return;
   const int w = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;
@@ -1147,11 +1202,11 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   STAGE_INIT();
-  for (int j = lane; j < TP::NV; j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
+  for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
   float time;
   if (mode == 1) {
-    for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = m.key_qpos[i];
-    for (int i = lane; i < TP::NV; i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
+    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
+    for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
     for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
     for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
     if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
@@ -1159,10 +1214,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
     WSYNC();
     stage_kinematics(s, m, lane);
   } else {
-    for (int i = lane; i < TP::NQ; i += kWave) s.qpos[i] = st.qpos[(size_t)w * TP::NQ + i];
-    for (int i = lane; i < TP::NV; i += kWave) {
-      s.qvel[i] = st.qvel[(size_t)w * TP::NV + i];
-      s.qacc[i] = st.qacc_ws[(size_t)w * TP::NV + i];
+    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = st.qpos[(size_t)w * s.nq() + i];
+    for (int i = lane; i < s.nv(); i += kWave) {
+      s.qvel[i] = st.qvel[(size_t)w * s.nv() + i];
+      s.qacc[i] = st.qacc_ws[(size_t)w * s.nv() + i];
     }
     for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = st.ctrl[(size_t)w * m.nu + i];
     time = st.time[w];
@@ -1261,6 +1316,10 @@ __global__ void __launch_bounds__(1024) nmf_order_kernel(const float* __restrict
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&base[(int)((cost[i] - l) * scale)], 1u)] = i;
 }
 
+}  // namespace nmf
+#include "nmf_tree.h"
+namespace nmf {
+
 using FlyTopo = Topo<6, 3, 2, 1, 1, 1, 1, 1, 1>;   // LEGS_ONLY skeleton: 49 bodies, 72 dofs
 using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
@@ -1268,5 +1327,7 @@ template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevSta
 template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
 
 }  // namespace nmf

@@ -1,0 +1,208 @@
+// nmf_tree.h — sweeps of the stepping kernel for a general kinematic tree (any JointPreset: ALL_BIOLOGICAL nv = 132,
+// ALL_POSSIBLE nv = 210, custom skeletons), included by nmf_step.hip.
+//
+// The chain-star kernels (Topo<...>: identical leg chains hanging off the root) unroll their sweeps at compile time with
+// (leg, row) lanes.  A general tree has no such regularity, so here every sweep walks the tree LEVEL BY LEVEL (bodies in
+// breadth-first order, tables built by the host): lane = one body of the current level, which does its whole 6-vector /
+// 6x6 work alone in registers; a down sweep reads its parent's result from LDS, an up sweep its children's.  The fly's
+// tree is at most 9 levels deep and 12 bodies wide, so a sweep is ~9 short wave passes.  Same algorithms, same LDS-
+// resident state, same shared stages (collision, contact rows, Newton loop, sensors) as the star kernels; the oracle
+// (oracle/nmf_oracle.c) is the same for both.  Slower per fly (few lanes busy per pass) — this is the generality path.
+#pragma once
+
+namespace nmf {
+
+// f(body) for every body of levels 1.. (root excluded), a wave barrier after each level
+template <class F>
+__device__ __forceinline__ void tree_down(const DevModel& m, int lane, F&& f) {
+  for (int lvl = 1; lvl < m.tree_nlevel; ++lvl) {
+    const int k = m.tree_lvl_start[lvl] + lane;
+    if (k < m.tree_lvl_start[lvl + 1]) f(m.tree_body[k]);
+    WSYNC();
+  }
+}
+template <class F>
+__device__ __forceinline__ void tree_up(const DevModel& m, int lane, F&& f) {
+  for (int lvl = m.tree_nlevel - 1; lvl >= 1; --lvl) {
+    const int k = m.tree_lvl_start[lvl] + lane;
+    if (k < m.tree_lvl_start[lvl + 1]) f(m.tree_body[k]);
+    WSYNC();
+  }
+}
+
+// rigid transforms down the tree: R_b = R_parent Rrel_b, p_b = p_parent + R_parent off_b  (relm[b] = Rrel (9), off (3))
+template <class TP>
+__device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]) {
+  tree_down(m, lane, [&](int b) {
+    const int p = m.body_parent[b];
+    const float* R = s.xmat[p];
+    const float* M = relm[b];
+    st3(s.xpos[b], ld3(s.xpos[p]) + mat_vec(R, ld3(M + 9)));
+    float out[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) out[3 * i + j] = R[3 * i] * M[j] + R[3 * i + 1] * M[3 + j] + R[3 * i + 2] * M[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.xmat[b][i] = out[i];
+  });
+}
+
+// body velocities -> W, bias accelerations (parent acceleration of the root = -gravity) -> T
+template <class TP>
+__device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
+  if (lane == 0) {
+    SV vt = SV{v3(0, 0, 0), v3(0, 0, 0)};
+    for (int j = 0; j < 3; ++j) vt = vt + s.qvel[j] * ldsv(s.S[j]);
+    SV v = vt, a = SV{v3(0, 0, 0), v3(-m.gravity[0], -m.gravity[1], -m.gravity[2])};
+    for (int j = 3; j < 6; ++j) {       // the three rotational dofs of the free joint share the velocity before the joint
+      a = a + s.qvel[j] * cross_motion(vt, ldsv(s.S[j]));
+      v = v + s.qvel[j] * ldsv(s.S[j]);
+    }
+    stsv(s.W[0], v); stsv(s.T[0], a);
+  }
+  WSYNC();
+  tree_down(m, lane, [&](int b) {
+    const int p = m.body_parent[b], adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    SV v = ldsv(s.W[p]), a = ldsv(s.T[p]);
+    for (int j = adr; j < adr + num; ++j) {
+      const SV S = ldsv(s.S[j]);
+      a = a + s.qvel[j] * cross_motion(v, S);
+      v = v + s.qvel[j] * S;
+    }
+    stsv(s.W[b], v); stsv(s.T[b], a);
+  });
+}
+
+// T[b] = twist of body b under the generalized vector x
+template <class TP>
+__device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+  if (lane == 0) {
+    SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
+    for (int j = 0; j < 6; ++j) t = t + x[j] * ldsv(s.S[j]);
+    stsv(T[0], t);
+  }
+  WSYNC();
+  tree_down(m, lane, [&](int b) {
+    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    SV t = ldsv(T[m.body_parent[b]]);
+    for (int j = adr; j < adr + num; ++j) t = t + x[j] * ldsv(s.S[j]);
+    stsv(T[b], t);
+  });
+}
+
+// W[b] <- sum over the subtree of b (in place; `extra(b)` adds a per-body term first), then emit(j, S_j . W[body(j)])
+template <class TP, class Extra, class Emit>
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
+  auto gather = [&](int b) {
+    SV w = extra(b, ldsv(W[b]));
+    const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
+    for (int k = c0; k < c1; ++k) w = w + ldsv(W[m.tree_body[k]]);
+    stsv(W[b], w);
+  };
+  tree_up(m, lane, gather);
+  if (lane == 0) gather(0);
+  WSYNC();
+  for (int j = lane; j < s.nv(); j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]])));
+  WSYNC();
+}
+
+// row k of the contact frame at contact c:  l = [r x d; d]
+__device__ __forceinline__ void contact_dirs(V3 r, const Frame& fr, float* ln, float* l1, float* l2) {
+  const V3 xn = cross(r, fr.n), x1 = cross(r, fr.t1), x2 = cross(r, fr.t2);
+  ln[0] = xn.x; ln[1] = xn.y; ln[2] = xn.z; ln[3] = fr.n.x; ln[4] = fr.n.y; ln[5] = fr.n.z;
+  l1[0] = x1.x; l1[1] = x1.y; l1[2] = x1.z; l1[3] = fr.t1.x; l1[4] = fr.t1.y; l1[5] = fr.t1.z;
+  l2[0] = x2.x; l2[1] = x2.y; l2[2] = x2.z; l2[3] = fr.t2.x; l2[4] = fr.t2.y; l2[5] = fr.t2.z;
+}
+
+// Articulated-body solve of (CRBA(I_b [+ K_b]) + diag(delta)) x = tau on the tree; leaves T = twists(x).
+//   up   : IA_b = I_b [+ contact stiffness] + children; per dof (last to first): U = IA s, D = s.U + delta,
+//          u = tau - s.pA, IA -= U UT / D, pA += U u / D; (U, u, 1/D) parked in LDS; (IA, pA) handed to the parent
+//   down : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
+template <class TP, bool WELD>
+__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane) {
+  const float* tau = s.vec(tau_id);
+  float* x = s.vec(x_id);
+  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  auto eliminate = [&](int b) {
+    Sym6 IA;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) IA.v[i] = s.Isym[b][i];
+    float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
+    for (int k = c0; k < c1; ++k) {
+      const float* sl = s.slot[m.tree_body[k]];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) IA.v[i] += sl[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pA[i] += sl[21 + i];
+    }
+    if (withK) {
+      for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) {
+        const int act = info_act(s.c_info[c]);
+        if (!act) continue;
+        float ln[6], l1[6], l2[6];
+        contact_dirs(ld3(s.c_r[c]), fr, ln, l1, l2);
+        const float D = s.c_D[c], mu = s.c_mu[c];
+        const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+        // sum_k a_k D (ln +- mu lt)(ln +- mu lt)T
+        sym6_rank1(IA, ln, D * (a0 + a1 + a2 + a3));
+        sym6_rank1(IA, l1, D * mu * mu * (a0 + a1));
+        sym6_rank1(IA, l2, D * mu * mu * (a2 + a3));
+        sym6_rank2(IA, ln, l1, D * mu * (a0 - a1));
+        sym6_rank2(IA, ln, l2, D * mu * (a2 - a3));
+      }
+      if constexpr (WELD) {
+        if (b == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) IA.v[sym_idx(i, i)] += s.weldD[i];
+        }
+      }
+    }
+    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    for (int j = adr + num - 1; j >= adr; --j) {
+      float sj[6], U[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sj[i] = s.S[j][i];
+      sym6_mul(IA, sj, U);
+      float D = j < 6 ? 0.f : s.arm[j] + hdamp * s.damp[j], sp = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
+      const float invD = __builtin_amdgcn_rcpf(D), u = tau[j] - sp;
+      float* f = s.fact[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) f[i] = U[i];
+      f[6] = u; f[7] = invD;
+      sym6_rank1(IA, U, -invD);
+      const float ku = u * invD;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pA[i] += U[i] * ku;
+    }
+    if (b != 0) {
+      float* sl = s.slot[b];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) sl[i] = IA.v[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sl[21 + i] = pA[i];
+    }
+  };
+  tree_up(m, lane, eliminate);
+  if (lane == 0) eliminate(0);
+  WSYNC();
+  auto expand = [&](int b, SV a) {
+    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+    for (int j = adr; j < adr + num; ++j) {
+      const float* f = s.fact[j];
+      const SV U = ldsv(f), S = ldsv(s.S[j]);
+      const float xj = (f[6] - dot(U, a)) * f[7];
+      x[j] = xj;
+      a = a + xj * S;
+    }
+    stsv(s.T[b], a);
+  };
+  if (lane == 0) expand(0, SV{v3(0, 0, 0), v3(0, 0, 0)});
+  WSYNC();
+  tree_down(m, lane, [&](int b) { expand(b, ldsv(s.T[m.body_parent[b]])); });
+}
+
+}  // namespace nmf

@@ -521,3 +521,62 @@ def test_single_world_simulation_mirrors_the_cpu_class(torch_mod, bench_model, o
         sim.set_leg_adhesion_states(fly.name, np.ones(5))
     sim.reset()
     assert sim.time == 0.0 and np.allclose(sim.get_joint_angles(fly.name), q0)
+
+
+@pytest.mark.parametrize("preset,nv", [("ALL_BIOLOGICAL", 132), ("ALL_POSSIBLE", 210)])
+def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
+    """Skeletons that are not a star of identical leg chains (head with antennae and proboscis, abdomen, wings,
+    halteres: 69 bodies, 132 / 210 dofs) run on the general-tree kernel (nmf_tree.h): reset poses, the drop, landing and
+    settling, then driven walking, against the float64 oracle — same bars as the leg-only skeletons."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = C.Fly(name="t")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=getattr(A.JointPreset, preset))
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    legs = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_actuators(legs.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    world = C.FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    n = 3
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    assert sim.model.nv == nv and sim.model.nb == 69 and int(sim.model["star"][0]) == 0
+    o = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+    o32 = oracle_lib.Oracle(sim.model.to_blob(), "f32")
+    assert np.abs(sim.field("seg_xpos").cpu().numpy()[0] - o.arr("seg_xpos")).max() < 2e-6
+    nu = sim.model.nu
+    assert nu == 48
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    for orc in (o, o32):
+        orc.ctrl[nu - 6:] = 1.0
+    for k in range(5):                                              # free fall, landing, settling
+        sim.step(100)
+        for orc in (o, o32):
+            orc.step(100)
+        q = sim.field("qpos").cpu().numpy()
+        assert np.abs(q - o.qpos[None]).max() < 5e-5, f"{preset} after {100 * (k + 1)} steps"
+    assert int(sim.field("stats")[0, 0].item()) == o32.ints()["ncon"] >= 5
+    assert int(sim.field("stats")[0, 1].item()) == o32.ints()["solver_iter"]
+    # one step from the same contact-rich state: accelerations to float32 accuracy, contact set bit-exact
+    _push_state(sim, torch, o32.qpos, o32.qvel, o32.ctrl, o32.arr("qacc_warmstart"))
+    sim.step(1); o32.step(1)
+    qa, qa_ref = sim.field("qacc").cpu().numpy()[0], o32.arr("qacc")
+    assert np.abs(qa - qa_ref).max() < 2e-3 * max(np.abs(qa_ref).max(), 1e4)
+    assert int(sim.field("stats")[0, 0].item()) == o32.ints()["ncon"]
+    # driven walking through the in-kernel control table (re-synchronised to the float64 state first)
+    order = fly.get_actuated_jointdofs_order(C.ActuatorType.POSITION)
+    table = TripodCPG(order, 1e-4).targets(1, 2500)
+    tdev = torch.as_tensor(np.repeat(table, n, axis=0), device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    _push_state(sim, torch, o.qpos, o.qvel, o.ctrl, o.arr("qacc_warmstart"))
+    for k in range(2):
+        sim.step_replay(tdev, ids, 100 * k, 100)
+        o.step_replay(table[0], ids.cpu().numpy(), 100 * k, 100)
+        assert np.abs(sim.field("qpos").cpu().numpy() - o.qpos[None]).max() < 1e-4, f"{preset} walking, tick {k}"
+    assert sim.get_joint_angles(fly.name).shape == (n, nv - 6)
+    assert torch.equal(sim.field("qpos")[0], sim.field("qpos")[n - 1])    # identical worlds stay identical
