@@ -175,6 +175,7 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode)
   if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
   else if (b->topo == 1) { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
+  else if (b->topo == 2) { if (weld) NMF_LAUNCH(nmf::TreeTopoSmall, true); else NMF_LAUNCH(nmf::TreeTopoSmall, false); }
   else { if (weld) NMF_LAUNCH(nmf::TreeTopo, true); else NMF_LAUNCH(nmf::TreeTopo, false); }
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
@@ -193,7 +194,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   // anything else (ALL_BIOLOGICAL, ALL_POSSIBLE, custom skeletons): the general-tree kernel, up to 72 bodies / 216 dofs
   std::vector<int> tree_body, child_start, child_count, lvl_start;
   if (topo < 0) {
-    topo = 2;
+    topo = model->nv <= nmf::TreeTopoSmall::NV && model->nu <= nmf::TreeTopoSmall::kCtrl ? 2 : 3;
     const HostArray* bp = model->find("body_parent");
     const HostArray* dn = model->find("body_dofnum");
     const HostArray* gb = model->find("geom_body");
@@ -234,7 +235,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     if (!ok) { fail("nmf_batch_create: unexpected hinge layout along the legs"); return nullptr; }
   }
   if (model->ng > nmf::kWave) { fail("nmf_batch_create: more than 64 contact geoms"); return nullptr; }
-  if (model->nu > (topo == 2 ? nmf::TreeTopo::kCtrl : nmf::kMaxCtrl)) { fail("nmf_batch_create: too many actuators (48 for the leg skeletons, 224 otherwise)"); return nullptr; }
+  if (model->nu > (topo >= 2 ? nmf::TreeTopo::kCtrl : nmf::kMaxCtrl)) { fail("nmf_batch_create: too many actuators (48 for the leg skeletons, 224 otherwise)"); return nullptr; }
   if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
   auto* b = new nmf_batch();
   b->model = model; b->n_worlds = n_worlds; b->device = device; b->topo = topo;
@@ -268,7 +269,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   UF(pair_friction); UF(pair_solref); UF(pair_solimp); UF(pair_margin);
 #undef UF
 #undef UI
-  if (topo == 2) {
+  if (topo >= 2) {
     const HostArray* bp = model->find("body_parent");
     rc |= upload(b, bp->i, &d.body_parent);
     rc |= upload(b, tree_body, &d.tree_body);
@@ -312,7 +313,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     st.sched = nullptr;
     st.order = nullptr;
     hipDeviceProp_t prop;
-    b->resident_waves = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 8 : 2048;   // 2 waves x 4 SIMDs per CU
+    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : 3);      // flies per CU: LDS-limited (18 / 35 / 43 KB per fly)
+    b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;
   }
   if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
     std::string keep = g_err.empty() ? std::string("nmf_batch_create: device initialisation failed") : g_err;

@@ -42,13 +42,17 @@ struct Topo {
   static constexpr bool is_first(int d) { return d == first_dof(lbody(d)); }
 };
 
-// A general kinematic tree (nmf_tree.h): LDS arrays sized for the largest fly skeleton (ALL_POSSIBLE: 69 bodies, 210
-// dofs), the actual counts are run-time values of the model.
-struct TreeTopo {
+// A general kinematic tree (nmf_tree.h): LDS arrays sized for NB_ bodies / NV_ dofs, the actual counts are run-time
+// values of the model.  Two sizes are built: 72 x 144 (ALL_BIOLOGICAL: 69 bodies, 132 dofs; 4 flies per CU) and
+// 72 x 216 (ALL_POSSIBLE: 210 dofs; 3 flies per CU).
+template <int NB_, int NV_>
+struct TreeTopoT {
   static constexpr bool kStar = false;
-  static constexpr int NB = 72, NV = 216, NQ = NV + 1;
-  static constexpr int kCtrl = 224;          // every dof actuated + adhesion
+  static constexpr int NB = NB_, NV = NV_, NQ = NV_ + 1;
+  static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
 };
+using TreeTopo = TreeTopoT<72, 216>;
+using TreeTopoSmall = TreeTopoT<72, 144>;
 
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {

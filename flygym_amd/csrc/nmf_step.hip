@@ -70,7 +70,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products)
-  float Isym[TP::NB][21];               // the same as a symmetric 6x6 (upper triangle): row fetches for the ABA
+  float Isym[TP::kStar ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches for the star ABA
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][6], W[TP::NB][6];
@@ -258,11 +258,13 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
     I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
     I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
     I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
+    if constexpr (TP::kStar) {
     float* Q = s.Isym[b];                // [[I, [h]x], [-[h]x, m 1]], upper triangle row-major
     Q[0] = I[4]; Q[1] = I[7]; Q[2] = I[8]; Q[3] = 0.f;   Q[4] = -I[3]; Q[5] = I[2];
     Q[6] = I[5]; Q[7] = I[9]; Q[8] = I[3]; Q[9] = 0.f;   Q[10] = -I[1];
     Q[11] = I[6]; Q[12] = -I[2]; Q[13] = I[1]; Q[14] = 0.f;
     Q[15] = ms; Q[16] = 0.f; Q[17] = 0.f; Q[18] = ms; Q[19] = 0.f; Q[20] = ms;
+    }
   }
   WSYNC();
 }
@@ -1329,5 +1331,7 @@ template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, 
 template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<TreeTopoSmall, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<TreeTopoSmall, true>(const DevModel*, DevState, ReplayArgs, int, int);
 
 }  // namespace nmf

@@ -126,8 +126,8 @@ __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, 
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   auto eliminate = [&](int b) {
     Sym6 IA;
-#pragma unroll
-    for (int i = 0; i < 21; ++i) IA.v[i] = s.Isym[b][i];
+    sym6_zero(IA);
+    sym6_add_inertia(IA, s.Ib[b]);
     float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
     for (int k = c0; k < c1; ++k) {
