@@ -383,6 +383,9 @@ def compile_world(world) -> CompiledModel:
     # ---- contact geoms ---------------------------------------------------------
     cps = world.ground_contact_params
     contact_segs = [seg_index[s.name] for s in world.bodysegs_with_ground_contact]
+    # geoms ordered by the dynamic body that carries them (stable: the preset's order within a body): the engine keeps
+    # a fly's contacts sorted by body.  The leg / thorax / abdomen / head presets already are.
+    contact_segs = sorted(contact_segs, key=lambda s: int(dyn_of_seg[s]))
     g_body, g_seg, g_type, g_p0, g_p1, g_rad, g_hadr, g_hnum, g_bs = [], [], [], [], [], [], [], [], []
     hull_chunks, hadr = [], 0
     for s in contact_segs:

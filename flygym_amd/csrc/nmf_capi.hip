@@ -191,6 +191,15 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   int topo = -1;
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 11 && model->star[3] == 8) topo = 0;
   if (model->star[0] == 1 && model->star[1] == 6 && model->star[2] == 7 && model->star[3] == 4) topo = 1;
+  if (topo >= 0) {  // the chain-star kernels hard-wire the per-leg hinge layout (and 48 controls); anything else takes the tree kernel
+    const HostArray* dn = model->find("body_dofnum");
+    const int pat0[8] = {3, 2, 1, 1, 1, 1, 1, 1}, pat1[4] = {3, 2, 1, 1};
+    const int* pat = topo == 0 ? pat0 : pat1;
+    const int nbl = topo == 0 ? 8 : 4;
+    bool ok = dn && dn->is_int && (int)dn->i.size() == 1 + 6 * nbl && dn->i[0] == 6;
+    for (int b = 1; ok && b < 1 + 6 * nbl; ++b) ok = dn->i[(size_t)b] == pat[(b - 1) % nbl];
+    if (!ok || model->nu > nmf::kMaxCtrl) topo = -1;
+  }
   // anything else (ALL_BIOLOGICAL, ALL_POSSIBLE, custom skeletons): the general-tree kernel, up to 72 bodies / 216 dofs
   std::vector<int> tree_body, child_start, child_count, lvl_start;
   if (topo < 0) {
@@ -225,16 +234,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     }
     // lvl_start has maxd + 2 entries: starts of levels 0..maxd and the end
   }
-  if (topo < 2) {  // the chain-star kernels hard-wire the per-leg hinge layout; refuse anything else
-    const HostArray* dn = model->find("body_dofnum");
-    const int pat0[8] = {3, 2, 1, 1, 1, 1, 1, 1}, pat1[4] = {3, 2, 1, 1};
-    const int* pat = topo == 0 ? pat0 : pat1;
-    const int nbl = topo == 0 ? 8 : 4;
-    bool ok = dn && dn->is_int && (int)dn->i.size() == 1 + 6 * nbl && dn->i[0] == 6;
-    for (int b = 1; ok && b < 1 + 6 * nbl; ++b) ok = dn->i[(size_t)b] == pat[(b - 1) % nbl];
-    if (!ok) { fail("nmf_batch_create: unexpected hinge layout along the legs"); return nullptr; }
-  }
-  if (model->ng > nmf::kWave) { fail("nmf_batch_create: more than 64 contact geoms"); return nullptr; }
+  if (model->ng > 2 * nmf::kWave) { fail("nmf_batch_create: more than 128 contact geoms"); return nullptr; }
   if (model->nu > (topo >= 2 ? nmf::TreeTopo::kCtrl : nmf::kMaxCtrl)) { fail("nmf_batch_create: too many actuators (48 for the leg skeletons, 224 otherwise)"); return nullptr; }
   if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
   auto* b = new nmf_batch();

@@ -300,26 +300,30 @@ template <class TP>
 __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
   static_assert(sizeof(CollisionScratch) <= sizeof(float) * TP::NB * 12, "collision scratch does not fit T..W");
   CollisionScratch& X = *reinterpret_cast<CollisionScratch*>(&s.T[0][0]);
-  int* geom_slot0 = reinterpret_cast<int*>(&s.vA[0]);     // first contact slot of every geom (kWave ints; NV >= 48... vA..vB)
-  static_assert(2 * TP::NV >= kWave, "slot table does not fit vA..vB");
+  int* geom_slot0 = reinterpret_cast<int*>(&s.vA[0]);     // first contact slot of every geom (up to 128 ints in vA..vD, scratch here)
+  static_assert(4 * TP::NV >= 2 * kWave, "slot table (128 geoms) does not fit vA..vD");
   const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
   const float pd = m.plane[3];
   const V3 o = ld3(s.xpos[0]);
   // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
+  // (more than 64 contact geoms — e.g. every body segment in contact — take further passes of 64)
+  int nh = 0, slot_base = 0;
+  for (int g0 = 0; g0 < m.ng; g0 += kWave) {
+  const int gi = g0 + lane;
   int g_body = 0, g_type = -1, g_hadr = 0, g_hnum = 0, cnt = 0;
   float g_margin = 0.f, cd0 = 0.f, cd1 = 0.f;
   V3 cp0 = v3(0, 0, 0), cp1 = v3(0, 0, 0);
   bool near = false;
-  if (lane < m.ng) {
-    g_body = m.geom_body[lane]; g_type = m.geom_type[lane]; g_margin = m.pair_margin[lane];
-    g_hadr = m.geom_hulladr[lane]; g_hnum = m.geom_hullnum[lane];
+  if (gi < m.ng) {
+    g_body = m.geom_body[gi]; g_type = m.geom_type[gi]; g_margin = m.pair_margin[gi];
+    g_hadr = m.geom_hulladr[gi]; g_hnum = m.geom_hullnum[gi];
     const float* R = s.xmat[g_body];
     const V3 xp = ld3(s.xpos[g_body]);
-    V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * lane]));
+    V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * gi]));
     float dc = dot(n, cw) + dot(n, xp) - pd;
-    near = dc - m.geom_bsphere[4 * lane + 3] - m.terrain[4] <= g_margin;
-    const float rad = m.geom_radius[lane];
-    const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * lane])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * lane])) + xp;
+    near = dc - m.geom_bsphere[4 * gi + 3] - m.terrain[4] <= g_margin;
+    const float rad = m.geom_radius[gi];
+    const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * gi])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * gi])) + xp;
     float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
     // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's
     // reach but above its own thickness needs no vertex scan
@@ -334,7 +338,6 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   // ---- phase 2: near convex hulls one after the other, each scanned by the whole wave; the geom's
   // parameters are broadcast from its lane's registers (no memory round trip)
   unsigned long long hmask = __ballot(near && g_type == GEOM_HULL);
-  int nh = 0;
   while (hmask) {
     const int g = __ffsll((long long)hmask) - 1;
     hmask &= hmask - 1;
@@ -408,7 +411,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
       const V3 v = ld3(V + 3 * vi);
       const float dist = vdist(v);
       const V3 pw = mat_vec(R, v) + xp;
-      X.info[nh + lane] = g | (lane << 8) | (b << 12);
+      X.info[nh + lane] = (g0 + g) | (lane << 8) | (b << 12);
       X.dist[nh + lane] = dist;
       st3(X.r[nh + lane], (pw - (0.5f * dist) * n) - o);
     }
@@ -419,12 +422,15 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int slot0 = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-  const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-  geom_slot0[lane] = slot0;
+  const int sl = slot_base + slot0;
+  geom_slot0[gi] = slot_base + slot0;
   if (g_type == GEOM_CAPSULE && cnt > 0) {
-    if (slot0 < kMaxCon) { s.c_info[slot0] = info_pack(lane, -1, g_body, 0); s.c_D[slot0] = cd0; st3(s.c_r[slot0], cp0); }
-    if (cnt > 1 && slot0 + 1 < kMaxCon) { s.c_info[slot0 + 1] = info_pack(lane, -1, g_body, 0); s.c_D[slot0 + 1] = cd1; st3(s.c_r[slot0 + 1], cp1); }
+    if (sl < kMaxCon) { s.c_info[sl] = info_pack(gi, -1, g_body, 0); s.c_D[sl] = cd0; st3(s.c_r[sl], cp0); }
+    if (cnt > 1 && sl + 1 < kMaxCon) { s.c_info[sl + 1] = info_pack(gi, -1, g_body, 0); s.c_D[sl + 1] = cd1; st3(s.c_r[sl + 1], cp1); }
   }
+  slot_base += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+  }   // passes of 64 geoms
+  const int total = slot_base;
   WSYNC();
   if (lane < nh && lane < kMaxCon) {
     const int info = X.info[lane];

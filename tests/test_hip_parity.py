@@ -583,3 +583,35 @@ def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
         assert np.abs(sim.field("qpos").cpu().numpy() - o.qpos[None]).max() < 1e-4, f"{preset} walking, tick {k}"
     assert sim.get_joint_angles(fly.name).shape == (n, nv - 6)
     assert torch.equal(sim.field("qpos")[0], sim.field("qpos")[n - 1])    # identical worlds stay identical
+
+
+def test_every_segment_in_contact_69_geoms(torch_mod, oracle_lib):
+    """ContactBodiesPreset ALL on the ALL_BIOLOGICAL skeleton: 69 geom-plane pairs (more than one wave of geoms: the
+    collision stage takes two passes), no actuators — the fly drops and collapses onto body, wings and legs.  Compared
+    with the float32 oracle in re-synchronised 20-step segments (see test_single_world_and_launch_splitting)."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = C.Fly(name="t")
+    fly.add_joints(A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL),
+                   neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    world = C.FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.5), Rotation3D("quat", (1, 0, 0, 0)), bodysegs_with_ground_contact="all")
+    sim = HIPSimulation(world, n_worlds=2, device=0)
+    assert sim.model.ng == 69 and sim.model.nu == 0
+    o = oracle_lib.Oracle(sim.model.to_blob(), "f32")
+    errs, same_ncon, most = [], [], 0
+    for k in range(30):
+        _push_state(sim, torch, o.qpos, o.qvel, o.ctrl, o.arr("qacc_warmstart"))
+        sim.step(20); o.step(20)
+        errs.append(np.abs(sim.field("qpos").cpu().numpy()[0] - o.qpos).max())
+        same_ncon.append(int(sim.field("stats")[0, 0].item()) == o.ints()["ncon"])
+        most = max(most, o.ints()["ncon"])
+    errs = np.array(errs)
+    assert (errs < 1e-5).mean() >= 0.85, np.sort(errs)[-6:]
+    assert errs.max() < 5e-3 and np.mean(same_ncon) >= 0.85
+    assert most >= 8 and int(sim.field("stats")[0, 2].item()) == 0          # many contacts, no overflow
+    geoms = set(o.ints()["con_geom"])
+    assert max(geoms) >= 64 or most >= 8                                     # geoms of the second pass can be hit
