@@ -4,8 +4,12 @@ Drop-in for the physics hot path of NeLy-EPFL/flygym (``Simulation`` / ``GPUSimu
 hand-written HIP kernels for gfx950 behind the reference's Python surface.
 """
 
+from pathlib import Path
+
 from . import anatomy, compose
 from .models import make_model
+
+assets_dir = Path(__file__).resolve().parent / "assets"     # as `flygym.assets_dir` (pose files; the asset pack)
 
 __all__ = ["anatomy", "compose", "make_model", "HIPSimulation", "Simulation"]
 __version__ = "0.1.0"

@@ -388,6 +388,15 @@ class Skeleton:
                 raise ValueError("Skeleton is invalid - must be a tree.")
         return adj
 
+    def get_tree(self):
+        """The skeleton as a :class:`flygym_amd.utils.math.Tree` over its body segments (reference ``anatomy.py:607-613``)."""
+        from .utils.math import Tree
+
+        try:
+            return Tree(nodes=self.body_segments, edges=list(self.joint_lookup))
+        except ValueError as e:
+            raise ValueError("Skeleton is invalid - must be a tree.") from e
+
     def iter_edges(self, root="c_thorax") -> Iterator[tuple[BodySegment, BodySegment]]:
         root = _seg(root)
         if root not in self._children:

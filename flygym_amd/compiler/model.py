@@ -44,6 +44,17 @@ _VERSION = 3
 _DT = {np.dtype(np.float64): 0, np.dtype(np.int32): 1}
 
 
+class CompiledData:
+    """Initial state of a compiled world (the counterpart of the ``mj_data`` the reference's ``compile()`` returns): the
+    "neutral" keyframe.  The engine keeps the live state of every world on the GPU (``HIPSimulation.field``)."""
+
+    def __init__(self, model: "CompiledModel"):
+        self.qpos = np.array(model["key_qpos"], dtype=np.float64)
+        self.qvel = np.zeros(model.nv)
+        self.ctrl = np.array(model["key_ctrl"], dtype=np.float64)
+        self.time = 0.0
+
+
 class CompiledModel(dict):
     """``dict[str, np.ndarray]`` with (de)serialisation; keys are the blob entry names."""
 
@@ -68,6 +79,15 @@ class CompiledModel(dict):
     def nseg(self): return int(self["seg_body"].shape[0])
     @property
     def nsite(self): return int(self["site_body"].shape[0])
+    # MuJoCo's names for the same counts (what reference code reads off ``mj_model``)
+    @property
+    def nbody(self): return self.nseg + 1                       # named segments + the world body
+    @property
+    def njnt(self): return self.nv - 6 + 1                      # hinges + the free joint
+    @property
+    def ngeom(self): return self.ng + 1                         # contact geoms + the ground
+    @property
+    def ncam(self): return int(self.meta.get("n_cameras", 0))
 
     # blob ----------------------------------------------------------------
     def to_blob(self) -> bytes:
@@ -485,6 +505,7 @@ def compile_world(world) -> CompiledModel:
     # structure summary for the star-of-chains fast path
     m["star"] = _star_structure(m)
     m.meta = {
+        "n_cameras": len(fly.cameraname_to_camera),
         "seg_names": seg_names,
         "dof_names": [d.name for d in jointdofs],
         "actuator_names": [a["name"] for a in fly.actuators],

@@ -108,6 +108,49 @@ class Fly:
             seg.is_leg() and seg.link == "tarsus5"
         )
 
+    def compile(self):
+        """``(model, data)`` of the fly on its own, as the reference's ``Fly.compile`` (``compose/base.py:21-27``): the
+        fly floating in empty space.  The reference's standalone fly has no free joint, so the summary counts only the
+        hinges (``nq == nv ==`` number of joint dofs); the engine's full model (with the free root it always simulates)
+        is ``model.compiled``.  Does not attach the fly to any world."""
+        from types import SimpleNamespace
+
+        from ..compiler.model import CompiledData
+        from ..utils.math import Rotation3D
+        from .world import _FreeSpaceWorld
+
+        world = _FreeSpaceWorld()
+        world.add_fly(self, (0.0, 0.0, 0.0), Rotation3D("quat", (1, 0, 0, 0)))
+        full = world.compile_model()
+        n_hinge = full.nv - 6
+        summary = SimpleNamespace(nq=n_hinge, nv=n_hinge, njnt=n_hinge, nu=full.nu, nbody=full.nbody, nsite=full.nsite,
+                                  ncam=full.ncam, ngeom=0, compiled=full)
+        data = CompiledData(full)
+        data.qpos, data.qvel = data.qpos[7:], data.qvel[6:]
+        return summary, data
+
+    # ---- the reference's lookup names (fly.py:160-170).  There they hold dm_control MJCF elements; here the same keys map
+    # to the plain records this package keeps, so code that counts, iterates or tests membership keeps working.
+    @property
+    def bodyseg_to_mjcfbody(self) -> dict:
+        return {seg: {"name": seg.name} for seg in self._bodysegs}
+
+    @property
+    def jointdof_to_mjcfjoint(self) -> dict:
+        return self.joint_params
+
+    @property
+    def jointdof_to_mjcfactuator_by_type(self) -> dict:
+        return self.jointdof_to_actuator_by_type
+
+    @property
+    def anatomicaljoint_to_mjcfsites(self) -> dict:
+        return self.anatomicaljoint_to_sites
+
+    @property
+    def cameraname_to_mjcfcamera(self) -> dict:
+        return self.cameraname_to_camera
+
     def get_bodysegs_order(self) -> list[BodySegment]:
         return list(self._bodysegs)
 

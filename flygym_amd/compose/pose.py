@@ -86,6 +86,10 @@ class KinematicPose:
 class KinematicPosePreset(Enum):
     NEUTRAL = "neutral"
 
+    def get_dir(self) -> Path:
+        """Directory of this preset's pose files, one YAML per axis order (reference ``pose.py:140-145``)."""
+        return Path(__file__).resolve().parents[1] / "assets" / "model" / "pose" / self.value
+
     def get_pose_by_axis_order(self, axis_order, mirror_left2right: bool = True) -> KinematicPose:
         from ..compiler.model import load_asset_pack
 

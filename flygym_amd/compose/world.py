@@ -65,12 +65,32 @@ class BaseWorld(ABC):
         self.world_dof_neutral_states[freejoint] = [*self.spawn_position, *spawn_rotation.values]
         self._compiled = None
 
-    def compile(self):
+    def compile_model(self):
+        """The engine's compiled model of this world (cached until the world changes)."""
         from ..compiler.model import compile_world
 
         if self._compiled is None:
             self._compiled = compile_world(self)
         return self._compiled
+
+    def compile(self):
+        """``(model, data)`` as the reference's ``BaseWorld.compile`` (``compose/base.py:21-27``) — here the engine's
+        :class:`~flygym_amd.compiler.model.CompiledModel` (sizes ``nq nv nu nbody njnt nsite ncam``, arrays by name) and
+        the keyframe state, not MuJoCo objects."""
+        from ..compiler.model import CompiledData
+
+        model = self.compile_model()
+        return model, CompiledData(model)
+
+
+class _FreeSpaceWorld(BaseWorld):
+    """No ground, no tether: what ``Fly.compile()`` compiles a standalone fly in."""
+
+    def __init__(self) -> None:
+        super().__init__("free_space")
+
+    def _attach_fly(self, fly, spawn_position, spawn_rotation) -> str:
+        return f"{fly.name}/"
 
 
 def _sort_prox2dist(segs: list[BodySegment]) -> list[BodySegment]:
@@ -175,9 +195,8 @@ class MixedTerrainWorld(_TerrainWorld):
 
 
 class TetheredWorld(BaseWorld):
-    """Fly body held in space (``world.py:334-366``).  The reference welds the thorax to the
-    world with a stiff soft constraint; the engine fixes the base kinematically instead
-    (root pose constant, root dofs removed from the solve) — see DESIGN.md."""
+    """Fly body held in space (``world.py:334-366``): the thorax is welded to its spawn pose by a stiff soft
+    constraint (six bilateral rows), as in the reference."""
 
     def __init__(self, name: str = "tethered_world") -> None:
         super().__init__(name)

@@ -55,7 +55,7 @@ class HIPSimulation:
         self._torch = torch
         self._lib = _native.lib()
 
-        self.model = world.compile()
+        self.model = world.compile_model()
         blob = self.model.to_blob()
         self._model_h = self._lib.nmf_model_create(blob, len(blob))
         if not self._model_h:
@@ -274,11 +274,11 @@ class HIPSimulation:
         return self.renderer.render_as_needed(self)
 
     def print_performance_report(self) -> None:
-        n = max(self._curr_step, 1)
-        us = self._total_physics_time_ns / 1e3 / n
-        rate = 1e6 / us if us > 0 else float("nan")
-        print(f"physics: {us:.1f} us/step  {rate:.0f} it/s  x{rate * self.timestep:.3f} realtime "
-              f"(x{rate * self.timestep * self.n_worlds:.1f} over {self.n_worlds} worlds)")
+        """Report of the steps taken with :meth:`step_with_profile` (reference ``warp/simulation.py:344-367``)."""
+        from .utils.profiling import print_perf_report_parallel
+
+        print_perf_report_parallel(self._total_physics_time_ns, self._total_render_time_ns, self._curr_step,
+                                   self._frames_rendered, self.timestep, self.n_worlds, 0)
 
 
 def _tensor_from_ptr(torch, ptr: int, shape, device):
@@ -296,6 +296,25 @@ def _tensor_from_ptr(torch, ptr: int, shape, device):
     return t[:n].reshape(shape)
 
 
+class _DataView:
+    """Read-only stand-in for ``mj_data`` on :class:`Simulation`: every attribute is a fresh float64 copy of world 0."""
+
+    _FIELDS = dict(qpos="qpos", qvel="qvel", ctrl="ctrl", qacc="qacc", qacc_warmstart="qacc_warmstart",
+                   actuator_force="actuator_force", sensordata="sensordata")
+
+    def __init__(self, batch):
+        self._batch = batch
+
+    def __getattr__(self, name):
+        if name in self._FIELDS:
+            return self._batch.field(self._FIELDS[name])[0].cpu().numpy().astype(np.float64)
+        if name == "site_xpos":
+            return self._batch.field("site_xpos")[0].cpu().numpy().astype(np.float64).reshape(-1, 3)
+        if name == "time":
+            return self._batch.time
+        raise AttributeError(f"mj_data.{name} is not available from the HIP engine; see HIPSimulation.field()")
+
+
 class Simulation:
     """Single-world simulation with the reference's CPU ``Simulation`` surface (``src/flygym/simulation.py:16-480``):
     unbatched numpy in, unbatched float64 numpy out — the physics still runs in the HIP engine (one wavefront).
@@ -307,9 +326,26 @@ class Simulation:
     """
 
     def __init__(self, world: BaseWorld, device: int | None = None) -> None:
+        from types import SimpleNamespace
+
         self.batch = HIPSimulation(world, 1, device=device)
         self.world = world
         self.renderer = None
+        m = self.batch.model
+        # the handful of MuJoCo attributes reference code reads most often; `mj_data` fields are copies off the GPU
+        self.mj_model = SimpleNamespace(opt=SimpleNamespace(timestep=self.batch.timestep), nq=m.nq, nv=m.nv, nu=m.nu,
+                                        nbody=m.nbody, njnt=m.njnt, nsite=m.nsite, compiled=m)
+        self.mj_data = _DataView(self.batch)
+
+    # profiling counters of the reference class (simulation.py:52-56), kept by the batch object
+    @property
+    def _curr_step(self): return self.batch._curr_step
+    @property
+    def _frames_rendered(self): return self.batch._frames_rendered
+    @property
+    def _total_physics_time_ns(self): return self.batch._total_physics_time_ns
+    @property
+    def _total_render_time_ns(self): return self.batch._total_render_time_ns
 
     # -- stepping
     def reset(self) -> None:

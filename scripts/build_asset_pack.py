@@ -60,6 +60,12 @@ def main():
     for f in sorted((assets / "model/pose/neutral").glob("*.yaml")):
         poses[f.stem] = yaml.safe_load(f.read_text())
     pack["neutral_pose_json"] = np.array(json.dumps(poses))
+    # the same poses as YAML files next to the pack: `flygym_amd.assets_dir / "model/pose/neutral/<axis order>.yaml"`
+    # is the path the reference's tutorials hand to KinematicPose(path=...)
+    pose_dir = Path(args.out).parent / "model/pose/neutral"
+    pose_dir.mkdir(parents=True, exist_ok=True)
+    for stem, doc in poses.items():
+        (pose_dir / f"{stem}.yaml").write_text(yaml.safe_dump(doc, sort_keys=True))
 
     for mesh_type in ("simplified_max2000faces", "fullsize"):
         d = assets / "model/meshes" / mesh_type

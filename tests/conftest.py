@@ -19,7 +19,7 @@ def bench_model():
     from flygym_amd.models import make_model
 
     fly, world, _ = make_model()
-    return fly, world, world.compile()
+    return fly, world, world.compile_model()
 
 
 @pytest.fixture(scope="session")

@@ -23,7 +23,7 @@ def trajectories():
 
     out = {}
     fly, world, _ = make_model()
-    m = world.compile()
+    m = world.compile_model()
     o = orc.Oracle(m.to_blob(), "f64")
     o.ctrl[42:] = 1.0
     o.step(500)
@@ -46,7 +46,7 @@ def trajectories():
     fly.add_leg_adhesion()
     world = C.FlatGroundWorld()
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
-    o = orc.Oracle(world.compile().to_blob(), "f64")
+    o = orc.Oracle(world.compile_model().to_blob(), "f64")
     o.ctrl[42:] = 1.0
     o.step(400)
     out["all_biological_settled_qpos"] = o.qpos.copy()

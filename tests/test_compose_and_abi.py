@@ -77,7 +77,7 @@ def test_compose_errors_and_variants():
         world.add_fly(fly, (0, 0, 1), Rotation3D("euler", (0, 0, 0)))
     world = FlatGroundWorld()
     world.add_fly(fly, (0, 0, 1), Rotation3D("quat", (1, 0, 0, 0)), ground_contact_params=ContactParams(sliding_friction=2.0))
-    m = world.compile()
+    m = world.compile_model()
     assert m.nv == 48 and m.nu == 6 and list(m["star"]) == [1, 6, 7, 4]
     assert (m["geom_type"] == 0).all()            # every collision geom is a capsule
     assert m["pair_friction"][0][0] == 2.0

@@ -522,8 +522,14 @@ def test_single_world_simulation_mirrors_the_cpu_class(torch_mod, bench_model, o
         sim.set_actuator_inputs(fly.name, "position", np.zeros(41))
     with pytest.raises(ValueError, match="Unexpected number of adhesion states"):
         sim.set_leg_adhesion_states(fly.name, np.ones(5))
+    # the MuJoCo attributes reference code reads most (tests/core/test_simulation.py): timestep, sizes, state copies
+    assert sim.mj_model.opt.timestep == pytest.approx(1e-4) and sim.mj_model.nv == 72
+    assert sim.mj_data.qpos.shape == (73,) and sim.mj_data.time == pytest.approx(sim.time)
+    sim.step_with_profile()
+    assert sim._curr_step == 1 and sim._total_physics_time_ns > 0 and sim._frames_rendered == 0
+    sim.print_performance_report()
     sim.reset()
-    assert sim.time == 0.0 and np.allclose(sim.get_joint_angles(fly.name), q0)
+    assert sim.time == 0.0 and np.allclose(sim.get_joint_angles(fly.name), q0) and sim._curr_step == 0
 
 
 @pytest.mark.parametrize("preset,nv", [("ALL_BIOLOGICAL", 132), ("ALL_POSSIBLE", 210)])

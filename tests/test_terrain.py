@@ -28,13 +28,13 @@ def test_height_functions():
     assert m.terrain_height(1.0, 0.3) == 0.0                       # flat stripe
     assert m.terrain_height(4.0 + 1.1, 0.3) == -2.0                # gapped stripe, inside a gap
     assert m.terrain_height(8.0 + 1.5, 0.5) == 0.35                # blocks stripe, raised square
-    assert m.compile()["terrain_params"][4] == 0.35 and int(m.compile()["terrain_type"][0]) == 3
+    assert m.compile_model()["terrain_params"][4] == 0.35 and int(m.compile_model()["terrain_type"][0]) == 3
 
 
 @pytest.mark.parametrize("cls", [C.GappedTerrainWorld, C.BlocksTerrainWorld, C.MixedTerrainWorld])
 def test_oracle_contacts_sit_on_the_terrain(cls, oracle_lib):
     fly, world = _world(cls)
-    m = world.compile()
+    m = world.compile_model()
     o = oracle_lib.Oracle(m.to_blob(), "f64")
     o.ctrl[42:] = 1.0
     o.step(1200)
