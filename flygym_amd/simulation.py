@@ -66,6 +66,14 @@ class HIPSimulation:
             raise _native.NativeError(self._lib.nmf_last_error().decode())
         self._views = {}
         self._build_index_maps()
+        # the MuJoCo attributes reference code reads most often (the reference's GPUSimulation keeps a CPU mj_model /
+        # mj_data of world 0 next to the device arrays); `mj_data` fields are float64 copies of world 0 off the GPU
+        from types import SimpleNamespace
+
+        m = self.model
+        self.mj_model = SimpleNamespace(opt=SimpleNamespace(timestep=float(m["opt_timestep"][0])), nq=m.nq, nv=m.nv, nu=m.nu,
+                                        nbody=m.nbody, njnt=m.njnt, nsite=m.nsite, compiled=m)
+        self.mj_data = _DataView(self)
         self._curr_step = 0
         self._frames_rendered = 0
         self._total_physics_time_ns = 0
@@ -326,16 +334,10 @@ class Simulation:
     """
 
     def __init__(self, world: BaseWorld, device: int | None = None) -> None:
-        from types import SimpleNamespace
-
         self.batch = HIPSimulation(world, 1, device=device)
         self.world = world
         self.renderer = None
-        m = self.batch.model
-        # the handful of MuJoCo attributes reference code reads most often; `mj_data` fields are copies off the GPU
-        self.mj_model = SimpleNamespace(opt=SimpleNamespace(timestep=self.batch.timestep), nq=m.nq, nv=m.nv, nu=m.nu,
-                                        nbody=m.nbody, njnt=m.njnt, nsite=m.nsite, compiled=m)
-        self.mj_data = _DataView(self.batch)
+        self.mj_model, self.mj_data = self.batch.mj_model, self.batch.mj_data
 
     # profiling counters of the reference class (simulation.py:52-56), kept by the batch object
     @property
