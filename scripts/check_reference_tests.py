@@ -25,7 +25,7 @@ for _m in ("mujoco", "dm_control", "dm_control.mjcf"):
 sys.modules["dm_control"].mjcf = sys.modules["dm_control.mjcf"]
 import flygym_amd
 for k in ("", ".anatomy", ".compose", ".compose.fly", ".compose.world", ".compose.pose", ".compose.physics", ".utils",
-          ".utils.math", ".utils.exceptions", ".utils.profiling", ".simulation"):
+          ".utils.math", ".utils.exceptions", ".utils.profiling", ".utils.pose_conversion", ".simulation"):
     sys.modules["flygym" + k] = importlib.import_module("flygym_amd" + k)
 spec = importlib.util.spec_from_file_location("ref_conftest", {str(ref / "tests/conftest.py")!r})
 mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
