@@ -137,3 +137,63 @@ def test_product_never_imports_the_oracle():
         text = f.read_text()
         assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
         assert "nmf_oracle" not in text or "oracle/nmf_oracle.c" in text, f   # comments may cite it
+
+
+def test_reference_utility_surface(bench_model, capsys):
+    """Helpers user code imports from the reference's ``flygym.utils`` / ``flygym.compose`` (``utils/math.py``,
+    ``utils/exceptions.py``, ``utils/profiling.py``, ``utils/pose_conversion.py``, ``compose/base.py::compile``)."""
+    import flygym_amd
+    from flygym_amd.anatomy import AxisOrder, JointPreset, Skeleton
+    from flygym_amd.compose import KinematicPose, KinematicPosePreset
+    from flygym_amd.utils.exceptions import FlyGymInternalError
+    from flygym_amd.utils.math import Tree, orderedset
+    from flygym_amd.utils.pose_conversion import get_body_names, get_xpos0_xquat0, qpos_to_kinematic_pose
+    from flygym_amd.utils.profiling import print_perf_report, print_perf_report_parallel
+
+    assert orderedset([3, 1, 3, 2, 1]) == [3, 1, 2]
+    tree = Tree(["a", "b", "c", "d"], [("a", "b"), ("a", "c"), ("c", "d")])
+    assert list(tree.dfs_edges("a")) == [("a", "b"), ("a", "c"), ("c", "d")]
+    assert list(tree.dfs_edges("d"))[0] == ("d", "c")
+    for nodes, edges in (([1, 2, 3], [(1, 2), (2, 3), (3, 1)]), ([1, 2, 3, 4], [(1, 2), (3, 4)]), ([1, 2], [(1, 2), (1, 2)]),
+                         ([1, 2], [(1, 2), (1, 1)]), ([1, 1, 2], [(1, 2)]), ([1, 2], [(1, 99)])):
+        with pytest.raises(ValueError):
+            Tree(nodes, edges)
+    with pytest.raises(ValueError):
+        list(tree.dfs_edges("zz"))
+    assert issubclass(FlyGymInternalError, Exception)
+    sk = Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.ALL_BIOLOGICAL)
+    assert len(list(sk.get_tree().dfs_edges(sk.body_segments[0]))) == len(sk.body_segments) - 1
+    # pose files on disk, as the reference's tutorials address them
+    path = flygym_amd.assets_dir / "model/pose/neutral/pitch_roll_yaw.yaml"
+    assert path.is_file() and KinematicPosePreset.NEUTRAL.get_dir() == path.parent
+    pose = KinematicPose(path=path)
+    assert pose.axis_order is AxisOrder.PITCH_ROLL_YAW and len(pose.joint_angles_lookup_rad) > 60
+    with pytest.raises(ValueError, match="axis_order"):
+        KinematicPose(path=path, axis_order=AxisOrder.PITCH_ROLL_YAW)
+    # compile() -> (model, data) for worlds and standalone flies
+    fly, world, m = bench_model
+    model, data = world.compile()
+    assert model is m and data.qpos.shape == (73,) and data.ctrl.shape == (48,) and data.time == 0.0
+    assert (model.nq, model.nv, model.nu, model.nbody, model.njnt) == (73, 72, 48, 70, 67)
+    from flygym_amd.compose import Fly
+
+    bare = Fly(name="bare")
+    bare.add_joints(Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.LEGS_ONLY),
+                    neutral_pose=KinematicPosePreset.NEUTRAL)
+    fm, fd = bare.compile()
+    assert fm.nv == fm.nq == 66 and fd.qpos.shape == (66,) and fm.compiled.nv == 72
+    names = get_body_names(fm)
+    assert names[0] == "world" and len(names) == fm.nbody == 70
+    xpos, xquat = get_xpos0_xquat0(fm, fd)
+    assert xpos.shape == (70, 3) and np.allclose(np.linalg.norm(xquat[1:], axis=1), 1.0, atol=1e-9)
+    back = qpos_to_kinematic_pose(fm, fd.qpos, AxisOrder.YAW_PITCH_ROLL)
+    ref = KinematicPosePreset.NEUTRAL.get_pose_by_axis_order(AxisOrder.YAW_PITCH_ROLL)
+    key = "c_thorax-rf_coxa-roll"
+    assert back.joint_angles_lookup_rad[key] == pytest.approx(ref.joint_angles_lookup_rad[key])      # mirrored from the left
+    # performance reports
+    print_perf_report(1_000_000, 500_000, 100, 10, 1e-3)
+    print_perf_report_parallel(1_000_000, 0, 100, 0, 1e-3, 8, 0)
+    out = capsys.readouterr().out
+    assert "PERFORMANCE" in out and "Physics" in out and "No frames" in out and "parallelized" in out.lower()
+    with pytest.raises(ValueError, match="n_steps"):
+        print_perf_report(1, 0, 0, 0, 1e-3)
