@@ -24,12 +24,21 @@ class MotionSnippet:
             self.legs = [str(x) for x in pack["clip_legs"]]
             self.dofs_per_leg = [tuple(str(y) for y in row) for row in pack["clip_dofs_per_leg"]]
             self.data_fps = float(pack["clip_fps"])
+            self.rawpred_egoxyz = pack["clip_rawpred_egoxyz"].copy()
+            self.fwdkin_egoxyz = pack["clip_fwdkin_egoxyz"].copy()
+            self.keypoints = [tuple(str(y) for y in row) for row in pack["clip_keypoints"]]
+            self.experiment_trial = str(pack["clip_experiment_trial"])
+            self.framerange_in_raw_recording = [int(x) for x in pack["clip_framerange"]]
         else:
             data = np.load(data_path, allow_pickle=True)
             self.joint_angles = data["joint_angles"].copy()
             self.legs = data["legs"].tolist()
             self.dofs_per_leg = [tuple(x) for x in data["dofs_per_leg"].tolist()]
             self.data_fps = float(data["data_fps"].item())
+            self.rawpred_egoxyz, self.fwdkin_egoxyz = data["rawpred_egoxyz"], data["fwdkin_egoxyz"]
+            self.keypoints = [tuple(x) for x in data["keypoints"].tolist()]
+            self.experiment_trial = data["experiment_trial"].item()
+            self.framerange_in_raw_recording = data["framerange_in_raw_recording"].tolist()
         if angles_global2anatomical:
             # right-leg roll / yaw change sign: global (IK) convention -> anatomical (:59-78)
             right = [i for i, leg in enumerate(self.legs) if leg[0] == "r"]

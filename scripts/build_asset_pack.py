@@ -88,6 +88,11 @@ def main():
     pack["clip_legs"] = np.array([str(x) for x in clip["legs"].tolist()])
     pack["clip_dofs_per_leg"] = np.array([[str(y) for y in x] for x in clip["dofs_per_leg"].tolist()])
     pack["clip_fps"] = np.array(float(clip["data_fps"].item()))
+    pack["clip_rawpred_egoxyz"] = clip["rawpred_egoxyz"].astype(np.float32)      # keypoint tracks of the recording
+    pack["clip_fwdkin_egoxyz"] = clip["fwdkin_egoxyz"].astype(np.float32)
+    pack["clip_keypoints"] = np.array([[str(y) for y in x] for x in clip["keypoints"].tolist()])
+    pack["clip_experiment_trial"] = np.array(str(clip["experiment_trial"].item()))
+    pack["clip_framerange"] = np.asarray(clip["framerange_in_raw_recording"], dtype=np.int64)
 
     out = Path(args.out)
     out.parent.mkdir(parents=True, exist_ok=True)
