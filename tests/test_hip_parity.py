@@ -621,3 +621,39 @@ def test_every_segment_in_contact_69_geoms(torch_mod, oracle_lib):
     assert most >= 8 and int(sim.field("stats")[0, 2].item()) == 0          # many contacts, no overflow
     geoms = set(o.ints()["con_geom"])
     assert max(geoms) >= 64 or most >= 8                                     # geoms of the second pass can be hit
+
+
+def test_joint_sites_and_profile_counters(torch_mod, oracle_lib):
+    """Reference tests/warp/test_simulation.py::TestSiteStateQueries / TestReset: sites added with add_joint_sites are
+    reported in fly order with shape (n_worlds, n_sites, 3) and agree with the CPU-side model (here: the oracle) to 1e-6
+    at reset and after stepping; reset clears time and the profiling counters."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = C.Fly(name="sites")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    fly.add_actuators(sk.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    joints = [j for j in sk.anatomical_joints if j.child.name.endswith(("tibia", "tarsus5"))]
+    fly.add_joint_sites(joints)
+    world = C.FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    sim = HIPSimulation(world, n_worlds=3, device=0)
+    o = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+    assert len(joints) == 12 and len(fly.get_sites_order()) == 12
+    sites = sim.get_site_positions(fly.name)
+    assert tuple(sites.shape) == (3, 12, 3)
+    np.testing.assert_allclose(sites[0].cpu().numpy(), o.arr("site_xpos").reshape(-1, 3), atol=1e-6)
+    np.testing.assert_allclose(sim.mj_data.site_xpos, o.arr("site_xpos").reshape(-1, 3), atol=1e-6)
+    for _ in range(3):
+        sim.step_with_profile()
+    o.step(3)
+    np.testing.assert_allclose(sim.get_site_positions(fly.name)[2].cpu().numpy(), o.arr("site_xpos").reshape(-1, 3), atol=2e-6)
+    assert sim._curr_step == 3 and sim._total_physics_time_ns > 0 and sim.time == pytest.approx(3e-4)
+    sim.reset()
+    assert sim.time == 0.0 and sim._curr_step == 0 and sim._total_physics_time_ns == 0
+    assert sim.n_worlds == 3 and isinstance(sim.time, float)
