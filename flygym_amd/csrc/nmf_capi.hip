@@ -176,7 +176,9 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
   if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
   else if (b->topo == 1) { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
   else if (b->topo == 2) { if (weld) NMF_LAUNCH(nmf::TreeTopoSmall, true); else NMF_LAUNCH(nmf::TreeTopoSmall, false); }
-  else { if (weld) NMF_LAUNCH(nmf::TreeTopo, true); else NMF_LAUNCH(nmf::TreeTopo, false); }
+  else if (b->topo == 3) { if (weld) NMF_LAUNCH(nmf::TreeTopo, true); else NMF_LAUNCH(nmf::TreeTopo, false); }
+  else if (b->topo == 4) { if (weld) NMF_LAUNCH(nmf::FlyTopoBio, true); else NMF_LAUNCH(nmf::FlyTopoBio, false); }
+  else { if (weld) NMF_LAUNCH(nmf::FlyTopoAll, true); else NMF_LAUNCH(nmf::FlyTopoAll, false); }
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -200,10 +202,31 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     for (int b = 1; ok && b < 1 + 6 * nbl; ++b) ok = dn->i[(size_t)b] == pat[(b - 1) % nbl];
     if (!ok || model->nu > nmf::kMaxCtrl) topo = -1;
   }
-  // anything else (ALL_BIOLOGICAL, ALL_POSSIBLE, custom skeletons): the general-tree kernel, up to 72 bodies / 216 dofs
-  std::vector<int> tree_body, child_start, child_count, lvl_start;
+  // the full-body skeletons (ALL_BIOLOGICAL, ALL_POSSIBLE): six identical leg chains at the END of the body order, the
+  // rest of the body (20 bodies, 60 dofs) between the root and the legs -> hybrid kernels (legs unrolled, rest as a tree)
+  std::vector<char> in_tree;          // bodies the tree tables cover (hybrid: root + rest; tree kernels: all)
   if (topo < 0) {
-    topo = model->nv <= nmf::TreeTopoSmall::NV && model->nu <= nmf::TreeTopoSmall::kCtrl ? 2 : 3;
+    const HostArray* bp = model->find("body_parent");
+    const HostArray* dn = model->find("body_dofnum");
+    const int patB[8] = {3, 2, 1, 1, 1, 1, 1, 1}, patA[8] = {3, 3, 3, 3, 3, 3, 3, 3};
+    for (int cand = 4; cand <= 5 && topo < 0 && bp && dn; ++cand) {
+      const int* pat = cand == 4 ? patB : patA;
+      const int nb = model->nb, lb0 = 21, want_nv = cand == 4 ? 132 : 210;
+      bool ok = nb == 69 && model->nv == want_nv && (int)dn->i.size() == nb && dn->i[0] == 6;
+      int rest_v = 0;
+      for (int bb = 1; ok && bb < lb0; ++bb) { rest_v += dn->i[(size_t)bb]; ok = bp->i[(size_t)bb] >= 0 && bp->i[(size_t)bb] < lb0 && bp->i[(size_t)bb] < bb; }
+      ok = ok && rest_v == 60;
+      for (int bb = lb0; ok && bb < nb; ++bb) {
+        const int l = (bb - lb0) % 8;
+        ok = dn->i[(size_t)bb] == pat[l] && bp->i[(size_t)bb] == (l == 0 ? 0 : bb - 1);
+      }
+      if (ok) { topo = cand; in_tree.assign((size_t)nb, 0); for (int bb = 0; bb < lb0; ++bb) in_tree[(size_t)bb] = 1; }
+    }
+  }
+  // anything else (custom skeletons): the general-tree kernel, up to 72 bodies / 216 dofs
+  std::vector<int> tree_body, child_start, child_count, lvl_start;
+  if (topo < 0 || topo >= 4) {
+    if (topo < 0) topo = model->nv <= nmf::TreeTopoSmall::NV && model->nu <= nmf::TreeTopoSmall::kCtrl ? 2 : 3;
     const HostArray* bp = model->find("body_parent");
     const HostArray* dn = model->find("body_dofnum");
     const HostArray* gb = model->find("geom_body");
@@ -211,6 +234,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       fail("nmf_batch_create: the general-tree kernel takes a free-floating root and up to 72 bodies / 216 dofs"); return nullptr;
     }
     const int nb = model->nb;
+    if (in_tree.empty()) in_tree.assign((size_t)nb, 1);
     for (int bb = 1; bb < nb; ++bb)
       if (bp->i[(size_t)bb] < 0 || bp->i[(size_t)bb] >= bb) { fail("nmf_batch_create: bodies must be ordered parents first"); return nullptr; }
     for (size_t g = 1; g < gb->i.size(); ++g)
@@ -218,7 +242,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     // breadth-first order: level by level, the children of a body contiguous
     std::vector<int> depth((size_t)nb, 0);
     int maxd = 0;
-    for (int bb = 1; bb < nb; ++bb) { depth[(size_t)bb] = depth[(size_t)bp->i[(size_t)bb]] + 1; maxd = std::max(maxd, depth[(size_t)bb]); }
+    for (int bb = 1; bb < nb; ++bb) {
+      depth[(size_t)bb] = depth[(size_t)bp->i[(size_t)bb]] + 1;
+      if (in_tree[(size_t)bb]) maxd = std::max(maxd, depth[(size_t)bb]);
+    }
     if (maxd + 2 > 18) { fail("nmf_batch_create: kinematic tree deeper than 16 levels"); return nullptr; }
     tree_body.push_back(0); lvl_start.push_back(0);
     child_start.assign((size_t)nb, 0); child_count.assign((size_t)nb, 0);
@@ -228,7 +255,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       for (int k = k0; k < k1; ++k) {
         const int par = tree_body[(size_t)k];
         child_start[(size_t)par] = (int)tree_body.size();
-        for (int bb = 1; bb < nb; ++bb) if (bp->i[(size_t)bb] == par) { tree_body.push_back(bb); child_count[(size_t)par]++; }
+        for (int bb = 1; bb < nb; ++bb) if (bp->i[(size_t)bb] == par && in_tree[(size_t)bb]) { tree_body.push_back(bb); child_count[(size_t)par]++; }
       }
       if (k1 - k0 > nmf::kWave) { fail("nmf_batch_create: more than 64 bodies on one tree level"); return nullptr; }
     }
@@ -313,7 +340,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     st.sched = nullptr;
     st.order = nullptr;
     hipDeviceProp_t prop;
-    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : 3);      // flies per CU: LDS-limited (18 / 35 / 43 KB per fly)
+    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 5 : 4)));   // flies per CU: LDS-limited
     b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;
   }
   if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {

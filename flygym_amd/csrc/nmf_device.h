@@ -25,15 +25,23 @@ enum { ACT_POSITION = 0, ACT_ADHESION = 1, ACT_MOTOR = 2 };
 // hinge counts of the chain's bodies from the root outwards (LEGS_ONLY leg: 3,2,1,1,1,1,1,1).
 // Everything about the chain layout is a compile-time constant so that the leg sweeps unroll
 // completely and never load structure from memory.
-template <int NLEG_, int... DOFS>
-struct Topo {
+// REST_B / REST_V: bodies / dofs of the "rest" of the fly (head, antennae, proboscis, abdomen, wings, halteres) that sit
+// between the root and the legs in the model's order; they are swept by the general-tree code (nmf_tree.h), the legs by
+// the unrolled chain code.  Leg-only skeletons have no rest.
+template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
+struct HybridTopo {
   static constexpr bool kStar = true;
-  static constexpr int kCtrl = kMaxCtrl;
+  static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 6 + REST_V_ + NLEG_ * (DOFS + ...) + 8;
+  static constexpr int REST_B = REST_B_, REST_V = REST_V_;
   static constexpr int NLEG = NLEG_;
   static constexpr int NBL = sizeof...(DOFS);
   static constexpr int NDL = (DOFS + ...);
-  static constexpr int NB = 1 + NLEG_ * NBL;
-  static constexpr int NV = 6 + NLEG_ * NDL;
+  static constexpr int LB0 = 1 + REST_B_;        // first leg body
+  static constexpr int LD0 = 6 + REST_V_;        // first leg dof
+  static constexpr int kFact0 = 6, kSlot0 = 1;   // the rest dofs / bodies only (tree sweeps); legs and root keep theirs in registers
+  static constexpr int kNFact = REST_V_ > 0 ? REST_V_ : 1, kNSlot = REST_B_ > 0 ? REST_B_ : 1;
+  static constexpr int NB = LB0 + NLEG_ * NBL;
+  static constexpr int NV = LD0 + NLEG_ * NDL;
   static constexpr int NQ = NV + 1;
   static constexpr int dofs(int l) { constexpr int t[] = {DOFS...}; return t[l]; }
   static constexpr int first_dof(int l) { int a = 0; for (int i = 0; i < l; ++i) a += dofs(i); return a; }
@@ -41,6 +49,8 @@ struct Topo {
   static constexpr bool is_last(int d) { return d == first_dof(lbody(d)) + dofs(lbody(d)) - 1; }
   static constexpr bool is_first(int d) { return d == first_dof(lbody(d)); }
 };
+template <int NLEG_, int... DOFS>
+using Topo = HybridTopo<0, 0, NLEG_, DOFS...>;
 
 // A general kinematic tree (nmf_tree.h): LDS arrays sized for NB_ bodies / NV_ dofs, the actual counts are run-time
 // values of the model.  Two sizes are built: 72 x 144 (ALL_BIOLOGICAL: 69 bodies, 132 dofs; 4 flies per CU) and
@@ -50,6 +60,8 @@ struct TreeTopoT {
   static constexpr bool kStar = false;
   static constexpr int NB = NB_, NV = NV_, NQ = NV_ + 1;
   static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
+  static constexpr int kFact0 = 0, kSlot0 = 1;      // every dof has articulated-body factors, every non-root body a hand-off slot
+  static constexpr int kNFact = NV_, kNSlot = NB_;
 };
 using TreeTopo = TreeTopoT<72, 216>;
 using TreeTopoSmall = TreeTopoT<72, 144>;

@@ -46,13 +46,18 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #endif
 
 // LDS used by the general-tree sweeps only (nmf_tree.h)
-template <class TP, bool STAR = TP::kStar>
+template <class TP, bool STAR = TP::kStar, bool REST = (TP::kNFact > 1)>
 struct TreeLds {};
 template <class TP>
-struct TreeLds<TP, false> {
-  float fact[TP::NV][8];      // articulated-body factors per dof: U (6), u, 1/D — written going up, read going down
-  float slot[TP::NB][27];     // articulated inertia (symmetric, 21) + bias wrench (6) a body hands to its parent
+struct TreeLds<TP, false, true> {
+  float fact[TP::kNFact][8];  // articulated-body factors per dof: U (6), u, 1/D — written going up, read going down
+  float slot[TP::kNSlot][27]; // articulated inertia (symmetric, 21) + bias wrench (6) a body hands to its parent
   int rt_nb, rt_nv;
+};
+template <class TP>
+struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodies only
+  float fact[TP::kNFact][8];
+  float slot[TP::kNSlot][27];
 };
 
 template <class TP>
@@ -124,10 +129,10 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
 template <class TP>
 __device__ __forceinline__ int dof_body_of(int j) {
   if (j < 6) return 0;
-  const int leg = (j - 6) / TP::NDL, d = (j - 6) % TP::NDL;
+  const int leg = (j - TP::LD0) / TP::NDL, d = (j - TP::LD0) % TP::NDL;     // leg dofs only (j >= LD0)
   int lb = 0;
   static_for<TP::NBL - 1>([&](auto I) { constexpr int l = decltype(I)::value; lb += d >= TP::first_dof(l + 1) ? 1 : 0; });
-  return 1 + leg * TP::NBL + lb;
+  return TP::LB0 + leg * TP::NBL + lb;
 }
 
 // ------------------------------------------------------------------ lane roles
@@ -155,6 +160,18 @@ template <class TP, class Extra, class Emit>
 __device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit);
 template <class TP, bool WELD>
 __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane);
+template <class TP> __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane);
+template <class TP, class Extra>
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra);
+template <class F> __device__ __forceinline__ void tree_down(const DevModel& m, int lane, F&& f);
+template <class F> __device__ __forceinline__ void tree_up(const DevModel& m, int lane, F&& f);
+struct Frame;
+template <class TP, bool WELD>
+__device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
+                                                        const DevModel& m, const Frame& fr);
+template <class TP>
+__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m);
 
 // ------------------------------------------------------------------ kinematics
 template <class TP>
@@ -180,9 +197,11 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   for (int b = 1 + lane; b < s.nb(); b += kWave) {
     int adr, num;
     if constexpr (TP::kStar) {
-      const int lb = (b - 1) % TP::NBL;
-      adr = 6 + ((b - 1) / TP::NBL) * TP::NDL; num = 0;
-      static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
+      if (b >= TP::LB0) {
+        const int lb = (b - TP::LB0) % TP::NBL;
+        adr = TP::LD0 + ((b - TP::LB0) / TP::NBL) * TP::NDL; num = 0;
+        static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
+      } else { adr = m.body_dofadr[b]; num = m.body_dofnum[b]; }     // hybrid: the rest of the body (tree part)
     } else { adr = m.body_dofadr[b]; num = m.body_dofnum[b]; }
     Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
     for (int j = adr + num - 1; j >= adr; --j) {
@@ -195,13 +214,14 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   WSYNC();
   if constexpr (!TP::kStar) tree_kinematics_chain(s, m, lane, relm);
   else {
+    if constexpr (TP::REST_B > 0) tree_kinematics_chain(s, m, lane, relm);     // head, abdomen, wings, ...: tree levels
     // chain of rigid transforms down each leg: lane (leg, r < 3) carries row r of the rotation and
     // component r of the position:  R_b = R_parent * Rrel_b ,  p_b = p_parent + R_parent * off_b
     const LaneRole L = lane_role<TP>(lane);
     const int r3 = L.r < 3 ? L.r : 2;
     float R0 = s.xmat[0][3 * r3], R1 = s.xmat[0][3 * r3 + 1], R2 = s.xmat[0][3 * r3 + 2];
     float p = s.xpos[0][r3];
-    const int b0 = 1 + L.lg * TP::NBL;
+    const int b0 = TP::LB0 + L.lg * TP::NBL;
     static_for<TP::NBL>([&](auto I) {
       constexpr int l = decltype(I)::value;
       const float* M = relm[b0 + l];
@@ -226,7 +246,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       S.l = v3(0.f, 0.f, 0.f);
     } else {
       int b;
-      if constexpr (TP::kStar) b = dof_body_of<TP>(j); else b = m.dof_body[j];
+      if constexpr (TP::kStar) b = j >= TP::LD0 ? dof_body_of<TP>(j) : m.dof_body[j]; else b = m.dof_body[j];
       V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
       V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
       S.a = a;
@@ -463,13 +483,14 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 #pragma unroll
   for (int j = 0; j < 6; ++j) t += x[j] * s.S[j][L.rr];
   if (lane < 6) T[0][lane] = t;
-  const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
+  const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_for<TP::NDL>([&](auto D) {
     constexpr int d = decltype(D)::value;
     t += x[j0 + d] * s.S[j0 + d][L.rr];
     if constexpr (TP::is_last(d)) T[b0 + TP::lbody(d)][L.rr] = t;
   });
   WSYNC();
+  if constexpr (TP::REST_B > 0) tree_sweep_twists_levels(s, x, T, m, lane);
   }
 }
 
@@ -478,8 +499,9 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 template <class TP, class Emit>
 __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Emit&& emit) {
   if constexpr (!TP::kStar) { tree_sweep_project(s, W, m, lane, [](int, SV w) { return w; }, emit); return; } else {
+  if constexpr (TP::REST_B > 0) tree_gather_levels(s, W, m, lane, [](int, SV w) { return w; });
   const LaneRole L = lane_role<TP>(lane);
-  const int b0 = 1 + L.lg * TP::NBL;
+  const int b0 = TP::LB0 + L.lg * TP::NBL;
   float acc = 0.f;
   static_for<TP::NBL>([&](auto I) {
     constexpr int l = TP::NBL - 1 - decltype(I)::value;
@@ -491,11 +513,14 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
   if (lane < 6) {
     float a0 = W[0][lane];
 #pragma unroll
-    for (int k = 0; k < TP::NLEG; ++k) a0 += W[1 + k * TP::NBL][lane];
+    for (int k = 0; k < TP::NLEG; ++k) a0 += W[TP::LB0 + k * TP::NBL][lane];
+    if constexpr (TP::REST_B > 0)
+      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) a0 += W[m.tree_body[k]][lane];
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[dof_body_of<TP>(j)])));
+  for (int j = lane; j < TP::NV; j += kWave)
+    emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : m.dof_body[j]])));
   WSYNC();
   }
 }
@@ -580,7 +605,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   float* x = s.vec(x_id);
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const LaneRole L = lane_role<TP>(lane);
-  const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
+  const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
   AbaHandoff<TP>& H = *reinterpret_cast<AbaHandoff<TP>*>(&s.T[0][0]);
   // offsets of row rr inside the symmetric storage (lane constants)
@@ -594,6 +619,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   int cs[TP::NBL + 1], cs_root0 = 0, cs_root1 = 0;                         // contact ranges of the leg's bodies / the root
   static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK ? s.body_cstart[b0 + l] : 0; });
   if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
+  // hybrid: the rest of the body (head, abdomen, wings, ...) is eliminated level by level first; its children-of-root
+  // hand their articulated inertias to the root below through s.slot
+  if constexpr (TP::REST_B > 0)
+    tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
   float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float pA = 0.f;
   // ---- backward sweep along the leg
@@ -638,6 +667,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       for (int i = 0; i < 6; i++) row[i] += H.legIA[k][L.rr][i];
       pA += H.legpA[k][L.rr];
     }
+    if constexpr (TP::REST_B > 0) {
+      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) {
+        const float* sl = s.slot[m.tree_body[k] - TP::kSlot0];
+#pragma unroll
+        for (int i = 0; i < 6; i++) row[i] += sl[so[i]];
+        pA += sl[21 + L.rr];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) IA[i] = row[i];
     static_for<6>([&](auto DD) {
@@ -668,6 +705,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
   });
   WSYNC();
+  if constexpr (TP::REST_B > 0)
+    tree_down(m, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[m.body_parent[b]]), x, m); });
   }
 }
 
@@ -753,8 +792,14 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     }, emit);
     return;
   } else {
+  if constexpr (TP::REST_B > 0)      // head / abdomen / wing contacts: tree levels of the rest of the body
+    tree_gather_levels(s, s.W, m, lane, [&](int b, SV w) {
+      SV own = SEEDED ? seed_scale * w : SV{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+      for (int cc = s.body_cstart[b]; cc < s.body_cstart[b + 1]; ++cc) own = own + ldsv(s.c_w[cc]);
+      return own;
+    });
   const LaneRole L = lane_role<TP>(lane);
-  const int b0 = 1 + L.lg * TP::NBL;
+  const int b0 = TP::LB0 + L.lg * TP::NBL;
   float acc = 0.f;
   int cs[TP::NBL + 1];                       // contact ranges of the leg's bodies, fetched in one batch
   static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = s.body_cstart[b0 + l]; });
@@ -770,11 +815,14 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     if (SEEDED) a0 += seed_scale * s.W[0][lane];
     for (int cc = s.body_cstart[0]; cc < s.body_cstart[1]; ++cc) a0 += s.c_w[cc][lane];
 #pragma unroll
-    for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[1 + k * TP::NBL][lane];
+    for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[TP::LB0 + k * TP::NBL][lane];
+    if constexpr (TP::REST_B > 0)
+      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) a0 += s.W[m.tree_body[k]][lane];
     s.W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(s.W[dof_body_of<TP>(j)])));
+  for (int j = lane; j < TP::NV; j += kWave)
+    emit(j, dot(ldsv(s.S[j]), ldsv(s.W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : m.dof_body[j]])));
   WSYNC();
   }
 }
@@ -864,8 +912,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
   } else {
+    // hybrid: root + the rest of the body by tree levels first (the chain passes below redo the root identically)
+    if constexpr (TP::REST_B > 0) tree_velocity_bias(s, m, lane);
     const LaneRole L = lane_role<TP>(lane);
-    const int j0 = 6 + L.lg * TP::NDL, b0 = 1 + L.lg * TP::NBL;
+    const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
     float(*vb)[6] = reinterpret_cast<float(*)[6]>(&s.qacc_smooth[0]);   // NV x 6 floats: qacc_smooth .. vD
     // pass 1: component-wise prefix of velocities
     float vt = 0.f;
@@ -892,7 +942,8 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
-    for (int j = 3 + lane; j < s.nv(); j += kWave) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
+    for (int j = 3 + lane; j < s.nv(); j += kWave)
+      if (TP::REST_V == 0 || j < 6 || j >= TP::LD0) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
     WSYNC();
     // pass 3: component-wise prefix of bias accelerations (root parent acceleration = -gravity)
     float a = L.rr >= 3 ? -m.gravity[L.rr - 3] : 0.f;
@@ -1329,12 +1380,20 @@ __global__ void __launch_bounds__(1024) nmf_order_kernel(const float* __restrict
 namespace nmf {
 
 using FlyTopo = Topo<6, 3, 2, 1, 1, 1, 1, 1, 1>;   // LEGS_ONLY skeleton: 49 bodies, 72 dofs
+// the full-body skeletons: 20 bodies / 60 dofs of head, antennae, proboscis, abdomen, wings, halteres (tree sweeps) + the
+// six legs (unrolled chain sweeps)
+using FlyTopoBio = HybridTopo<20, 60, 6, 3, 2, 1, 1, 1, 1, 1, 1>;        // ALL_BIOLOGICAL: 69 bodies, 132 dofs
+using FlyTopoAll = HybridTopo<20, 60, 6, 3, 3, 3, 3, 3, 3, 3, 3>;        // ALL_POSSIBLE:   69 bodies, 210 dofs
 using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
 template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoBio, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoBio, true>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoAll, false>(const DevModel*, DevState, ReplayArgs, int, int);
+template __global__ void nmf_step_kernel<FlyTopoAll, true>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
 template __global__ void nmf_step_kernel<TreeTopoSmall, false>(const DevModel*, DevState, ReplayArgs, int, int);

@@ -62,6 +62,12 @@ __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
     stsv(s.W[0], v); stsv(s.T[0], a);
   }
   WSYNC();
+  tree_velocity_bias_levels(s, m, lane);
+}
+
+// the levels below the root (W[0], T[0] given)
+template <class TP>
+__device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane) {
   tree_down(m, lane, [&](int b) {
     const int p = m.body_parent[b], adr = m.body_dofadr[b], num = m.body_dofnum[b];
     SV v = ldsv(s.W[p]), a = ldsv(s.T[p]);
@@ -83,6 +89,11 @@ __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], 
     stsv(T[0], t);
   }
   WSYNC();
+  tree_sweep_twists_levels(s, x, T, m, lane);
+}
+
+template <class TP>
+__device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
   tree_down(m, lane, [&](int b) {
     const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
     SV t = ldsv(T[m.body_parent[b]]);
@@ -91,17 +102,27 @@ __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], 
   });
 }
 
-// W[b] <- sum over the subtree of b (in place; `extra(b)` adds a per-body term first), then emit(j, S_j . W[body(j)])
-template <class TP, class Extra, class Emit>
-__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
-  auto gather = [&](int b) {
+// W[b] <- extra(b, W[b]) + sum of the children's W, for the bodies below the root, deepest level first
+template <class TP, class Extra>
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra) {
+  tree_up(m, lane, [&](int b) {
     SV w = extra(b, ldsv(W[b]));
     const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
     for (int k = c0; k < c1; ++k) w = w + ldsv(W[m.tree_body[k]]);
     stsv(W[b], w);
-  };
-  tree_up(m, lane, gather);
-  if (lane == 0) gather(0);
+  });
+}
+
+// W[b] <- sum over the subtree of b (in place; `extra(b)` adds a per-body term first), then emit(j, S_j . W[body(j)])
+template <class TP, class Extra, class Emit>
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
+  tree_gather_levels(s, W, m, lane, extra);
+  if (lane == 0) {
+    SV w = extra(0, ldsv(W[0]));
+    const int c0 = m.tree_child_start[0], c1 = c0 + m.tree_child_count[0];
+    for (int k = c0; k < c1; ++k) w = w + ldsv(W[m.tree_body[k]]);
+    stsv(W[0], w);
+  }
   WSYNC();
   for (int j = lane; j < s.nv(); j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]])));
   WSYNC();
@@ -119,90 +140,97 @@ __device__ __forceinline__ void contact_dirs(V3 r, const Frame& fr, float* ln, f
 //   up   : IA_b = I_b [+ contact stiffness] + children; per dof (last to first): U = IA s, D = s.U + delta,
 //          u = tau - s.pA, IA -= U UT / D, pA += U u / D; (U, u, 1/D) parked in LDS; (IA, pA) handed to the parent
 //   down : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
+// The per-body pieces are separate so that the hybrid kernels (legs unrolled, the rest of the body as a tree) can run
+// them on the rest bodies only.  TP::kFact0 = first dof that has a `fact` slot, TP::kSlot0 = first body with a `slot`.
+template <class TP, bool WELD>
+__device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
+                                                        const DevModel& m, const Frame& fr) {
+  Sym6 IA;
+  sym6_zero(IA);
+  sym6_add_inertia(IA, s.Ib[b]);
+  float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
+  for (int k = c0; k < c1; ++k) {
+    const float* sl = s.slot[m.tree_body[k] - TP::kSlot0];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) IA.v[i] += sl[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pA[i] += sl[21 + i];
+  }
+  if (withK) {
+    for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) {
+      const int act = info_act(s.c_info[c]);
+      if (!act) continue;
+      float ln[6], l1[6], l2[6];
+      contact_dirs(ld3(s.c_r[c]), fr, ln, l1, l2);
+      const float D = s.c_D[c], mu = s.c_mu[c];
+      const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+      // sum_k a_k D (ln +- mu lt)(ln +- mu lt)T
+      sym6_rank1(IA, ln, D * (a0 + a1 + a2 + a3));
+      sym6_rank1(IA, l1, D * mu * mu * (a0 + a1));
+      sym6_rank1(IA, l2, D * mu * mu * (a2 + a3));
+      sym6_rank2(IA, ln, l1, D * mu * (a0 - a1));
+      sym6_rank2(IA, ln, l2, D * mu * (a2 - a3));
+    }
+    if constexpr (WELD) {
+      if (b == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) IA.v[sym_idx(i, i)] += s.weldD[i];
+      }
+    }
+  }
+  const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  for (int j = adr + num - 1; j >= adr; --j) {
+    float sj[6], U[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sj[i] = s.S[j][i];
+    sym6_mul(IA, sj, U);
+    float D = j < 6 ? 0.f : s.arm[j] + hdamp * s.damp[j], sp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
+    const float invD = __builtin_amdgcn_rcpf(D), u = tau[j] - sp;
+    float* f = s.fact[j - TP::kFact0];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f[i] = U[i];
+    f[6] = u; f[7] = invD;
+    sym6_rank1(IA, U, -invD);
+    const float ku = u * invD;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pA[i] += U[i] * ku;
+  }
+  if (b >= TP::kSlot0) {
+    float* sl = s.slot[b - TP::kSlot0];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) sl[i] = IA.v[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sl[21 + i] = pA[i];
+  }
+}
+
+template <class TP>
+__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m) {
+  const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  for (int j = adr; j < adr + num; ++j) {
+    const float* f = s.fact[j - TP::kFact0];
+    const SV U = ldsv(f), S = ldsv(s.S[j]);
+    const float xj = (f[6] - dot(U, a)) * f[7];
+    x[j] = xj;
+    a = a + xj * S;
+  }
+  stsv(s.T[b], a);
+}
+
 template <class TP, bool WELD>
 __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane) {
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
-  auto eliminate = [&](int b) {
-    Sym6 IA;
-    sym6_zero(IA);
-    sym6_add_inertia(IA, s.Ib[b]);
-    float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
-    for (int k = c0; k < c1; ++k) {
-      const float* sl = s.slot[m.tree_body[k]];
-#pragma unroll
-      for (int i = 0; i < 21; ++i) IA.v[i] += sl[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) pA[i] += sl[21 + i];
-    }
-    if (withK) {
-      for (int c = s.body_cstart[b]; c < s.body_cstart[b + 1]; ++c) {
-        const int act = info_act(s.c_info[c]);
-        if (!act) continue;
-        float ln[6], l1[6], l2[6];
-        contact_dirs(ld3(s.c_r[c]), fr, ln, l1, l2);
-        const float D = s.c_D[c], mu = s.c_mu[c];
-        const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
-        // sum_k a_k D (ln +- mu lt)(ln +- mu lt)T
-        sym6_rank1(IA, ln, D * (a0 + a1 + a2 + a3));
-        sym6_rank1(IA, l1, D * mu * mu * (a0 + a1));
-        sym6_rank1(IA, l2, D * mu * mu * (a2 + a3));
-        sym6_rank2(IA, ln, l1, D * mu * (a0 - a1));
-        sym6_rank2(IA, ln, l2, D * mu * (a2 - a3));
-      }
-      if constexpr (WELD) {
-        if (b == 0) {
-#pragma unroll
-          for (int i = 0; i < 6; ++i) IA.v[sym_idx(i, i)] += s.weldD[i];
-        }
-      }
-    }
-    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-    for (int j = adr + num - 1; j >= adr; --j) {
-      float sj[6], U[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) sj[i] = s.S[j][i];
-      sym6_mul(IA, sj, U);
-      float D = j < 6 ? 0.f : s.arm[j] + hdamp * s.damp[j], sp = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
-      const float invD = __builtin_amdgcn_rcpf(D), u = tau[j] - sp;
-      float* f = s.fact[j];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) f[i] = U[i];
-      f[6] = u; f[7] = invD;
-      sym6_rank1(IA, U, -invD);
-      const float ku = u * invD;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) pA[i] += U[i] * ku;
-    }
-    if (b != 0) {
-      float* sl = s.slot[b];
-#pragma unroll
-      for (int i = 0; i < 21; ++i) sl[i] = IA.v[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) sl[21 + i] = pA[i];
-    }
-  };
-  tree_up(m, lane, eliminate);
-  if (lane == 0) eliminate(0);
+  tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+  if (lane == 0) tree_aba_eliminate_body<TP, WELD>(s, 0, tau, withK, hdamp, m, fr);
   WSYNC();
-  auto expand = [&](int b, SV a) {
-    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-    for (int j = adr; j < adr + num; ++j) {
-      const float* f = s.fact[j];
-      const SV U = ldsv(f), S = ldsv(s.S[j]);
-      const float xj = (f[6] - dot(U, a)) * f[7];
-      x[j] = xj;
-      a = a + xj * S;
-    }
-    stsv(s.T[b], a);
-  };
-  if (lane == 0) expand(0, SV{v3(0, 0, 0), v3(0, 0, 0)});
+  if (lane == 0) tree_aba_expand_body(s, 0, SV{v3(0, 0, 0), v3(0, 0, 0)}, x, m);
   WSYNC();
-  tree_down(m, lane, [&](int b) { expand(b, ldsv(s.T[m.body_parent[b]])); });
+  tree_down(m, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[m.body_parent[b]]), x, m); });
 }
 
 }  // namespace nmf

@@ -33,7 +33,7 @@ for k in range(30):
           f"ncon {st[0]:.0f}/{o.ints()['ncon']} it {st[1]:.0f}/{o.ints()['solver_iter']} finite {np.isfinite(q).all()}")
 torch.cuda.synchronize()
 import time
-n = 2048
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 s2 = HIPSimulation(world, n_worlds=n, device=0)
 s2.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 s2.step(300); torch.cuda.synchronize()

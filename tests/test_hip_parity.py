@@ -532,11 +532,13 @@ def test_single_world_simulation_mirrors_the_cpu_class(torch_mod, bench_model, o
     assert sim.time == 0.0 and np.allclose(sim.get_joint_angles(fly.name), q0) and sim._curr_step == 0
 
 
-@pytest.mark.parametrize("preset,nv", [("ALL_BIOLOGICAL", 132), ("ALL_POSSIBLE", 210)])
+@pytest.mark.parametrize("preset,nv", [("ALL_BIOLOGICAL", 132), ("ALL_POSSIBLE", 210), ("custom", 105)])
 def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
     """Skeletons that are not a star of identical leg chains (head with antennae and proboscis, abdomen, wings,
-    halteres: 69 bodies, 132 / 210 dofs) run on the general-tree kernel (nmf_tree.h): reset poses, the drop, landing and
-    settling, then driven walking, against the float64 oracle — same bars as the leg-only skeletons."""
+    halteres): the full-body presets (69 bodies, 132 / 210 dofs) run on the hybrid kernels (legs unrolled, the rest of
+    the body swept as a tree), a custom skeleton (ALL_BIOLOGICAL without wings, halteres and abdomen joints: 60 bodies,
+    105 dofs) on the pure general-tree kernel (nmf_tree.h).  Reset poses, the drop, landing and settling, then driven
+    walking, against the float64 oracle — same bars as the leg-only skeletons."""
     torch = torch_mod
     import flygym_amd.compose as C
     from flygym_amd import HIPSimulation, anatomy as A
@@ -544,7 +546,12 @@ def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
     from flygym_amd.utils.math import Rotation3D
 
     fly = C.Fly(name="t")
-    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=getattr(A.JointPreset, preset))
+    if preset == "custom":
+        bio = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL)
+        keep = [j for j in bio.anatomical_joints if not any(k in j.child.name for k in ("wing", "haltere", "abdomen"))]
+        sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, anatomical_joints=keep)
+    else:
+        sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=getattr(A.JointPreset, preset))
     fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
     legs = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
     fly.add_actuators(legs.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
@@ -554,7 +561,7 @@ def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     n = 3
     sim = HIPSimulation(world, n_worlds=n, device=0)
-    assert sim.model.nv == nv and sim.model.nb == 69 and int(sim.model["star"][0]) == 0
+    assert sim.model.nv == nv and sim.model.nb == (60 if preset == "custom" else 69) and int(sim.model["star"][0]) == 0
     o = oracle_lib.Oracle(sim.model.to_blob(), "f64")
     o32 = oracle_lib.Oracle(sim.model.to_blob(), "f32")
     assert np.abs(sim.field("seg_xpos").cpu().numpy()[0] - o.arr("seg_xpos")).max() < 2e-6
