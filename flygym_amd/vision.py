@@ -5,8 +5,9 @@ turned the two eye-camera images into ommatidia readings; this snapshot keeps on
 (``src/flygym/assets/model/legacy/flygym1_config.yaml:141-173``).  Build-defined here:
 
 * each eye is a camera attached to its eye segment at the legacy offset; the legacy Euler triple is read as rotations
-  about the fixed parent axes x, y, z in that order (it makes the left eye look 27 degrees forward of straight left,
-  the right eye symmetrically); the camera looks along its -z, +y is up;
+  about the fixed parent axes x, y, z in that order — the model's ``eulerseq: XYZ`` (``mujoco_globals.yaml:4``; upper
+  case = extrinsic in MJCF) — which makes the left eye look 27 degrees forward of straight left, the right eye
+  symmetrically; the camera looks along its -z, +y is up;
 * the lens is an equidistant fisheye: a pixel's ray makes the angle ``rho * fov / 2`` with the optical axis, ``rho``
   = distance from the image centre in units of half the image height, ``fov`` = 157 degrees (``fovy_per_eye``); the
   legacy pinhole + distortion-coefficient pipeline is not reproduced;
