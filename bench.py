@@ -54,6 +54,8 @@ def parse_args():
                     help="flat = BASELINE config 2; gapped/blocks = config 4; mixed = config 5 (build-defined height maps)")
     ap.add_argument("--cpg-adhesion", type=float, default=0.0, metavar="ON",
                     help="drive leg adhesion from the CPG: control ON in stance, 1 (the reference's minimum) in swing (config 5)")
+    ap.add_argument("--joint-preset", choices=["legs_only", "all_biological"], default="legs_only",
+                    help="skeleton: the benchmark's LEGS_ONLY (default) or the full-body ALL_BIOLOGICAL (hybrid kernel)")
     ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,7 +172,7 @@ def main():
         spl = next(d for d in range(spl, 0, -1) if args.steps % d == 0)
     n_launches = args.steps // spl
 
-    fly, world, _ = make_model(simplify_geom=args.simplify_geom)
+    fly, world, _ = make_model(joints_preset=args.joint_preset, simplify_geom=args.simplify_geom)
     if args.terrain != "flat":
         import flygym_amd.compose as C
         from flygym_amd.utils.math import Rotation3D
@@ -274,7 +276,7 @@ def main():
         if tfile.exists():
             rec = json.loads(tfile.read_text())
             if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch"), rec.get("control")) == (n_local, spl, args.workload) \
-                    and args.terrain == "flat" and not args.odor and not args.cpg_adhesion:
+                    and args.terrain == "flat" and not args.odor and not args.cpg_adhesion and args.joint_preset == "legs_only":
                 traffic = rec["traffic_bytes_per_launch"]
                 issue = rec.get("issue") or None
         out = {
@@ -283,7 +285,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", LEGS_ONLY fly (nq 73, nv 72, nu 48), 55 geom-plane pairs "
+                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", " + (f"{args.joint_preset.upper()} fly (nq {sim.model.nq}, nv {sim.model.nv}, nu {sim.model.nu}), 55 geom-plane pairs ")
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else
@@ -299,7 +301,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "nmf_step_kernel<Topo<6,3,2,1,1,1,1,1,1>, false>", "kernel_ms_per_launch": ms,
+                "kernel": ("nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>" if args.joint_preset == "legs_only" else
+                           "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>"), "kernel_ms_per_launch": ms,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 # instruction-issue side of the same kernel, from the SQ counters of the committed profile (profiles/*_summary.md)
                 "issue": issue,

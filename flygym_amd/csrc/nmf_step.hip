@@ -58,6 +58,10 @@ template <class TP>
 struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodies only
   float fact[TP::kNFact][8];
   float slot[TP::kNSlot][27];
+  // the rest carries no contacts while walking, so its matrix factors are the same for the smooth solve and every Newton
+  // solve of a step: cached (valid flag reset every step; the damping term they were built with)
+  int rest_fact_valid;
+  float rest_fact_hdamp;
 };
 
 template <class TP>
@@ -172,6 +176,8 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
                                                         const DevModel& m, const Frame& fr);
 template <class TP>
 __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m);
+template <class TP>
+__device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m);
 
 // ------------------------------------------------------------------ kinematics
 template <class TP>
@@ -621,8 +627,16 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
   // hybrid: the rest of the body (head, abdomen, wings, ...) is eliminated level by level first; its children-of-root
   // hand their articulated inertias to the root below through s.slot
-  if constexpr (TP::REST_B > 0)
-    tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+  if constexpr (TP::REST_B > 0) {
+    const bool rest_K = withK && s.body_cstart[TP::LB0] > s.body_cstart[1];     // contact stiffness on a rest body
+    const bool reuse = s.rest_fact_valid != 0 && s.rest_fact_hdamp == hdamp && !rest_K;
+    if (reuse) tree_up(m, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
+    else {
+      tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+      if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
+      WSYNC();
+    }
+  }
   float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float pA = 0.f;
   // ---- backward sweep along the leg
@@ -837,6 +851,7 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
 template <class TP, bool WELD>
 __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) s.rest_fact_valid = 0; } }   // new configuration: new factors
   stage_kinematics(s, m, lane);
   STAGE(1);
   stage_inertia(s, m, lane);
