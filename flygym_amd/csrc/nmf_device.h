@@ -40,6 +40,7 @@ struct HybridTopo {
   static constexpr int LD0 = 6 + REST_V_;        // first leg dof
   static constexpr int kFact0 = 6, kSlot0 = 1;   // the rest dofs / bodies only (tree sweeps); legs and root keep theirs in registers
   static constexpr int kNFact = REST_V_ > 0 ? REST_V_ : 1, kNSlot = REST_B_ > 0 ? REST_B_ : 1;
+  static constexpr int kTblB = 1 + REST_B_, kTblV = 6 + REST_V_;   // tree tables: root + rest bodies, root + rest dofs
   static constexpr int NB = LB0 + NLEG_ * NBL;
   static constexpr int NV = LD0 + NLEG_ * NDL;
   static constexpr int NQ = NV + 1;
@@ -62,6 +63,7 @@ struct TreeTopoT {
   static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
   static constexpr int kFact0 = 0, kSlot0 = 1;      // every dof has articulated-body factors, every non-root body a hand-off slot
   static constexpr int kNFact = NV_, kNSlot = NB_;
+  static constexpr int kTblB = NB_, kTblV = NV_;
 };
 using TreeTopo = TreeTopoT<72, 216>;
 using TreeTopoSmall = TreeTopoT<72, 144>;

@@ -45,6 +45,15 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_FLUSH()
 #endif
 
+// tree tables staged in LDS once per launch (bodies in breadth-first order; see nmf_capi.hip): body of BFS slot k, parent /
+// first dof / dof count / child range of body b, body of dof j, level starts
+// (sized for the bodies / dofs the tree sweeps touch: everything for the tree kernels, root + rest for the hybrid ones —
+// the hybrid kernel sits 700 bytes below the LDS budget of 5 flies per CU)
+#define NMF_TREE_TABLES                                                                                                  \
+  unsigned char t_body[TP::kTblB], t_parent[TP::kTblB], t_dofadr[TP::kTblB], t_dofnum[TP::kTblB], t_cstart[TP::kTblB],    \
+      t_ccount[TP::kTblB], t_dofbody[TP::kTblV];                                                                          \
+  unsigned char t_lvl[18], t_nlevel;
+
 // LDS used by the general-tree sweeps only (nmf_tree.h)
 template <class TP, bool STAR = TP::kStar, bool REST = (TP::kNFact > 1)>
 struct TreeLds {};
@@ -53,6 +62,7 @@ struct TreeLds<TP, false, true> {
   float fact[TP::kNFact][8];  // articulated-body factors per dof: U (6), u, 1/D — written going up, read going down
   float slot[TP::kNSlot][27]; // articulated inertia (symmetric, 21) + bias wrench (6) a body hands to its parent
   int rt_nb, rt_nv;
+  NMF_TREE_TABLES
 };
 template <class TP>
 struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodies only
@@ -62,6 +72,7 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
   // solve of a step: cached (valid flag reset every step; the damping term they were built with)
   int rest_fact_valid;
   float rest_fact_hdamp;
+  NMF_TREE_TABLES
 };
 
 template <class TP>
@@ -103,6 +114,9 @@ struct __align__(16) FlyLds : TreeLds<TP> {
     }
   }
 };
+template <class TP> __device__ __forceinline__ int tbl_dofbody(const FlyLds<TP>& s, int j) { if constexpr (TP::kNFact > 1) return s.t_dofbody[j]; else return 0; }
+template <class TP> __device__ __forceinline__ int tbl_dofadr(const FlyLds<TP>& s, int b) { if constexpr (TP::kNFact > 1) return s.t_dofadr[b]; else return 0; }
+template <class TP> __device__ __forceinline__ int tbl_dofnum(const FlyLds<TP>& s, int b) { if constexpr (TP::kNFact > 1) return s.t_dofnum[b]; else return 0; }
 enum { V_QACC = 0, V_QACC_SMOOTH = 1, V_QFRC_SMOOTH = 2, V_A = 3, V_B = 4, V_C = 5, V_D = 6 };
 
 __device__ __forceinline__ int info_geom(int i) { return i & 0xff; }
@@ -168,8 +182,8 @@ template <class TP> __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, con
 template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane);
 template <class TP, class Extra>
 __device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra);
-template <class F> __device__ __forceinline__ void tree_down(const DevModel& m, int lane, F&& f);
-template <class F> __device__ __forceinline__ void tree_up(const DevModel& m, int lane, F&& f);
+template <class S, class F> __device__ __forceinline__ void tree_down(const S& s, int lane, F&& f);
+template <class S, class F> __device__ __forceinline__ void tree_up(const S& s, int lane, F&& f);
 struct Frame;
 template <class TP, bool WELD>
 __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
@@ -207,8 +221,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
         const int lb = (b - TP::LB0) % TP::NBL;
         adr = TP::LD0 + ((b - TP::LB0) / TP::NBL) * TP::NDL; num = 0;
         static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
-      } else { adr = m.body_dofadr[b]; num = m.body_dofnum[b]; }     // hybrid: the rest of the body (tree part)
-    } else { adr = m.body_dofadr[b]; num = m.body_dofnum[b]; }
+      } else { adr = tbl_dofadr(s, b); num = tbl_dofnum(s, b); }     // hybrid: the rest of the body (tree part)
+    } else { adr = tbl_dofadr(s, b); num = tbl_dofnum(s, b); }
     Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
     for (int j = adr + num - 1; j >= adr; --j) {
       st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
@@ -252,7 +266,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       S.l = v3(0.f, 0.f, 0.f);
     } else {
       int b;
-      if constexpr (TP::kStar) b = j >= TP::LD0 ? dof_body_of<TP>(j) : m.dof_body[j]; else b = m.dof_body[j];
+      if constexpr (TP::kStar) b = j >= TP::LD0 ? dof_body_of<TP>(j) : tbl_dofbody(s, j); else b = tbl_dofbody(s, j);
       V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
       V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
       S.a = a;
@@ -521,12 +535,12 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += W[TP::LB0 + k * TP::NBL][lane];
     if constexpr (TP::REST_B > 0)
-      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) a0 += W[m.tree_body[k]][lane];
+      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += W[(int)s.t_body[k]][lane];
     W[0][lane] = a0;
   }
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave)
-    emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : m.dof_body[j]])));
+    emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
   WSYNC();
   }
 }
@@ -630,9 +644,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   if constexpr (TP::REST_B > 0) {
     const bool rest_K = withK && s.body_cstart[TP::LB0] > s.body_cstart[1];     // contact stiffness on a rest body
     const bool reuse = s.rest_fact_valid != 0 && s.rest_fact_hdamp == hdamp && !rest_K;
-    if (reuse) tree_up(m, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
+    if (reuse) tree_up(s, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
     else {
-      tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+      tree_up(s, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
       if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
       WSYNC();
     }
@@ -682,8 +696,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       pA += H.legpA[k][L.rr];
     }
     if constexpr (TP::REST_B > 0) {
-      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) {
-        const float* sl = s.slot[m.tree_body[k] - TP::kSlot0];
+      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
+        const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
 #pragma unroll
         for (int i = 0; i < 6; i++) row[i] += sl[so[i]];
         pA += sl[21 + L.rr];
@@ -720,7 +734,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   });
   WSYNC();
   if constexpr (TP::REST_B > 0)
-    tree_down(m, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[m.body_parent[b]]), x, m); });
+    tree_down(s, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[(int)s.t_parent[b]]), x, m); });
   }
 }
 
@@ -831,12 +845,12 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[TP::LB0 + k * TP::NBL][lane];
     if constexpr (TP::REST_B > 0)
-      for (int k = m.tree_child_start[0]; k < m.tree_child_start[0] + m.tree_child_count[0]; ++k) a0 += s.W[m.tree_body[k]][lane];
+      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += s.W[(int)s.t_body[k]][lane];
     s.W[0][lane] = a0;
   }
   WSYNC();
   for (int j = lane; j < TP::NV; j += kWave)
-    emit(j, dot(ldsv(s.S[j]), ldsv(s.W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : m.dof_body[j]])));
+    emit(j, dot(ldsv(s.S[j]), ldsv(s.W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
   WSYNC();
   }
 }
@@ -1269,6 +1283,18 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   __shared__ FlyLds<TP> s;
   const DevModel& m = *mp;
   if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }
+  if constexpr (TP::kNFact > 1) {     // kernels with tree sweeps: stage the tree tables
+    for (int b = threadIdx.x; b < TP::kTblB && b < m.nb; b += kWave) {
+      s.t_body[b] = (unsigned char)m.tree_body[b < m.tree_lvl_start[m.tree_nlevel] ? b : 0];
+      s.t_parent[b] = (unsigned char)(b ? m.body_parent[b] : 0);
+      s.t_dofadr[b] = (unsigned char)m.body_dofadr[b]; s.t_dofnum[b] = (unsigned char)m.body_dofnum[b];
+      s.t_cstart[b] = (unsigned char)m.tree_child_start[b]; s.t_ccount[b] = (unsigned char)m.tree_child_count[b];
+    }
+    for (int j = threadIdx.x; j < TP::kTblV && j < m.nv; j += kWave) s.t_dofbody[j] = (unsigned char)m.dof_body[j];
+    if (threadIdx.x < 18) s.t_lvl[threadIdx.x] = (unsigned char)m.tree_lvl_start[threadIdx.x];
+    if (threadIdx.x == 0) s.t_nlevel = (unsigned char)m.tree_nlevel;
+    __syncthreads();
+  }
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= st.n_worlds) return;
   const int w = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;

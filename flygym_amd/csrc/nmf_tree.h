@@ -13,19 +13,19 @@
 namespace nmf {
 
 // f(body) for every body of levels 1.. (root excluded), a wave barrier after each level
-template <class F>
-__device__ __forceinline__ void tree_down(const DevModel& m, int lane, F&& f) {
-  for (int lvl = 1; lvl < m.tree_nlevel; ++lvl) {
-    const int k = m.tree_lvl_start[lvl] + lane;
-    if (k < m.tree_lvl_start[lvl + 1]) f(m.tree_body[k]);
+template <class S, class F>
+__device__ __forceinline__ void tree_down(const S& s, int lane, F&& f) {
+  for (int lvl = 1; lvl < (int)s.t_nlevel; ++lvl) {
+    const int k = (int)s.t_lvl[lvl] + lane;
+    if (k < (int)s.t_lvl[lvl + 1]) f((int)s.t_body[k]);
     WSYNC();
   }
 }
-template <class F>
-__device__ __forceinline__ void tree_up(const DevModel& m, int lane, F&& f) {
-  for (int lvl = m.tree_nlevel - 1; lvl >= 1; --lvl) {
-    const int k = m.tree_lvl_start[lvl] + lane;
-    if (k < m.tree_lvl_start[lvl + 1]) f(m.tree_body[k]);
+template <class S, class F>
+__device__ __forceinline__ void tree_up(const S& s, int lane, F&& f) {
+  for (int lvl = (int)s.t_nlevel - 1; lvl >= 1; --lvl) {
+    const int k = (int)s.t_lvl[lvl] + lane;
+    if (k < (int)s.t_lvl[lvl + 1]) f((int)s.t_body[k]);
     WSYNC();
   }
 }
@@ -33,8 +33,8 @@ __device__ __forceinline__ void tree_up(const DevModel& m, int lane, F&& f) {
 // rigid transforms down the tree: R_b = R_parent Rrel_b, p_b = p_parent + R_parent off_b  (relm[b] = Rrel (9), off (3))
 template <class TP>
 __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]) {
-  tree_down(m, lane, [&](int b) {
-    const int p = m.body_parent[b];
+  tree_down(s, lane, [&](int b) {
+    const int p = (int)s.t_parent[b];
     const float* R = s.xmat[p];
     const float* M = relm[b];
     st3(s.xpos[b], ld3(s.xpos[p]) + mat_vec(R, ld3(M + 9)));
@@ -68,8 +68,8 @@ __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
 // the levels below the root (W[0], T[0] given)
 template <class TP>
 __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane) {
-  tree_down(m, lane, [&](int b) {
-    const int p = m.body_parent[b], adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  tree_down(s, lane, [&](int b) {
+    const int p = (int)s.t_parent[b], adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
     SV v = ldsv(s.W[p]), a = ldsv(s.T[p]);
     for (int j = adr; j < adr + num; ++j) {
       const SV S = ldsv(s.S[j]);
@@ -94,9 +94,9 @@ __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], 
 
 template <class TP>
 __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
-  tree_down(m, lane, [&](int b) {
-    const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
-    SV t = ldsv(T[m.body_parent[b]]);
+  tree_down(s, lane, [&](int b) {
+    const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
+    SV t = ldsv(T[(int)s.t_parent[b]]);
     for (int j = adr; j < adr + num; ++j) t = t + x[j] * ldsv(s.S[j]);
     stsv(T[b], t);
   });
@@ -105,10 +105,10 @@ __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*
 // W[b] <- extra(b, W[b]) + sum of the children's W, for the bodies below the root, deepest level first
 template <class TP, class Extra>
 __device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra) {
-  tree_up(m, lane, [&](int b) {
+  tree_up(s, lane, [&](int b) {
     SV w = extra(b, ldsv(W[b]));
-    const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
-    for (int k = c0; k < c1; ++k) w = w + ldsv(W[m.tree_body[k]]);
+    const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
+    for (int k = c0; k < c1; ++k) w = w + ldsv(W[(int)s.t_body[k]]);
     stsv(W[b], w);
   });
 }
@@ -119,12 +119,12 @@ __device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6],
   tree_gather_levels(s, W, m, lane, extra);
   if (lane == 0) {
     SV w = extra(0, ldsv(W[0]));
-    const int c0 = m.tree_child_start[0], c1 = c0 + m.tree_child_count[0];
-    for (int k = c0; k < c1; ++k) w = w + ldsv(W[m.tree_body[k]]);
+    const int c0 = (int)s.t_cstart[0], c1 = c0 + (int)s.t_ccount[0];
+    for (int k = c0; k < c1; ++k) w = w + ldsv(W[(int)s.t_body[k]]);
     stsv(W[0], w);
   }
   WSYNC();
-  for (int j = lane; j < s.nv(); j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[m.dof_body[j]])));
+  for (int j = lane; j < s.nv(); j += kWave) emit(j, dot(ldsv(s.S[j]), ldsv(W[(int)s.t_dofbody[j]])));
   WSYNC();
 }
 
@@ -147,13 +147,13 @@ __device__ __forceinline__ void contact_dirs(V3 r, const Frame& fr, float* ln, f
 template <class TP>
 __device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m) {
   float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
+  const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
   for (int k = c0; k < c1; ++k) {
-    const float* sl = s.slot[m.tree_body[k] - TP::kSlot0];
+    const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pA[i] += sl[21 + i];
   }
-  const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
   for (int j = adr + num - 1; j >= adr; --j) {
     float* f = s.fact[j - TP::kFact0];
     float sp = 0.f;
@@ -179,9 +179,9 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
   sym6_zero(IA);
   sym6_add_inertia(IA, s.Ib[b]);
   float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int c0 = m.tree_child_start[b], c1 = c0 + m.tree_child_count[b];
+  const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
   for (int k = c0; k < c1; ++k) {
-    const float* sl = s.slot[m.tree_body[k] - TP::kSlot0];
+    const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
 #pragma unroll
     for (int i = 0; i < 21; ++i) IA.v[i] += sl[i];
 #pragma unroll
@@ -209,7 +209,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
       }
     }
   }
-  const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
   for (int j = adr + num - 1; j >= adr; --j) {
     float sj[6], U[6];
 #pragma unroll
@@ -239,7 +239,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
 
 template <class TP>
 __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m) {
-  const int adr = m.body_dofadr[b], num = m.body_dofnum[b];
+  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
   for (int j = adr; j < adr + num; ++j) {
     const float* f = s.fact[j - TP::kFact0];
     const SV U = ldsv(f), S = ldsv(s.S[j]);
@@ -255,12 +255,12 @@ __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, 
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
-  tree_up(m, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+  tree_up(s, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
   if (lane == 0) tree_aba_eliminate_body<TP, WELD>(s, 0, tau, withK, hdamp, m, fr);
   WSYNC();
   if (lane == 0) tree_aba_expand_body(s, 0, SV{v3(0, 0, 0), v3(0, 0, 0)}, x, m);
   WSYNC();
-  tree_down(m, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[m.body_parent[b]]), x, m); });
+  tree_down(s, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[(int)s.t_parent[b]]), x, m); });
 }
 
 }  // namespace nmf

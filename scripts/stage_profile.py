@@ -15,7 +15,8 @@ from flygym_amd import HIPSimulation, make_model
 from flygym_amd.compose import ActuatorType
 from flygym_amd.replay import ReplayTargetData
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
-fly, world, _ = make_model()
+preset = next((a.split('=')[1] for a in sys.argv if a.startswith('--joint-preset=')), 'legs_only')
+fly, world, _ = make_model(joints_preset=preset)
 sim = HIPSimulation(world, n_worlds=n, device=0)
 L = _native.lib()
 L.nmf_debug_stage_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
