@@ -340,7 +340,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     st.sched = nullptr;
     st.order = nullptr;
     hipDeviceProp_t prop;
-    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 5 : 4)));   // flies per CU: LDS-limited
+    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 6 : 5)));   // flies per CU: LDS-limited
     b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;
   }
   if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {

@@ -72,8 +72,15 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
   // solve of a step: cached (valid flag reset every step; the damping term they were built with)
   int rest_fact_valid;
   float rest_fact_hdamp;
+  // reduced constraint problem (physics_forward): while no rest body is in contact the rest's accelerations are
+  // eliminated from the Newton loop — the root carries the rest's articulated inertia restA (symmetric 6x6) instead
+  int reduced;
+  float restA[21];
   NMF_TREE_TABLES
 };
+
+template <class TP> constexpr bool has_isym() { if constexpr (TP::kStar) return TP::REST_B == 0; else return false; }
+template <class TP> inline constexpr bool kHasIsym = has_isym<TP>();
 
 template <class TP>
 struct __align__(16) FlyLds : TreeLds<TP> {
@@ -90,7 +97,9 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
   float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products)
-  float Isym[TP::kStar ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches for the star ABA
+  // the same as a symmetric 6x6 (upper triangle): row fetches for the star ABA.  The hybrid kernels build the rows from
+  // Ib instead: they are latency bound and the 5.8 KB buy one more resident fly per CU
+  float Isym[kHasIsym<TP> ? TP::NB : 1][21];
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][6], W[TP::NB][6];
@@ -190,6 +199,8 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
                                                         const DevModel& m, const Frame& fr);
 template <class TP>
 __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m);
+template <class TP>
+__device__ __forceinline__ void tree_aba_recover_body(FlyLds<TP>& s, int b, SV a);
 template <class TP>
 __device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m);
 
@@ -298,7 +309,7 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
     I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
     I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
     I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
-    if constexpr (TP::kStar) {
+    if constexpr (kHasIsym<TP>) {
     float* Q = s.Isym[b];                // [[I, [h]x], [-[h]x, m 1]], upper triangle row-major
     Q[0] = I[4]; Q[1] = I[7]; Q[2] = I[8]; Q[3] = 0.f;   Q[4] = -I[3]; Q[5] = I[2];
     Q[6] = I[5]; Q[7] = I[9]; Q[8] = I[3]; Q[9] = 0.f;   Q[10] = -I[1];
@@ -495,6 +506,30 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
 // store them to the same LDS words as their twins, so the sweeps are branch-free straight-line code (no exec
 // masking) and the DPP reductions stay converged; `mask` removes the shadow rows from group sums.
 // T[b] = twist of body b under generalized vector x:  T_b = T_parent + sum_j S_j x_j
+// hybrid kernels: true while the Newton loop runs on the reduced problem (root + legs; see physics_forward)
+template <class TP>
+__device__ __forceinline__ bool rest_reduced(const FlyLds<TP>& s) {
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) return __builtin_amdgcn_readfirstlane(s.reduced) != 0; }
+  return false;
+}
+// restA * t  (the rest's articulated inertia applied to the root twist)
+template <class TP>
+__device__ __forceinline__ SV rest_inertia_mul(const FlyLds<TP>& s, SV t) {
+  const float tv[6] = {t.a.x, t.a.y, t.a.z, t.l.x, t.l.y, t.l.z};
+  float o[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const int i = r < c ? r : c, jx = r < c ? c : r;
+      acc += s.restA[i * 6 - i * (i - 1) / 2 + (jx - i)] * tv[c];
+    }
+    o[r] = acc;
+  }
+  return SV{v3(o[0], o[1], o[2]), v3(o[3], o[4], o[5])};
+}
+
 template <class TP>
 __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
   if constexpr (!TP::kStar) { tree_sweep_twists(s, x, T, m, lane); return; } else {
@@ -510,7 +545,7 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
     if constexpr (TP::is_last(d)) T[b0 + TP::lbody(d)][L.rr] = t;
   });
   WSYNC();
-  if constexpr (TP::REST_B > 0) tree_sweep_twists_levels(s, x, T, m, lane);
+  if constexpr (TP::REST_B > 0) { if (!rest_reduced(s)) tree_sweep_twists_levels(s, x, T, m, lane); }
   }
 }
 
@@ -519,7 +554,8 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 template <class TP, class Emit>
 __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Emit&& emit) {
   if constexpr (!TP::kStar) { tree_sweep_project(s, W, m, lane, [](int, SV w) { return w; }, emit); return; } else {
-  if constexpr (TP::REST_B > 0) tree_gather_levels(s, W, m, lane, [](int, SV w) { return w; });
+  const bool red = rest_reduced(s);
+  if constexpr (TP::REST_B > 0) { if (!red) tree_gather_levels(s, W, m, lane, [](int, SV w) { return w; }); }
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = TP::LB0 + L.lg * TP::NBL;
   float acc = 0.f;
@@ -534,13 +570,16 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
     float a0 = W[0][lane];
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += W[TP::LB0 + k * TP::NBL][lane];
-    if constexpr (TP::REST_B > 0)
-      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += W[(int)s.t_body[k]][lane];
+    if constexpr (TP::REST_B > 0) {
+      if (!red) for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += W[(int)s.t_body[k]][lane];
+    }
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave)
+  for (int j = lane; j < TP::NV; j += kWave) {
+    if (TP::REST_V > 0 && red && j >= 6 && j < TP::LD0) continue;      // reduced problem: the rest's dofs are not in it
     emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
+  }
   WSYNC();
   }
 }
@@ -550,7 +589,14 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], cons
 template <class TP, class Emit>
 __device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const DevModel& m, int lane, bool have_twists, Emit&& emit) {
   if (!have_twists) sweep_twists(s, x, s.T, m, lane);
-  for (int b = lane; b < s.nb(); b += kWave) stsv(s.W[b], inert_mul(s.Ib[b], ldsv(s.T[b])));
+  const bool red = rest_reduced(s);
+  for (int b = lane; b < s.nb(); b += kWave) {
+    if constexpr (TP::kStar) { if (TP::REST_B > 0 && red && b >= 1 && b < TP::LB0) continue; }
+    const SV tb = ldsv(s.T[b]);
+    SV wb = inert_mul(s.Ib[b], tb);
+    if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (red && b == 0) wb = wb + rest_inertia_mul(s, tb); } }
+    stsv(s.W[b], wb);
+  }
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) { emit(j, v + s.arm[j] * x[j]); });
 }
@@ -641,10 +687,12 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
   // hybrid: the rest of the body (head, abdomen, wings, ...) is eliminated level by level first; its children-of-root
   // hand their articulated inertias to the root below through s.slot
+  const bool red = rest_reduced(s);
   if constexpr (TP::REST_B > 0) {
     const bool rest_K = withK && s.body_cstart[TP::LB0] > s.body_cstart[1];     // contact stiffness on a rest body
     const bool reuse = s.rest_fact_valid != 0 && s.rest_fact_hdamp == hdamp && !rest_K;
-    if (reuse) tree_up(s, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
+    if (red) {}
+    else if (reuse) tree_up(s, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
     else {
       tree_up(s, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
       if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
@@ -660,8 +708,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
       const int b = b0 + TP::lbody(d);
       float row[6];
+      if constexpr (kHasIsym<TP>) {
 #pragma unroll
-      for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
+        for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
+      } else inertia_row(s.Ib[b], L.rr, row);
       for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
 #pragma unroll
       for (int i = 0; i < 6; i++) IA[i] += row[i];
@@ -681,8 +731,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   float Ur[6], ur[6], invDr[6], Sr[6];
   {
     float row[6];
+    if constexpr (kHasIsym<TP>) {
 #pragma unroll
-    for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
+      for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
+    } else inertia_row(s.Ib[0], L.rr, row);
     if (withK) {
       for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, L.rr, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
@@ -696,6 +748,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       pA += H.legpA[k][L.rr];
     }
     if constexpr (TP::REST_B > 0) {
+      if (red) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) row[i] += s.restA[so[i]];
+      } else
       for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
         const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
 #pragma unroll
@@ -733,8 +789,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
   });
   WSYNC();
-  if constexpr (TP::REST_B > 0)
-    tree_down(s, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[(int)s.t_parent[b]]), x, m); });
+  if constexpr (TP::REST_B > 0) {
+    if (!red) tree_down(s, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[(int)s.t_parent[b]]), x, m); });
+  }
   }
 }
 
@@ -820,12 +877,14 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     }, emit);
     return;
   } else {
-  if constexpr (TP::REST_B > 0)      // head / abdomen / wing contacts: tree levels of the rest of the body
-    tree_gather_levels(s, s.W, m, lane, [&](int b, SV w) {
+  const bool red = rest_reduced(s);
+  if constexpr (TP::REST_B > 0) {    // head / abdomen / wing contacts: tree levels of the rest of the body
+    if (!red) tree_gather_levels(s, s.W, m, lane, [&](int b, SV w) {
       SV own = SEEDED ? seed_scale * w : SV{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
       for (int cc = s.body_cstart[b]; cc < s.body_cstart[b + 1]; ++cc) own = own + ldsv(s.c_w[cc]);
       return own;
     });
+  }
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = TP::LB0 + L.lg * TP::NBL;
   float acc = 0.f;
@@ -844,13 +903,16 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     for (int cc = s.body_cstart[0]; cc < s.body_cstart[1]; ++cc) a0 += s.c_w[cc][lane];
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) a0 += s.W[TP::LB0 + k * TP::NBL][lane];
-    if constexpr (TP::REST_B > 0)
-      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += s.W[(int)s.t_body[k]][lane];
+    if constexpr (TP::REST_B > 0) {
+      if (!red) for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a0 += s.W[(int)s.t_body[k]][lane];
+    }
     s.W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave)
+  for (int j = lane; j < TP::NV; j += kWave) {
+    if (TP::REST_V > 0 && red && j >= 6 && j < TP::LD0) continue;
     emit(j, dot(ldsv(s.S[j]), ldsv(s.W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
+  }
   WSYNC();
   }
 }
@@ -865,7 +927,7 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
 template <class TP, bool WELD>
 __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
-  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) s.rest_fact_valid = 0; } }   // new configuration: new factors
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) { s.rest_fact_valid = 0; s.reduced = 0; } } }   // new configuration: new factors
   stage_kinematics(s, m, lane);
   STAGE(1);
   stage_inertia(s, m, lane);
@@ -1041,18 +1103,52 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     // leaf-to-root sweep (body wrenches alpha I_b T_b and the contact wrenches of −df together) instead of a product
     // with M plus a fresh JT f.  vA holds the Newton right-hand side −grad, vD the magnitude of the summed terms.
     float* Gv = s.vC; float* rhs = s.vA; float* search = s.vB; float* magv = s.vD;
+    // Hybrid kernels, no rest body (head, abdomen, wings, ...) in contact: the cost depends on the rest's accelerations
+    // through the Gauss term only, so they are minimised out in closed form.  What is left is the same problem over
+    // root + legs with the rest's articulated inertia restA (from the factors of the smooth solve) added to the root
+    // and the same unconstrained accelerations; the Newton loop below then never visits the rest's tree levels, and
+    // the rest's accelerations follow from the root's at the end (one root-to-leaf pass over the cached factors).
+    bool red = false;
+    if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) {
+      red = s.body_cstart[TP::LB0] == s.body_cstart[1];
+      red = __builtin_amdgcn_readfirstlane(red ? 1 : 0) != 0;
+      if (red) {
+        if (lane < 21) {
+          float a = 0.f;
+          for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a += s.slot[(int)s.t_body[k] - TP::kSlot0][lane];
+          s.restA[lane] = a;
+        }
+        for (int j = lane; j < TP::NV; j += kWave) {
+          const bool rest = j >= 6 && j < TP::LD0;
+          search[j] = rest ? 0.f : s.qacc[j] - s.qacc_smooth[j];
+          if (rest) { Gv[j] = 0.f; rhs[j] = 0.f; magv[j] = 0.f; }
+        }
+        if (lane == 0) s.reduced = 1;
+        WSYNC();
+      }
+    } }
     // candidate 1: warm start
     float g = 0.f;
-    mul_M(s, s.qacc, m, lane, false, [&](int j, float v) {      // qacc still holds the warm start
-      const float gv = v - s.qfrc_smooth[j];
-      Gv[j] = gv;
-      g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * gv;
-    });
-    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
+    if (red) {
+      mul_M(s, search, m, lane, false, [&](int j, float v) {      // Gauss gradient M' (qacc − qacc_smooth)
+        Gv[j] = v;
+        g += 0.5f * search[j] * v;
+      });
+      if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);  // J (qacc − qacc_smooth); candidate 2 adds J qacc_smooth − aref
+      if (wr.on) wr.jar = s.T[0][wr.comp];
+    } else {
+      mul_M(s, s.qacc, m, lane, false, [&](int j, float v) {      // qacc still holds the warm start
+        const float gv = v - s.qfrc_smooth[j];
+        Gv[j] = gv;
+        g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * gv;
+      });
+      if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
 #pragma unroll
-      for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
-    if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
-    float gauss = wave_sum(g), ccost = constraint_cost<TP>(c, wr);
+        for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
+      if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
+    }
+    float gauss = wave_sum(g), ccost = 0.f;
+    if (!red) ccost = constraint_cost<TP>(c, wr);
     // candidate 2: unconstrained acceleration
     sweep_twists(s, s.qacc_smooth, s.T, m, lane);
     {
@@ -1062,6 +1158,12 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) { j0[k] -= c.aref[k]; if (j0[k] < 0.f) v += 0.5f * c.D * j0[k] * j0[k]; } }
       if (wr.on) { w0 = s.T[0][wr.comp] - wr.aref; v += 0.5f * wr.D * w0 * w0; }
+      if (red) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) c.jar[k] += j0[k];
+        wr.jar += w0;
+        ccost = constraint_cost<TP>(c, wr);
+      }
       const float cost_sm = wave_sum(v);
       if (cost_sm < gauss + ccost) {
         gauss = 0.f; ccost = cost_sm;
@@ -1102,7 +1204,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       float g1 = 0.f, g2 = 0.f;
       for (int j = lane; j < s.nv(); j += kWave) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; }
       for (int b = lane; b < s.nb(); b += kWave) {
-        const SV tb = ldsv(s.T[b]), wb = inert_mul(s.Ib[b], tb);
+        if constexpr (TP::kStar) { if (TP::REST_B > 0 && red && b >= 1 && b < TP::LB0) continue; }
+        const SV tb = ldsv(s.T[b]);
+        SV wb = inert_mul(s.Ib[b], tb);
+        if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (red && b == 0) wb = wb + rest_inertia_mul(s, tb); } }
         stsv(s.W[b], wb);
         g2 += dot(tb, wb);
       }
@@ -1183,6 +1288,19 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       if (c.on) contact_row_forces(c, 1.f, ff);
       contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, [&](int j, float v) { s.vD[j] = v; });
     }   // qfrc_constraint lives in vD until the Euler step
+    if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) {
+      if (red) {     // the rest's accelerations: qacc_smooth + the response of the cached factors to the root's change
+        if (lane < 6) {
+          float tw = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) tw += (s.qacc[j] - s.qacc_smooth[j]) * s.S[j][lane];
+          s.T[0][lane] = tw;
+        }
+        if (lane == 0) s.reduced = 0;
+        WSYNC();
+        tree_down(s, lane, [&](int b) { tree_aba_recover_body(s, b, ldsv(s.T[(int)s.t_parent[b]])); });
+      }
+    } }
   }
   if (lane == 0) s.iters = iters;
   STAGE(14);

@@ -250,6 +250,21 @@ __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a,
   stsv(s.T[b], a);
 }
 
+// reduced constraint problem (physics_forward): acceleration of body b's dofs relative to the unconstrained one when its
+// parent's acceleration changes by `a` and no force acts on the subtree — the homogeneous part of the expansion above
+template <class TP>
+__device__ __forceinline__ void tree_aba_recover_body(FlyLds<TP>& s, int b, SV a) {
+  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
+  for (int j = adr; j < adr + num; ++j) {
+    const float* f = s.fact[j - TP::kFact0];
+    const SV U = ldsv(f), S = ldsv(s.S[j]);
+    const float xj = -dot(U, a) * f[7];
+    s.qacc[j] = s.qacc_smooth[j] + xj;
+    a = a + xj * S;
+  }
+  stsv(s.T[b], a);
+}
+
 template <class TP, bool WELD>
 __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane) {
   const float* tau = s.vec(tau_id);
