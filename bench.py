@@ -268,7 +268,10 @@ def main():
         ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(n_launches)]))
         total_worlds = n_local * world_size
         value = total_worlds * args.steps / elapsed
-        achieved = BYTES_PER_ENV_STEP * n_local * spl / (ms * 1e-3) / 1e9
+        # SURVEY §8(d) formula on this model's sizes: read qpos + qvel + ctrl + warm start, write qpos + qvel + warm start
+        bytes_per_env_step = 4 * (2 * sim.model.nq + 4 * sim.model.nv + sim.model.nu)
+        assert args.joint_preset != "legs_only" or bytes_per_env_step == BYTES_PER_ENV_STEP
+        achieved = bytes_per_env_step * n_local * spl / (ms * 1e-3) / 1e9
         # HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
         # --pmc passes of this very command (profiles/hbm_traffic.json, written by scripts/summarize_profile.py)
         traffic = issue = None
@@ -301,9 +304,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>" if args.joint_preset == "legs_only" else
-                           "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>"), "kernel_ms_per_launch": ms,
-                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+                "kernel": {"legs_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>",
+                           "all_biological": "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>",
+                           "all_possible": "nmf_step_kernel<HybridTopo<20,60,6,3,3,3,3,3,3,3,3>, false>"}[args.joint_preset],
+                "kernel_ms_per_launch": ms,
+                "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 # instruction-issue side of the same kernel, from the SQ counters of the committed profile (profiles/*_summary.md)
                 "issue": issue,
                 "note": "the step is VALU-issue bound by construction (state crosses HBM once per launch); "
