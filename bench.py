@@ -212,8 +212,11 @@ def main():
 
     # observation gather: double-buffered so that the RCCL all-gather of tick k runs on RCCL's stream while the
     # stepping kernel of tick k + 1 already runs on the compute stream (the only exchange of the path)
-    obs_local = [torch.empty((n_local, OBS_DIM), dtype=torch.float32, device=sim.device) for _ in range(2)]
-    obs_all = [torch.empty((world_size * n_local, OBS_DIM), dtype=torch.float32, device=sim.device) for _ in range(2)] if use_dist else None
+    nj = sim.model.nv - 6                # joint angles, joint velocities, position-actuator forces, contact sensors
+    obs_dim = 2 * nj + 42 + 96
+    assert args.joint_preset != "legs_only" or obs_dim == OBS_DIM
+    obs_local = [torch.empty((n_local, obs_dim), dtype=torch.float32, device=sim.device) for _ in range(2)]
+    obs_all = [torch.empty((world_size * n_local, obs_dim), dtype=torch.float32, device=sim.device) for _ in range(2)] if use_dist else None
     pending = [None, None]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
@@ -231,10 +234,10 @@ def main():
             if pending[slot] is not None:
                 pending[slot].wait()          # the gather that last used this buffer pair (two ticks ago)
             ol = obs_local[slot]
-            ol[:, 0:66] = sim.field("qpos")[:, 7:]
-            ol[:, 66:132] = sim.field("qvel")[:, 6:]
-            ol[:, 132:174] = sim.field("actuator_force")[:, :42]
-            ol[:, 174:270] = sim.field("sensordata")
+            ol[:, 0:nj] = sim.field("qpos")[:, 7:]
+            ol[:, nj:2 * nj] = sim.field("qvel")[:, 6:]
+            ol[:, 2 * nj:2 * nj + 42] = sim.field("actuator_force")[:, :42]
+            ol[:, 2 * nj + 42:] = sim.field("sensordata")
             pending[slot] = dist.all_gather_into_tensor(obs_all[slot], ol, async_op=True)
 
     # untimed: one tick to settle allocator / RCCL channels

@@ -304,8 +304,28 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     rc |= upload(b, child_count, &d.tree_child_count);
     d.tree_nlevel = (int)lvl_start.size() - 1;
     for (size_t k = 0; k < 18; ++k) d.tree_lvl_start[k] = k < lvl_start.size() ? lvl_start[k] : (int)tree_body.size();
+    d.rest_fast = 0; d.rest_pack = nullptr;
+    if (topo >= 4) {
+      const HostArray* dn = model->find("body_dofnum");
+      const HostArray* da = model->find("body_dofadr");
+      const int nl = (int)lvl_start.size() - 2;                 // levels below the root
+      // NMF_DISABLE_REST_FAST: diagnostic switch, forces the table-driven level passes (tests cover both paths)
+      bool fast = da && nl <= nmf::kRestLevels && !getenv("NMF_DISABLE_REST_FAST");
+      std::vector<int> pack((size_t)nmf::kRestLevels * 16, -1);
+      for (int lv = 1; fast && lv <= nl; ++lv) {
+        const int k0 = lvl_start[(size_t)lv], k1 = lvl_start[(size_t)lv + 1];
+        fast = k1 - k0 <= 8;
+        for (int k = k0; fast && k < k1; ++k) {
+          const int bb = tree_body[(size_t)k];
+          fast = dn->i[(size_t)bb] == 3 && da->i[(size_t)bb] < 256 && child_count[(size_t)bb] < 256 && child_start[(size_t)bb] < 256;
+          pack[(size_t)((lv - 1) * 8 + (k - k0)) * 2] = bb | (bp->i[(size_t)bb] << 8) | (da->i[(size_t)bb] << 16) | (child_count[(size_t)bb] << 24);
+          pack[(size_t)((lv - 1) * 8 + (k - k0)) * 2 + 1] = child_start[(size_t)bb] | (k << 8);
+        }
+      }
+      if (fast) { d.rest_fast = 1; const int* pp = nullptr; rc |= upload(b, pack, &pp); d.rest_pack = reinterpret_cast<const unsigned int*>(pp); }
+    }
   } else {
-    d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0;
+    d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0; d.rest_fast = 0; d.rest_pack = nullptr;
   }
   if (rc == 0) {
     void* p = nullptr;

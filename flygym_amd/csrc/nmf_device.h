@@ -14,6 +14,7 @@
 namespace nmf {
 
 constexpr int kWave = 64;
+constexpr int kRestLevels = 6;   // levels below the root the fast passes of the hybrid kernels unroll
 constexpr int kMaxCon = 48;      // contacts per fly kept by the engine (overflow is flagged)
 constexpr int kMaxCtrl = 48;
 constexpr float kMinVal = 1e-15f;
@@ -92,6 +93,11 @@ struct DevModel {
   // general-tree kernel only: bodies in breadth-first order (level by level, children of a body contiguous)
   const int *body_parent, *tree_body, *tree_child_start, *tree_child_count;   // child ranges index tree_body
   int tree_nlevel, tree_lvl_start[18];
+  // hybrid kernels, fast level passes: every body of the rest has exactly three dofs, at most kRestLevels levels of at
+  // most 8 bodies.  rest_pack[level - 1][group][2]: body | parent << 8 | first dof << 16 | children << 24,
+  // first child (breadth-first slot) | own breadth-first slot << 8;  0xffffffff = no body for that group
+  int rest_fast;
+  const unsigned int* rest_pack;
   const float *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
   const int* seg_body;
   const float *seg_pos, *seg_quat;

@@ -37,7 +37,12 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_ARG , StageClock& sc_
 #define STAGE_PASS , sc_
 #define STAGE(k) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sc_.acc[k] += t_ - sc_.last; sc_.last = clock64(); } } while (0)
+// sub-stages inside a non-inlined function (block 0 only, straight to the global accumulators 18..23)
+#define SUB_T0() unsigned long long sub_t_ = clock64()
+#define SUB(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sub_t_; sub_t_ = clock64(); } } while (0)
 #else
+#define SUB_T0()
+#define SUB(k)
 #define STAGE_INIT()
 #define STAGE_ARG
 #define STAGE_PASS
@@ -76,6 +81,7 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
   // eliminated from the Newton loop — the root carries the rest's articulated inertia restA (symmetric 6x6) instead
   int reduced;
   float restA[21];
+  unsigned int t_pack[kRestLevels][8][2];   // fast level passes: DevModel::rest_pack staged
   NMF_TREE_TABLES
 };
 
@@ -199,8 +205,15 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
                                                         const DevModel& m, const Frame& fr);
 template <class TP>
 __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m);
-template <class TP>
-__device__ __forceinline__ void tree_aba_recover_body(FlyLds<TP>& s, int b, SV a);
+struct RestNode;
+template <class TP, bool FAST, bool UP, class F> __device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f);
+template <class TP, int NUM>
+__device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6]);
+template <class TP, int NUM>
+__device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
+template <class TP, int NUM, bool HOMOGENEOUS>
+__device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& nd, float* x, const LaneRole& L);
 template <class TP>
 __device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m);
 
@@ -688,17 +701,22 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // hybrid: the rest of the body (head, abdomen, wings, ...) is eliminated level by level first; its children-of-root
   // hand their articulated inertias to the root below through s.slot
   const bool red = rest_reduced(s);
+  SUB_T0();
   if constexpr (TP::REST_B > 0) {
     const bool rest_K = withK && s.body_cstart[TP::LB0] > s.body_cstart[1];     // contact stiffness on a rest body
     const bool reuse = s.rest_fact_valid != 0 && s.rest_fact_hdamp == hdamp && !rest_K;
     if (red) {}
-    else if (reuse) tree_up(s, lane, [&](int b) { tree_aba_eliminate_body_reuse(s, b, tau, m); });
-    else {
-      tree_up(s, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
+    else if (reuse) {
+      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 3>(s, nd, tau, L); });
+      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 0>(s, nd, tau, L); });
+    } else {
+      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so); });
+      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so); });
       if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
       WSYNC();
     }
   }
+  SUB(18);
   float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float pA = 0.f;
   // ---- backward sweep along the leg
@@ -753,7 +771,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
         for (int i = 0; i < 6; i++) row[i] += s.restA[so[i]];
       } else
       for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
-        const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
+        const float* sl = s.slot[k - 1];               // hybrid: slots in breadth-first order
 #pragma unroll
         for (int i = 0; i < 6; i++) row[i] += sl[so[i]];
         pA += sl[21 + L.rr];
@@ -789,9 +807,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
   });
   WSYNC();
+  SUB(19);
   if constexpr (TP::REST_B > 0) {
-    if (!red) tree_down(s, lane, [&](int b) { tree_aba_expand_body(s, b, ldsv(s.T[(int)s.t_parent[b]]), x, m); });
+    if (!red) {
+      if (m.rest_fast) rest_levels<TP, true, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 3, false>(s, nd, x, L); });
+      else rest_levels<TP, false, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 0, false>(s, nd, x, L); });
+    }
   }
+  SUB(20);
   }
 }
 
@@ -1115,7 +1138,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
       if (red) {
         if (lane < 21) {
           float a = 0.f;
-          for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a += s.slot[(int)s.t_body[k] - TP::kSlot0][lane];
+          for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a += s.slot[k - 1][lane];
           s.restA[lane] = a;
         }
         for (int j = lane; j < TP::NV; j += kWave) {
@@ -1298,7 +1321,9 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
         }
         if (lane == 0) s.reduced = 0;
         WSYNC();
-        tree_down(s, lane, [&](int b) { tree_aba_recover_body(s, b, ldsv(s.T[(int)s.t_parent[b]])); });
+        const LaneRole L = lane_role<TP>(lane);
+        if (m.rest_fast) rest_levels<TP, true, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 3, true>(s, nd, s.qacc, L); });
+        else rest_levels<TP, false, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 0, true>(s, nd, s.qacc, L); });
       }
     } }
   }
@@ -1411,6 +1436,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = threadIdx.x; j < TP::kTblV && j < m.nv; j += kWave) s.t_dofbody[j] = (unsigned char)m.dof_body[j];
     if (threadIdx.x < 18) s.t_lvl[threadIdx.x] = (unsigned char)m.tree_lvl_start[threadIdx.x];
     if (threadIdx.x == 0) s.t_nlevel = (unsigned char)m.tree_nlevel;
+    if constexpr (TP::kStar) {
+      for (int i = threadIdx.x; i < kRestLevels * 16; i += kWave) (&s.t_pack[0][0][0])[i] = m.rest_fast ? m.rest_pack[i] : 0xffffffffu;
+    }
     __syncthreads();
   }
   const int lane = threadIdx.x;

@@ -250,19 +250,186 @@ __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a,
   stsv(s.T[b], a);
 }
 
-// reduced constraint problem (physics_forward): acceleration of body b's dofs relative to the unconstrained one when its
-// parent's acceleration changes by `a` and no force acts on the subtree — the homogeneous part of the expansion above
+// ---------------------------------------------------------------- hybrid kernels: the rest's ABA in the leg chains' lane layout
+// One 8-lane group per body of a level (the fly's rest has at most 6 bodies per level): lane r < 6 of the group carries
+// row r of the body's articulated inertia and component r of its bias wrench, group sums by DPP.  Same LDS hand-off as
+// above (s.fact per dof, s.slot: upper triangle + bias wrench), the slots in breadth-first order so that the children
+// of a body are contiguous.
+// A level pass is a chain of dependent LDS round trips (level table -> body -> dof range -> axes -> ...), ~100 cycles
+// each with one or two waves per SIMD, and that chain, not the arithmetic, is its cost.  FAST (DevModel::rest_fast: three
+// dofs per body, <= kRestLevels levels of <= 8 bodies): the (level, group) -> body / parent / dofs / children table is
+// one packed 8-byte word per lane and level, fetched for all levels at once, and the dof loops are unrolled, so every
+// load of a body is issued up front — one round trip per body plus one per child.
+struct RestNode { int b, parent, adr, ccount, cstart, k; };   // body, its parent, first dof, children (count, first slot), own slot
+
 template <class TP>
-__device__ __forceinline__ void tree_aba_recover_body(FlyLds<TP>& s, int b, SV a) {
-  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
-  for (int j = adr; j < adr + num; ++j) {
-    const float* f = s.fact[j - TP::kFact0];
-    const SV U = ldsv(f), S = ldsv(s.S[j]);
-    const float xj = -dot(U, a) * f[7];
-    s.qacc[j] = s.qacc_smooth[j] + xj;
-    a = a + xj * S;
+__device__ __forceinline__ RestNode rest_node_tbl(const FlyLds<TP>& s, int k) {
+  RestNode nd;
+  nd.k = k; nd.b = (int)s.t_body[k];
+  nd.parent = (int)s.t_parent[nd.b]; nd.adr = (int)s.t_dofadr[nd.b];
+  nd.ccount = (int)s.t_ccount[nd.b]; nd.cstart = (int)s.t_cstart[nd.b];
+  return nd;
+}
+
+// f(node) for every body of the rest, level by level: UP = deepest level first
+template <class TP, bool FAST, bool UP, class F>
+__device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f) {
+  const int nl = __builtin_amdgcn_readfirstlane((int)s.t_nlevel) - 1;      // levels below the root
+  if constexpr (FAST) {
+    unsigned int w0[kRestLevels], w1[kRestLevels];
+#pragma unroll
+    for (int l = 0; l < kRestLevels; ++l) { w0[l] = s.t_pack[l][lane >> 3][0]; w1[l] = s.t_pack[l][lane >> 3][1]; }
+    static_for<kRestLevels>([&](auto I) {
+      constexpr int l = UP ? kRestLevels - 1 - decltype(I)::value : decltype(I)::value;
+      if (l < nl) {
+        if (w0[l] != 0xffffffffu) {
+          RestNode nd;
+          nd.b = w0[l] & 255; nd.parent = (w0[l] >> 8) & 255; nd.adr = (w0[l] >> 16) & 255; nd.ccount = w0[l] >> 24;
+          nd.cstart = w1[l] & 255; nd.k = (w1[l] >> 8) & 255;
+          f(nd);
+        }
+        WSYNC();
+      }
+    });
+  } else {
+    for (int i = 0; i < nl; ++i) {
+      const int lvl = UP ? nl - i : 1 + i;
+      for (int k = (int)s.t_lvl[lvl] + (lane >> 3); k < (int)s.t_lvl[lvl + 1]; k += 8) f(rest_node_tbl(s, k));
+      WSYNC();
+    }
   }
-  stsv(s.T[b], a);
+}
+
+// the dofs of a body, last to first (REV) or first to last; NUM > 0: a compile-time count (fully unrolled, so the LDS
+// loads of all dofs are issued up front), NUM == 0: the run-time count
+template <int NUM, bool REV, class F>
+__device__ __forceinline__ void rest_dofs(int adr, int num, F&& f) {
+  if constexpr (NUM > 0) {
+    static_for<NUM>([&](auto I) { constexpr int i = decltype(I)::value; f(adr + (REV ? NUM - 1 - i : i)); });
+  } else if (REV) { for (int j = adr + num - 1; j >= adr; --j) f(j); }
+  else { for (int j = adr; j < adr + num; ++j) f(j); }
+}
+
+// full elimination of a body: matrix factors and vector part
+template <class TP, int NUM>
+__device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6]) {
+  const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
+  // everything that depends on the node only, first: the body's inertia row and its dofs' axes and scalars
+  float row[6];
+  inertia_row(s.Ib[nd.b], L.rr, row);
+  float sj[NUM > 0 ? NUM : 1][6], sown[NUM > 0 ? NUM : 1], delta[NUM > 0 ? NUM : 1], tj[NUM > 0 ? NUM : 1];
+  if constexpr (NUM > 0) {
+#pragma unroll
+    for (int d = 0; d < NUM; ++d) {
+      const int j = nd.adr + d;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sj[d][i] = s.S[j][i];
+      sown[d] = s.S[j][L.rr]; delta[d] = s.arm[j] + hdamp * s.damp[j]; tj[d] = tau[j];
+    }
+  }
+  float pA = 0.f;
+  for (int k = nd.cstart - 1; k < nd.cstart - 1 + nd.ccount; ++k) {
+    const float* sl = s.slot[k];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[c] += sl[so[c]];
+    pA += sl[21 + L.rr];
+  }
+  if (withK)
+    for (int c = s.body_cstart[nd.b]; c < s.body_cstart[nd.b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+  if constexpr (NUM > 0) {
+    static_for<NUM>([&](auto I) {
+      constexpr int d = NUM - 1 - decltype(I)::value;
+      float U, u, invD;
+      aba_step(row, pA, sj[d], sown[d], L.mask, delta[d], tj[d], U, u, invD);
+      float* f = s.fact[nd.adr + d - TP::kFact0];
+      if (L.r < 6) f[L.rr] = U;
+      if (L.r == 0) { f[6] = u; f[7] = invD; }
+    });
+  } else {
+    for (int j = nd.adr + num - 1; j >= nd.adr; --j) {
+      float s1[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) s1[i] = s.S[j][i];
+      float U, u, invD;
+      aba_step(row, pA, s1, s.S[j][L.rr], L.mask, s.arm[j] + hdamp * s.damp[j], tau[j], U, u, invD);
+      float* f = s.fact[j - TP::kFact0];
+      if (L.r < 6) f[L.rr] = U;
+      if (L.r == 0) { f[6] = u; f[7] = invD; }
+    }
+  }
+  if (L.r < 6) {
+    float* sl = s.slot[nd.k - 1];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) if (c >= L.rr) sl[so[c]] = row[c];
+    sl[21 + L.rr] = pA;
+  }
+}
+
+// vector part only, over factors kept from a full elimination of the same matrix
+template <class TP, int NUM>
+__device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L) {
+  const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
+  float sown[NUM > 0 ? NUM : 1], Uj[NUM > 0 ? NUM : 1], invD[NUM > 0 ? NUM : 1], tj[NUM > 0 ? NUM : 1];
+  if constexpr (NUM > 0) {
+#pragma unroll
+    for (int d = 0; d < NUM; ++d) {
+      const int j = nd.adr + d;
+      const float* f = s.fact[j - TP::kFact0];
+      sown[d] = L.mask * s.S[j][L.rr]; Uj[d] = f[L.rr]; invD[d] = f[7]; tj[d] = tau[j];
+    }
+  }
+  float pA = 0.f;
+  for (int k = nd.cstart - 1; k < nd.cstart - 1 + nd.ccount; ++k) pA += s.slot[k][21 + L.rr];
+  if constexpr (NUM > 0) {
+    static_for<NUM>([&](auto I) {
+      constexpr int d = NUM - 1 - decltype(I)::value;
+      const float u = tj[d] - grp8_sum(sown[d] * pA);
+      if (L.r == 0) s.fact[nd.adr + d - TP::kFact0][6] = u;
+      pA += Uj[d] * (u * invD[d]);
+    });
+  } else {
+    for (int j = nd.adr + num - 1; j >= nd.adr; --j) {
+      float* f = s.fact[j - TP::kFact0];
+      const float u = tau[j] - grp8_sum(L.mask * s.S[j][L.rr] * pA);
+      if (L.r == 0) f[6] = u;
+      pA += f[L.rr] * (u * f[7]);
+    }
+  }
+  if (L.r < 6) s.slot[nd.k - 1][21 + L.rr] = pA;
+}
+
+// back-substitution of a body given its parent's acceleration in T; HOMOGENEOUS: no force on the subtree, the dofs'
+// accelerations are written to qacc as changes of the unconstrained ones (reduced constraint problem, physics_forward)
+template <class TP, int NUM, bool HOMOGENEOUS>
+__device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& nd, float* x, const LaneRole& L) {
+  const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
+  float a = s.T[nd.parent][L.rr];
+  if constexpr (NUM > 0) {
+    float sown[NUM], Uj[NUM], uj[NUM], invD[NUM], base[NUM];
+#pragma unroll
+    for (int d = 0; d < NUM; ++d) {
+      const int j = nd.adr + d;
+      const float* f = s.fact[j - TP::kFact0];
+      sown[d] = s.S[j][L.rr]; Uj[d] = L.mask * f[L.rr]; uj[d] = HOMOGENEOUS ? 0.f : f[6]; invD[d] = f[7];
+      base[d] = HOMOGENEOUS ? s.qacc_smooth[j] : 0.f;
+    }
+    static_for<NUM>([&](auto I) {
+      constexpr int d = decltype(I)::value;
+      const float xj = (uj[d] - grp8_sum(Uj[d] * a)) * invD[d];
+      if (L.r == 0) { if (HOMOGENEOUS) s.qacc[nd.adr + d] = base[d] + xj; else x[nd.adr + d] = xj; }
+      a += xj * sown[d];
+    });
+  } else {
+    for (int j = nd.adr; j < nd.adr + num; ++j) {
+      const float* f = s.fact[j - TP::kFact0];
+      const float Ua = grp8_sum(L.mask * f[L.rr] * a);
+      const float xj = HOMOGENEOUS ? -Ua * f[7] : (f[6] - Ua) * f[7];
+      if (L.r == 0) { if (HOMOGENEOUS) s.qacc[j] = s.qacc_smooth[j] + xj; else x[j] = xj; }
+      a += xj * s.S[j][L.rr];
+    }
+  }
+  if (L.r < 6) s.T[nd.b][L.rr] = a;
 }
 
 template <class TP, bool WELD>

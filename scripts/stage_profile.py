@@ -32,9 +32,10 @@ sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
 L.nmf_debug_stage_cycles(buf, 24, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
          "ABA smooth", "solver init + first grad", "newton: test/exit", "newton: ABA(H)", "newton: jv, g1, g2", "newton: linesearch",
-         "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors"]
+         "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors",
+         "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
-tot = cyc.sum()
+tot = cyc[:18].sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
 for nm, c in zip(names, cyc):
     print(f"  {nm:24s} {c:9.0f}  {100*c/tot:5.1f}%")

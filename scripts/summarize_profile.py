@@ -77,11 +77,12 @@ if fetch and write:
     # MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on
     # gfx950 (this kernel's reads are dword-wide, so the x2 is an upper bound); WRITE_SIZE uncalibrated.
     traffic = (2 * fk + wk) * 1024
-    algo = 1928 * b["config"]["worlds_per_gpu"] * b["config"]["steps_per_launch"]
+    per = b["roofline"].get("algorithmic_bytes_per_env_step", 1928)
+    algo = per * b["config"]["worlds_per_gpu"] * b["config"]["steps_per_launch"]
     out.append(f"## HBM traffic per timed launch (PMC, separate passes)\n\nFETCH_SIZE {fk:.1f} KiB (x2 gfx950 correction -> {2*fk*1024/1e6:.2f} MB), "
                f"WRITE_SIZE {wk:.1f} KiB ({wk*1024/1e6:.2f} MB) -> traffic **{traffic/1e6:.2f} MB** per launch; algorithmic bytes "
-               f"(1928 B x worlds x steps) = {algo/1e6:.2f} MB; compulsory state+table traffic of a {b['config']['steps_per_launch']}-step persistent launch = "
-               f"{(1928 + 168*b['config']['steps_per_launch']) * b['config']['worlds_per_gpu']/1e6:.2f} MB\n")
+               f"({per} B x worlds x steps) = {algo/1e6:.2f} MB; compulsory state+table traffic of a {b['config']['steps_per_launch']}-step persistent launch = "
+               f"{(per + 168*b['config']['steps_per_launch']) * b['config']['worlds_per_gpu']/1e6:.2f} MB\n")
 sq = {**counters("pmc_sq"), **counters("pmc_sq2")}
 if sq:
     out.append("## SQ counters per timed launch (mean)\n\n| counter | value |\n|---|---|")
@@ -106,7 +107,9 @@ if traffic is not None:
                  "valu_active_per_wave": sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_WAVE_CYCLES"],
                  "valu_busy_per_simd": 2.0 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_WAVE_CYCLES"],
                  "wait_any_per_wave": sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]}
-    (dst / "hbm_traffic.json").write_text(json.dumps({
+    # bench.py reads hbm_traffic.json for its default (LEGS_ONLY) command; other skeletons keep their own file
+    headline = "HybridTopo<0,0," in b["roofline"].get("kernel", "HybridTopo<0,0,")
+    (dst / ("hbm_traffic.json" if headline else f"{tag}_traffic.json")).write_text(json.dumps({
         "profile": tag, "traffic_bytes_per_launch": traffic, "worlds_per_gpu": b["config"]["worlds_per_gpu"],
         "steps_per_launch": b["config"]["steps_per_launch"], "control": b["config"].get("control"), "issue": issue,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, FETCH_SIZE x2 (gfx950), "
