@@ -30,11 +30,36 @@ __device__ __forceinline__ void tree_up(const S& s, int lane, F&& f) {
   }
 }
 
+// Hybrid kernels with DevModel::rest_fast (three dofs per rest body, <= kRestLevels levels of <= 8 bodies): the level
+// passes below fetch (body, parent, first dof, children) of all their levels as one packed word pair per lane up front
+// (t_pack) instead of walking the byte tables level by level, and unroll the three dofs — the passes are chains of
+// dependent LDS round trips, and this removes most of them.  Lane g < 8 takes the g-th body of a level.
+struct RestNode { int b, parent, adr, ccount, cstart, k; };   // body, its parent, first dof, children (count, first slot), own slot
+__device__ __forceinline__ RestNode rest_unpack(unsigned int w0, unsigned int w1) {
+  RestNode nd;
+  nd.b = w0 & 255; nd.parent = (w0 >> 8) & 255; nd.adr = (w0 >> 16) & 255; nd.ccount = w0 >> 24;
+  nd.cstart = w1 & 255; nd.k = (w1 >> 8) & 255;
+  return nd;
+}
+template <class TP, bool UP, class F>
+__device__ __forceinline__ void rest_levels_lane(FlyLds<TP>& s, int lane, F&& f) {
+  const int nl = __builtin_amdgcn_readfirstlane((int)s.t_nlevel) - 1;      // levels below the root
+  unsigned int w0[kRestLevels], w1[kRestLevels];
+#pragma unroll
+  for (int l = 0; l < kRestLevels; ++l) { w0[l] = s.t_pack[l][lane & 7][0]; w1[l] = s.t_pack[l][lane & 7][1]; }
+  static_for<kRestLevels>([&](auto I) {
+    constexpr int l = UP ? kRestLevels - 1 - decltype(I)::value : decltype(I)::value;
+    if (l < nl) {
+      if (lane < 8 && w0[l] != 0xffffffffu) f(rest_unpack(w0[l], w1[l]));
+      WSYNC();
+    }
+  });
+}
+
 // rigid transforms down the tree: R_b = R_parent Rrel_b, p_b = p_parent + R_parent off_b  (relm[b] = Rrel (9), off (3))
 template <class TP>
 __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]) {
-  tree_down(s, lane, [&](int b) {
-    const int p = (int)s.t_parent[b];
+  auto body = [&](int b, int p) {
     const float* R = s.xmat[p];
     const float* M = relm[b];
     st3(s.xpos[b], ld3(s.xpos[p]) + mat_vec(R, ld3(M + 9)));
@@ -45,7 +70,11 @@ __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane
       for (int j = 0; j < 3; ++j) out[3 * i + j] = R[3 * i] * M[j] + R[3 * i + 1] * M[3 + j] + R[3 * i + 2] * M[6 + j];
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.xmat[b][i] = out[i];
-  });
+  };
+  if constexpr (TP::kStar) {
+    if (m.rest_fast) { rest_levels_lane<TP, false>(s, lane, [&](const RestNode& nd) { body(nd.b, nd.parent); }); return; }
+  }
+  tree_down(s, lane, [&](int b) { body(b, (int)s.t_parent[b]); });
 }
 
 // body velocities -> W, bias accelerations (parent acceleration of the root = -gravity) -> T
@@ -68,6 +97,20 @@ __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
 // the levels below the root (W[0], T[0] given)
 template <class TP>
 __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane) {
+  if constexpr (TP::kStar) {
+    if (m.rest_fast) {
+      rest_levels_lane<TP, false>(s, lane, [&](const RestNode& nd) {
+        SV v = ldsv(s.W[nd.parent]), a = ldsv(s.T[nd.parent]);
+        SV S[3]; float qd[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { S[d] = ldsv(s.S[nd.adr + d]); qd[d] = s.qvel[nd.adr + d]; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a = a + qd[d] * cross_motion(v, S[d]); v = v + qd[d] * S[d]; }
+        stsv(s.W[nd.b], v); stsv(s.T[nd.b], a);
+      });
+      return;
+    }
+  }
   tree_down(s, lane, [&](int b) {
     const int p = (int)s.t_parent[b], adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
     SV v = ldsv(s.W[p]), a = ldsv(s.T[p]);
@@ -260,8 +303,6 @@ __device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a,
 // dofs per body, <= kRestLevels levels of <= 8 bodies): the (level, group) -> body / parent / dofs / children table is
 // one packed 8-byte word per lane and level, fetched for all levels at once, and the dof loops are unrolled, so every
 // load of a body is issued up front — one round trip per body plus one per child.
-struct RestNode { int b, parent, adr, ccount, cstart, k; };   // body, its parent, first dof, children (count, first slot), own slot
-
 template <class TP>
 __device__ __forceinline__ RestNode rest_node_tbl(const FlyLds<TP>& s, int k) {
   RestNode nd;
@@ -282,12 +323,7 @@ __device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f) {
     static_for<kRestLevels>([&](auto I) {
       constexpr int l = UP ? kRestLevels - 1 - decltype(I)::value : decltype(I)::value;
       if (l < nl) {
-        if (w0[l] != 0xffffffffu) {
-          RestNode nd;
-          nd.b = w0[l] & 255; nd.parent = (w0[l] >> 8) & 255; nd.adr = (w0[l] >> 16) & 255; nd.ccount = w0[l] >> 24;
-          nd.cstart = w1[l] & 255; nd.k = (w1[l] >> 8) & 255;
-          f(nd);
-        }
+        if (w0[l] != 0xffffffffu) f(rest_unpack(w0[l], w1[l]));
         WSYNC();
       }
     });
