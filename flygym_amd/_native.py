@@ -12,6 +12,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libnmf_hip.so"
+MATH_FLAGS = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-signed-zeros", "-fassociative-math", "-fno-trapping-math", "-fno-math-errno", "-fapprox-func"]
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 
@@ -29,15 +30,19 @@ class NativeError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_device.h",
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h",
             INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     # -fno-slp-vectorize: the SLP vectoriser packs the 6-vector arithmetic into v_pk_* pairs and pays for it in v_mov
     # shuffles and register pressure (12 spilled VGPRs); scalar code is 9 % faster on the step kernel.  The iterative
     # ILP scheduler interleaves the independent chains of the unrolled sweeps better than the default (+5 %).
+    # Arithmetic: divisions and square roots to 1-2.5 ulp (v_rcp / v_sqrt without the correctly-rounded fix-up sequences),
+    # reassociation and no signed zeros (+3.7 % together); NaN / Inf semantics are kept (no -ffinite-math-only), and the
+    # only transcendental of the step, the joint-angle sincos, is the kernel's own polynomial (nmf_device.h).
     cmd = [
-        "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC", "-shared",
+        "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+        *MATH_FLAGS, "-fPIC", "-shared",
         f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(LIB_PATH),
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)

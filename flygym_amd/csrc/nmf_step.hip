@@ -228,7 +228,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
   for (int j = 6 + lane; j < s.nv(); j += kWave) {
     float sn, cs;
-    sincosf(0.5f * s.qpos[j + 1], &sn, &cs);
+    sincos_bounded(0.5f * s.qpos[j + 1], &sn, &cs);
     jq[j][0] = cs; jq[j][1] = m.dof_axis[3 * j] * sn; jq[j][2] = m.dof_axis[3 * j + 1] * sn;
     jq[j][3] = m.dof_axis[3 * j + 2] * sn;
   }
@@ -1379,7 +1379,7 @@ __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STA
     Q4 q = ldq(&s.qpos[3]);
     if (wn > kMinVal) {
       float sn, cs;
-      sincosf(0.5f * h * wn, &sn, &cs);
+      sincos_bounded(0.5f * h * wn, &sn, &cs);
       V3 ax = (sn / wn) * w;
       q = qmul(q, Q4{cs, ax.x, ax.y, ax.z});
     }

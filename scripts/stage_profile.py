@@ -7,7 +7,7 @@ import numpy as np, torch
 from flygym_amd import _native
 lib_prof = ROOT / "flygym_amd" / "libnmf_hip_prof.so"
 if "--build" in sys.argv or not lib_prof.exists():
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC", "-shared", "-DNMF_STAGE_PROFILE",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *_native.MATH_FLAGS, "-fPIC", "-shared", "-DNMF_STAGE_PROFILE",
                     f"-I{ROOT/'include'}", f"-I{ROOT/'flygym_amd/csrc'}", str(ROOT/"flygym_amd/csrc/nmf_capi.hip"), "-o", str(lib_prof)], check=True)
     if "--build" in sys.argv: sys.exit(0)
 _native.LIB_PATH = lib_prof
