@@ -214,8 +214,6 @@ template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
 template <class TP, int NUM, bool HOMOGENEOUS>
 __device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& nd, float* x, const LaneRole& L);
-template <class TP>
-__device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m);
 
 // ------------------------------------------------------------------ kinematics
 template <class TP>

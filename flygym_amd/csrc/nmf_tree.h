@@ -185,36 +185,6 @@ __device__ __forceinline__ void contact_dirs(V3 r, const Frame& fr, float* ln, f
 //   down : x_j = (u_j - U_j . a) / D_j,  a += s_j x_j
 // The per-body pieces are separate so that the hybrid kernels (legs unrolled, the rest of the body as a tree) can run
 // them on the rest bodies only.  TP::kFact0 = first dof that has a `fact` slot, TP::kSlot0 = first body with a `slot`.
-// Vector-only elimination of body b with the matrix part (U, 1/D per dof in s.fact, the articulated inertia handed to the
-// parent in s.slot) kept from an earlier full elimination of the SAME matrix: only u and the bias wrench are redone.
-template <class TP>
-__device__ __forceinline__ void tree_aba_eliminate_body_reuse(FlyLds<TP>& s, int b, const float* tau, const DevModel& m) {
-  float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
-  for (int k = c0; k < c1; ++k) {
-    const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pA[i] += sl[21 + i];
-  }
-  const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
-  for (int j = adr + num - 1; j >= adr; --j) {
-    float* f = s.fact[j - TP::kFact0];
-    float sp = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sp += s.S[j][i] * pA[i];
-    const float u = tau[j] - sp;
-    f[6] = u;
-    const float ku = u * f[7];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pA[i] += f[i] * ku;
-  }
-  if (b >= TP::kSlot0) {
-    float* sl = s.slot[b - TP::kSlot0];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sl[21 + i] = pA[i];
-  }
-}
-
 template <class TP, bool WELD>
 __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
                                                         const DevModel& m, const Frame& fr) {
