@@ -692,7 +692,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr;
     so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
   }
-  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[TP::NDL];   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j
+  // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
+  // forward sweep instead of keeping it: 24 registers fewer to spill
+  constexpr bool kKeepS = TP::NDL <= 16;
+  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[kKeepS ? TP::NDL : 1];
   int cs[TP::NBL + 1], cs_root0 = 0, cs_root1 = 0;                         // contact ranges of the leg's bodies / the root
   static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK ? s.body_cstart[b0 + l] : 0; });
   if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
@@ -736,7 +739,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
     for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
     const float sown = s.S[j][L.rr];
-    Sreg[d] = sown;
+    if constexpr (kKeepS) Sreg[d] = sown;
     aba_step(IA, pA, sj, sown, L.mask, s.arm[j] + hdamp * s.damp[j], tau[j], Ureg[d], ureg[d], invDreg[d]);
   });
 #pragma unroll
@@ -801,7 +804,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     const int j = j0 + d;
     const float xj = (ureg[d] - grp8_sum(Ureg[d] * a)) * invDreg[d];
     x[j] = xj;
-    a += xj * Sreg[d];
+    if constexpr (kKeepS) a += xj * Sreg[d]; else a += xj * s.S[j][L.rr];
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
   });
   WSYNC();
