@@ -54,7 +54,7 @@ def parse_args():
                     help="flat = BASELINE config 2; gapped/blocks = config 4; mixed = config 5 (build-defined height maps)")
     ap.add_argument("--cpg-adhesion", type=float, default=0.0, metavar="ON",
                     help="drive leg adhesion from the CPG: control ON in stance, 1 (the reference's minimum) in swing (config 5)")
-    ap.add_argument("--joint-preset", choices=["legs_only", "all_biological"], default="legs_only",
+    ap.add_argument("--joint-preset", choices=["legs_only", "legs_active_only", "all_biological"], default="legs_only",
                     help="skeleton: the benchmark's LEGS_ONLY (default) or the full-body ALL_BIOLOGICAL (hybrid kernel)")
     ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
@@ -291,7 +291,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", " + (f"{args.joint_preset.upper()} fly (nq {sim.model.nq}, nv {sim.model.nv}, nu {sim.model.nu}), 55 geom-plane pairs ")
+                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", " + (f"{args.joint_preset.upper()} fly (nq {sim.model.nq}, nv {sim.model.nv}, nu {sim.model.nu}), {sim.model.ng} geom-plane pairs ")
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else
@@ -308,6 +308,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": {"legs_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>",
+                           "legs_active_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1>, false>",
                            "all_biological": "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>",
                            "all_possible": "nmf_step_kernel<HybridTopo<20,60,6,3,3,3,3,3,3,3,3>, false>"}[args.joint_preset],
                 "kernel_ms_per_launch": ms,
