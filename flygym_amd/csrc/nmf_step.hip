@@ -746,8 +746,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
   H.legpA[L.lg][L.rr] = pA;
   WSYNC();
-  // ---- root: every group eliminates the six root dofs redundantly (no single-lane solve, no broadcast)
-  float Ur[6], ur[6], invDr[6], Sr[6];
+  // ---- root: every group eliminates the six root dofs redundantly (no single-lane solve, no broadcast).
+  // The free joint spans all six spatial directions, so the elimination runs in world axes (angular x, y, z about the
+  // root origin, then linear x, y, z) instead of the joint's own (body-frame rotation axes): with unit axes U is a column
+  // of IA, D and s.pA are single entries (one group broadcast each, and D's is one of the six U broadcasts the rank-1
+  // update needs anyway) — 11 instead of 28 vector instructions per dof.  Generalized forces go in as R tau_rot, the
+  // rotational accelerations come out as RT alpha.
+  float Ur[6], ur[6], invDr[6];
+  float Rm[3][3];                       // Rm[c][k] = component c of the k-th rotation axis of the free joint
   {
     float row[6];
     if constexpr (kHasIsym<TP>) {
@@ -780,24 +786,47 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) IA[i] = row[i];
-    static_for<6>([&](auto DD) {
-      constexpr int j = 5 - decltype(DD)::value;
-      float sj[6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
-      const float sown = s.S[j][L.rr];
-      Sr[j] = sown;
-      aba_step(IA, pA, sj, sown, L.mask, 0.f, tau[j], Ur[j], ur[j], invDr[j]);
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rm[c][k] = s.S[3 + k][c];
+    float tw[6];
+    const float t3 = tau[3], t4 = tau[4], t5 = tau[5];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { tw[c] = Rm[c][0] * t3 + Rm[c][1] * t4 + Rm[c][2] * t5; tw[3 + c] = tau[c]; }
+    static_for<6>([&](auto DD) {
+      constexpr int i = decltype(DD)::value;
+      constexpr int e = i < 3 ? 2 - i : 8 - i;          // angular z, y, x, then linear z, y, x
+      const float U = IA[e];
+      const float b0 = grp8_bcast<0>(U), b1 = grp8_bcast<1>(U), b2 = grp8_bcast<2>(U), b3 = grp8_bcast<3>(U),
+                  b4 = grp8_bcast<4>(U), b5 = grp8_bcast<5>(U);
+      const float D = e == 0 ? b0 : e == 1 ? b1 : e == 2 ? b2 : e == 3 ? b3 : e == 4 ? b4 : b5;
+      const float sp = grp8_bcast<e>(pA);
+      const float invD = __builtin_amdgcn_rcpf(D);
+      const float u = tw[e] - sp;
+      const float k = U * invD;
+      IA[0] -= k * b0; IA[1] -= k * b1; IA[2] -= k * b2; IA[3] -= k * b3; IA[4] -= k * b4; IA[5] -= k * b5;
+      pA += k * u;
+      Ur[e] = L.mask * U; ur[e] = u; invDr[e] = invD;
     });
   }
-  // ---- forward sweep: root dofs, then down the leg
+  // ---- forward sweep: root (linear x, y, z, then angular x, y, z), then down the leg
   float a = 0.f;
-  static_for<6>([&](auto DD) {
-    constexpr int j = decltype(DD)::value;
-    const float xj = (ur[j] - grp8_sum(Ur[j] * a)) * invDr[j];
-    x[j] = xj;
-    a += xj * Sr[j];
-  });
+  {
+    float xw[6];
+    static_for<6>([&](auto DD) {
+      constexpr int i = decltype(DD)::value;
+      constexpr int e = i < 3 ? 3 + i : i - 3;
+      const float xe = (ur[e] - grp8_sum(Ur[e] * a)) * invDr[e];
+      xw[e] = xe;
+      a = L.rr == e ? a + xe : a;
+    });
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      x[k] = xw[3 + k];
+      x[3 + k] = Rm[0][k] * xw[0] + Rm[1][k] * xw[1] + Rm[2][k] * xw[2];
+    }
+  }
   s.T[0][L.rr] = a;
   static_for<TP::NDL>([&](auto DD) {
     constexpr int d = decltype(DD)::value;
