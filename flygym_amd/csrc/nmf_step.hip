@@ -112,6 +112,10 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];   // c_D holds the distance until setup
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
+  // star kernels: the 3x3 pyramid-coefficient matrix of every contact for its active rows (nn, n1, n2, 11, 22), written
+  // with the active-row mask; the hybrid kernels have no LDS to spare and rebuild it from the mask
+  float c_m3[kHasIsym<TP> ? kMaxCon : 1][5];
+  float k_tab[6][12];                   // KLane constants of the contact stiffness rows per row index (staged once per launch)
   float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
   int body_cstart[TP::NB + 1];
   int ncon, overflow, iters;
@@ -627,27 +631,51 @@ __device__ __forceinline__ void inertia_row(const float* I, int r, float* row) {
   row[3] = top ? c0 : ms * e0; row[4] = top ? c1 : ms * e1; row[5] = top ? c2 : ms * e2;
 }
 
-// row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t
+// row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t,  l_m = (rc x d_m ; d_m)
+// for the frame directions d_m = n, t1, t2.  With M3 the symmetric 3x3 of pyramid coefficients over (n, t1, t2) — D sum a,
+// D mu (a0 - a1), D mu (a2 - a3), D mu^2 (a0 + a1), D mu^2 (a2 + a3) — and o_m = l_m[r] the lane's own components,
+//   row = sum_m C_m l_m = (rc x w ; w),   C = M3 o,   w = sum_m C_m d_m :
+// the cross product is taken once, of the combined direction, instead of three times.
+// KLane: what depends on the lane's row index and the (wave-uniform) contact frame only.
+struct KLane { float dA[3], dB[3], dO[3]; int ia, ib; };
+__device__ __forceinline__ KLane k_lane(int r, const Frame& fr) {
+  KLane K;
+  const bool top = r < 3;
+  const int k = top ? r : r - 3;
+  K.ia = k == 2 ? 0 : k + 1; K.ib = k == 0 ? 2 : k - 1;       // (rc x d)[k] = rc[ia] d[ib] - rc[ib] d[ia]
+  const V3 d[3] = {fr.n, fr.t1, fr.t2};
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const float da = K.ib == 0 ? d[m].x : (K.ib == 1 ? d[m].y : d[m].z), db = K.ia == 0 ? d[m].x : (K.ia == 1 ? d[m].y : d[m].z);
+    const float dk = k == 0 ? d[m].x : (k == 1 ? d[m].y : d[m].z);
+    K.dA[m] = top ? da : 0.f; K.dB[m] = top ? db : 0.f; K.dO[m] = top ? 0.f : dk;
+  }
+  return K;
+}
 template <class TP>
-__device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, int r, const Frame& fr) {
-  const int act = info_act(s.c_info[c]);
-  if (!act) return;
+__device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, const KLane& K, const Frame& fr) {
+  float m_nn, m_n1, m_n2, m_11, m_22;
+  if constexpr (kHasIsym<TP>) {
+    const float* q = s.c_m3[c];
+    m_nn = q[0]; m_n1 = q[1]; m_n2 = q[2]; m_11 = q[3]; m_22 = q[4];
+    if (m_nn == 0.f) return;                       // no active row
+  } else {
+    const int act = info_act(s.c_info[c]);
+    if (!act) return;
+    const float D = s.c_D[c], mu = s.c_mu[c];
+    const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+    const float Dm = D * mu, Dmm = Dm * mu;
+    m_nn = D * (a0 + a1 + a2 + a3); m_n1 = Dm * (a0 - a1); m_n2 = Dm * (a2 - a3); m_11 = Dmm * (a0 + a1); m_22 = Dmm * (a2 + a3);
+  }
   const V3 rc = ld3(s.c_r[c]);
-  const float D = s.c_D[c], mu = s.c_mu[c];
-  const V3 xn = cross(rc, fr.n), x1 = cross(rc, fr.t1), x2 = cross(rc, fr.t2);
-  const float ln[6] = {xn.x, xn.y, xn.z, fr.n.x, fr.n.y, fr.n.z};
-  const float l1[6] = {x1.x, x1.y, x1.z, fr.t1.x, fr.t1.y, fr.t1.z};
-  const float l2[6] = {x2.x, x2.y, x2.z, fr.t2.x, fr.t2.y, fr.t2.z};
-  float lnr = 0.f, l1r = 0.f, l2r = 0.f;
-#pragma unroll
-  for (int i = 0; i < 6; i++) { const float e = r == i ? 1.f : 0.f; lnr += e * ln[i]; l1r += e * l1[i]; l2r += e * l2[i]; }
-  const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
-  const float Dm = D * mu, Dmm = Dm * mu;
-  const float cn = D * (a0 + a1 + a2 + a3) * lnr + Dm * (a0 - a1) * l1r + Dm * (a2 - a3) * l2r;
-  const float c1 = Dm * (a0 - a1) * lnr + Dmm * (a0 + a1) * l1r;
-  const float c2 = Dm * (a2 - a3) * lnr + Dmm * (a2 + a3) * l2r;
-#pragma unroll
-  for (int i = 0; i < 6; i++) row[i] += cn * ln[i] + c1 * l1[i] + c2 * l2[i];
+  const float rcA = s.c_r[c][K.ia], rcB = s.c_r[c][K.ib];
+  const float o_n = fmaf(rcA, K.dA[0], fmaf(-rcB, K.dB[0], K.dO[0]));
+  const float o_1 = fmaf(rcA, K.dA[1], fmaf(-rcB, K.dB[1], K.dO[1]));
+  const float o_2 = fmaf(rcA, K.dA[2], fmaf(-rcB, K.dB[2], K.dO[2]));
+  const float C_n = m_nn * o_n + m_n1 * o_1 + m_n2 * o_2, C_1 = m_n1 * o_n + m_11 * o_1, C_2 = m_n2 * o_n + m_22 * o_2;
+  const V3 w = C_n * fr.n + C_1 * fr.t1 + C_2 * fr.t2;
+  const V3 x = cross(rc, w);
+  row[0] += x.x; row[1] += x.y; row[2] += x.z; row[3] += w.x; row[4] += w.y; row[5] += w.z;
 }
 
 // Articulated-body solve of (CRBA(I_b [+ K_b]) + diag(delta)) x = tau, delta_j = armature_j +
@@ -696,6 +724,13 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // forward sweep instead of keeping it: 24 registers fewer to spill
   constexpr bool kKeepS = TP::NDL <= 16;
   float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[kKeepS ? TP::NDL : 1];
+  KLane KL;                             // contact stiffness rows: per-row constants from the launch's table
+  if (withK) {
+    const float* q = s.k_tab[L.rr];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { KL.dA[i] = q[i]; KL.dB[i] = q[3 + i]; KL.dO[i] = q[6 + i]; }
+    KL.ia = __float_as_int(q[9]); KL.ib = __float_as_int(q[10]);
+  }
   int cs[TP::NBL + 1], cs_root0 = 0, cs_root1 = 0;                         // contact ranges of the leg's bodies / the root
   static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK ? s.body_cstart[b0 + l] : 0; });
   if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
@@ -731,7 +766,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
         for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
       } else inertia_row(s.Ib[b], L.rr, row);
-      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
 #pragma unroll
       for (int i = 0; i < 6; i++) IA[i] += row[i];
     }
@@ -761,7 +796,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
     } else inertia_row(s.Ib[0], L.rr, row);
     if (withK) {
-      for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+      for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, KL, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
       if constexpr (WELD) static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
     }
@@ -919,6 +954,12 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
     stsv(s.c_w[lane], SV{cross(c.r, F), F});
     s.c_info[lane] = c.info | (act << 20);
+    if constexpr (kHasIsym<TP>) {
+      const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
+      const float Dm = c.D * c.mu, Dmm = Dm * c.mu;
+      float* q = s.c_m3[lane];
+      q[0] = c.D * (a0 + a1 + a2 + a3); q[1] = Dm * (a0 - a1); q[2] = Dm * (a2 - a3); q[3] = Dmm * (a0 + a1); q[4] = Dmm * (a2 + a3);
+    }
   }
   WSYNC();
   if constexpr (!TP::kStar) {
@@ -1479,6 +1520,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
   if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   STAGE_INIT();
   for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
+  if (lane < 6) {
+    const KLane K = k_lane(lane, make_frame(v3(m.plane[0], m.plane[1], m.plane[2])));
+    float* q = s.k_tab[lane];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q[i] = K.dA[i]; q[3 + i] = K.dB[i]; q[6 + i] = K.dO[i]; }
+    q[9] = __int_as_float(K.ia); q[10] = __int_as_float(K.ib); q[11] = 0.f;
+  }
   float time;
   if (mode == 1) {
     for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];

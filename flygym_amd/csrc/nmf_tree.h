@@ -341,8 +341,14 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
     for (int c = 0; c < 6; ++c) row[c] += sl[so[c]];
     pA += sl[21 + L.rr];
   }
-  if (withK)
-    for (int c = s.body_cstart[nd.b]; c < s.body_cstart[nd.b + 1]; ++c) add_contact_K_row(row, s, c, L.rr, fr);
+  if (withK) {
+    KLane KL;
+    const float* q = s.k_tab[L.rr];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { KL.dA[i] = q[i]; KL.dB[i] = q[3 + i]; KL.dO[i] = q[6 + i]; }
+    KL.ia = __float_as_int(q[9]); KL.ib = __float_as_int(q[10]);
+    for (int c = s.body_cstart[nd.b]; c < s.body_cstart[nd.b + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
+  }
   if constexpr (NUM > 0) {
     static_for<NUM>([&](auto I) {
       constexpr int d = NUM - 1 - decltype(I)::value;
