@@ -3,24 +3,35 @@
 Protocol = the reference's GPU benchmark (``src/flygym_demo/benchmark/time_gpu_simulation.py:108-198``,
 driver ``scripts/dev/run_gpu_benchmark.py:10-32``): benchmark model (``make_model`` defaults: LEGS_ONLY
 skeleton nq 73 / nv 72, 42 position actuators kp 50, 6 adhesion actuators, flat ground, 55 geom-plane
-pairs, mesh-hull collision geometry), adhesion on for all legs, untimed warm-up, then K timed steps of
-kinematic replay (world w replays clip partition w % 20), no rendering;
+pairs, mesh-hull collision geometry), adhesion on for all legs, the UNCONDITIONAL untimed settle of the
+reference (``sim.warmup()`` = 500 steps at the neutral targets, ``:129-131``) — and, for the CPG
+workload, one more full 12 Hz gait cycle under the control table so that the timed region is steady
+walking — then W further untimed warm-up steps, then K timed steps, no rendering;
 ``steps_per_second = K * n_worlds / wall``.
 
-    python bench.py                      # 1 GPU, 4096 worlds, 1000 timed steps after 500 warm-up steps
+    python bench.py                      # 1 GPU, 4096 worlds, 1000 timed steps
+    python bench.py --gpus 8             # spawns 8 ranks itself (one process per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 1000 --warmup 500
+        --master-port 29500 bench.py --gpus 8 --steps 1000 --warmup 500       # the same, launched from outside
 
-One process per GPU; worlds are independent, so each rank steps its own 4096 (weak scaling) and the
-only inter-GPU traffic is an RCCL all-gather of the observation block once per control tick.
-Rank 0 prints ONE JSON line.
+A short timed region (K < 500: the driver's ``--steps 20``) is one launch of a few milliseconds, so it is
+repeated (the gait continuing) and the mean is reported; ``config.repeats`` says how often.  The line is marked
+``"valid": false`` and the exit code is 3 if the timed region was not contact-rich stepping (mean contacts < 1
+or no solver iterations: flies in free fall), if the state went non-finite, or if contacts overflowed.
+
+One process per GPU; worlds are independent, so each rank steps its own shard (``--scaling weak``: 4096 per
+GPU; ``--scaling strong``: 4096 in total) and the only inter-GPU traffic is an RCCL all-gather of the
+observation block once per control tick.  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,15 +47,23 @@ for p in (ROOT, ROOT / "oracle"):
 # qacc_warmstart 72, write qpos 73 + qvel 72 + qacc_warmstart 72  = 482 floats.
 BYTES_PER_ENV_STEP = 1928
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # same guide: FP32 vector peak (256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz)
 OBS_DIM = 66 + 66 + 42 + 96    # joint angles, joint velocities, actuator forces, contact sensors
+SETTLE_NEUTRAL_S = 0.05        # reference Simulation.warmup(duration_s=0.05)
+GAIT_HZ = 12.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=500,
+                    help="untimed steps under the control table AFTER the unconditional settle")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how often the K-step timed region is repeated (0 = auto: about 1000 timed steps in total)")
     ap.add_argument("--worlds-per-gpu", type=int, default=4096)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --worlds-per-gpu on every GPU; strong: --worlds-per-gpu worlds in TOTAL, sharded over the GPUs")
     ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="physics steps fused into one kernel launch (= one control tick)")
     ap.add_argument("--workload", choices=["cpg", "replay"], default="cpg",
@@ -60,7 +79,7 @@ def parse_args():
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200000)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def host_cores(cap=64):
@@ -82,7 +101,7 @@ def host_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(model_blob, table_rows, act_ids, warmup, n_steps):
+def cpu_baseline(model_blob, table_rows, act_ids, settle_steps, n_steps):
     """The C oracle (a port of the pipeline, NOT real MuJoCo) on the host cores, same control tables: one world on
     one core, then one world per core on all cores (independent oracle instances on Python threads; the C call
     releases the GIL)."""
@@ -95,7 +114,7 @@ def cpu_baseline(model_blob, table_rows, act_ids, warmup, n_steps):
     def make():
         o = orc.Oracle(model_blob, "f64")
         o.ctrl[42:] = 1.0
-        o.step(warmup)
+        o.step(settle_steps)
         return o
 
     o = make()
@@ -109,7 +128,7 @@ def cpu_baseline(model_blob, table_rows, act_ids, warmup, n_steps):
     done = [0] * cores
 
     def worker(k):
-        ok = make()               # warm-up outside the timed region
+        ok = make()               # settle outside the timed region
         gate.wait()
         end = time.perf_counter() + budget_s
         pos = 0
@@ -130,30 +149,79 @@ def cpu_baseline(model_blob, table_rows, act_ids, warmup, n_steps):
     return {
         "value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "single_core_value": single,
-        "sample": f"float64 C oracle (oracle/nmf_oracle.c) on the same control tables after {warmup} warm-up steps: "
+        "sample": f"float64 C oracle (oracle/nmf_oracle.c) on the same control tables after {settle_steps} settle steps: "
                   f"{cores} worlds x ~{total // cores} steps on {cores} threads ({os.cpu_count()} logical CPUs visible, "
                   f"{cores} usable by this process) in {wall:.1f} s; "
                   f"single core: 1 world x {n_steps} steps in {res[0]:.1f} s",
     }
 
 
+def algorithmic_flops(nv, nb, ncon, iters):
+    """Useful floating-point operations of one fly-step (DESIGN.md §3 "compute roofline"): the arithmetic of the
+    articulated-body formulation itself, counted per stage for this model's sizes and the measured mean contact count
+    and Newton iteration count — no shadow lanes, no address arithmetic, no reductions' redundant copies."""
+    nh = nv - 6
+    kin = nh * 45 + nb * 75 + nv * 21            # joint quaternions + relative transforms, chain products, motion subspaces
+    inertia = nb * 140                           # R I R^T, parallel-axis shift
+    collision = 55 * 40 + ncon * 60 + 6 * 400 * 8    # culls, ~6 near hulls of ~400 vertices (distance scan), contact frames
+    bias = nv * 40 + nb * 130                    # velocities, velocity-product accelerations, I a + v x* I v
+    aba = nh * 150 + 6 * 60 + nb * 36 + nv * 14  # per hinge: U = IA s, D, rank-1 downdate, bias; root; inertia rows; back-substitution
+    newton = nv * 30 + nb * 70 + ncon * 160      # twists, I T, energy, row velocities, line search, merged gradient sweep
+    solves = 2.0 + iters                         # smooth + Euler + one per Newton iteration
+    return kin + inertia + collision + bias + solves * aba + iters * (newton + ncon * 50) + nv * 20
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(args):
+    """``python bench.py --gpus N`` without an external launcher: re-run this script as N ranks under
+    torch.distributed.run (one process per GPU) and pass rank 0's JSON line through."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def traffic_model(n_local, spl, args):
+    """HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3 --pmc
+    passes of this command (profiles/hbm_traffic.json, written by scripts/summarize_profile.py).  A persistent launch
+    moves state + outputs once and one control-table row per step, so the profile stores both terms per world
+    (fitted from two launch lengths) and any steps_per_launch scales from them."""
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if not tfile.exists() or args.terrain != "flat" or args.odor or args.cpg_adhesion or args.joint_preset != "legs_only":
+        return None, None
+    rec = json.loads(tfile.read_text())
+    issue = rec.get("issue") or None
+    if "per_world_per_launch_bytes" in rec:
+        return n_local * (rec["per_world_per_launch_bytes"] + rec["per_world_per_step_bytes"] * spl), issue
+    if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch")) == (n_local, spl):
+        return rec["traffic_bytes_per_launch"], issue
+    return None, issue
+
+
 def main():
     args = parse_args()
+    env_ws = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_ws is None:
+        raise SystemExit(self_spawn(args))
+
     import torch
     import torch.distributed as dist
 
     from flygym_amd import HIPSimulation, make_model
-    from flygym_amd import _native
     from flygym_amd.compose import ActuatorType
     from flygym_amd.replay import ReplayTargetData
+    from flygym_amd.sharding import ObsGather, shard_range
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    world_size = int(env_ws or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world_size
+    args.gpus = world_size
     torch.cuda.set_device(local_rank)
     # NMF_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, all-gather, barrier, max-reduce)
     # even with one rank, so it can be validated on a single-GPU box
@@ -166,11 +234,20 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    n_local = args.worlds_per_gpu
+    if args.scaling == "strong":
+        total_worlds = args.worlds_per_gpu
+        first_world, last_world = shard_range(total_worlds, rank, world_size)
+    else:
+        total_worlds = args.worlds_per_gpu * world_size
+        first_world, last_world = rank * args.worlds_per_gpu, (rank + 1) * args.worlds_per_gpu
+    n_local = last_world - first_world
+    if n_local <= 0:
+        raise SystemExit("more ranks than worlds")
     spl = max(1, min(args.steps_per_launch, args.steps))
     if args.steps % spl:
         spl = next(d for d in range(spl, 0, -1) if args.steps % d == 0)
     n_launches = args.steps // spl
+    repeats = args.repeats if args.repeats > 0 else (1 if args.steps >= 500 else min(100, max(2, math.ceil(1000 / args.steps))))
 
     fly, world, _ = make_model(joints_preset=args.joint_preset, simplify_geom=args.simplify_geom)
     if args.terrain != "flat":
@@ -191,107 +268,130 @@ def main():
     replay = ReplayTargetData(sim.timestep, order)
     if args.workload == "replay":
         table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
-        table_np = replay.make_target_angles_all_worlds(n_local, table_steps, first_world=rank * n_local)
+        table = torch.as_tensor(replay.make_target_angles_all_worlds(n_local, table_steps, first_world=first_world), device=sim.device)
     else:
         from flygym_amd.controllers import TripodCPG
 
         table_steps = 2500  # three 12 Hz gait cycles: the table wraps around seamlessly
         cpg = TripodCPG(order, sim.timestep)
-        table_np = None
         adhesion = (cpg.stance_bins(sim.model, fly), args.cpg_adhesion, 1.0) if args.cpg_adhesion > 0 else None
-        table = cpg.targets(n_local, table_steps, device=sim.device, first_world=rank * n_local,
-                            total_worlds=n_local * world_size, adhesion=adhesion)   # built on the GPU: no multi-GB host arrays
-    if table_np is not None:
-        table = torch.as_tensor(table_np, device=sim.device)
+        table = cpg.targets(n_local, table_steps, device=sim.device, first_world=first_world,
+                            total_worlds=total_worlds, adhesion=adhesion)   # built on the GPU: no multi-GB host arrays
     act_ids = sim.replay_ids(fly.name, with_adhesion=args.workload == "cpg" and args.cpg_adhesion > 0)
-    maps = sim._ids_by_fly[fly.name]
 
+    # ---- the unconditional settle (never a CLI knob): reference warm-up, then one gait cycle under the CPG table
     sim.set_leg_adhesion_states(fly.name, np.ones((n_local, 6), dtype=np.float32))
-    if args.warmup > 0:
-        sim.step(args.warmup)   # reference: sim.warmup() = 500 steps at the neutral targets
+    settle_neutral = int(SETTLE_NEUTRAL_S / sim.timestep)
+    sim.step(settle_neutral)
+    cursor = 0                                   # position in the control table; the gait continues across all phases
+    settle_gait = 0
+    if args.workload == "cpg":
+        settle_gait = int(math.ceil(1.0 / (GAIT_HZ * sim.timestep) / 50.0)) * 50       # >= one full 12 Hz cycle
+        for _ in range(settle_gait // 50):
+            sim.step_replay(table, act_ids, cursor, 50)
+            cursor += 50
+    done = 0
+    while done < args.warmup:                    # the driver's --warmup: further untimed steps, same launch shape
+        n = min(spl, args.warmup - done)
+        sim.step_replay(table, act_ids, cursor, n)
+        cursor += n; done += n
 
     # observation gather: double-buffered so that the RCCL all-gather of tick k runs on RCCL's stream while the
     # stepping kernel of tick k + 1 already runs on the compute stream (the only exchange of the path)
     nj = sim.model.nv - 6                # joint angles, joint velocities, position-actuator forces, contact sensors
-    obs_dim = 2 * nj + 42 + 96
-    assert args.joint_preset != "legs_only" or obs_dim == OBS_DIM
-    obs_local = [torch.empty((n_local, obs_dim), dtype=torch.float32, device=sim.device) for _ in range(2)]
-    obs_all = [torch.empty((world_size * n_local, obs_dim), dtype=torch.float32, device=sim.device) for _ in range(2)] if use_dist else None
-    pending = [None, None]
+    gather = ObsGather(n_local, nj, 42, sim.device, total_worlds=total_worlds) if use_dist else None
+    assert args.joint_preset != "legs_only" or 2 * nj + 42 + 96 == OBS_DIM
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 1)]
+    n_events = repeats * n_launches
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)]
 
-    def control_tick(start, k=n_launches):
+    def control_tick(start, k=n_events):
         # the kernel is launched on torch's current stream, so these events bracket exactly it
         ev0[k].record()
         sim.step_replay(table, act_ids, start, spl)
         ev1[k].record()
         if odor is not None:
             odor.get_odor_intensities()
+        if gather is not None:
+            gather.tick(sim.field("qpos"), sim.field("qvel"), sim.field("actuator_force"), sim.field("sensordata"))
+
+    def fence():
+        torch.cuda.synchronize()
         if use_dist:
-            slot = k & 1
-            if pending[slot] is not None:
-                pending[slot].wait()          # the gather that last used this buffer pair (two ticks ago)
-            ol = obs_local[slot]
-            ol[:, 0:nj] = sim.field("qpos")[:, 7:]
-            ol[:, nj:2 * nj] = sim.field("qvel")[:, 6:]
-            ol[:, 2 * nj:2 * nj + 42] = sim.field("actuator_force")[:, :42]
-            ol[:, 2 * nj + 42:] = sim.field("sensordata")
-            pending[slot] = dist.all_gather_into_tensor(obs_all[slot], ol, async_op=True)
+            dist.barrier()
+        torch.cuda.synchronize()
 
     # untimed: one tick to settle allocator / RCCL channels
-    control_tick(0)
-    torch.cuda.synchronize()
+    control_tick(cursor); cursor += spl
+    fence()
+    sums0 = sim.field("stats_sum").clone()
+    elapsed_all = []
+    for r in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        for k in range(n_launches):
+            control_tick(cursor, r * n_launches + k)
+            cursor += spl
+        if gather is not None:
+            gather.drain()                        # every gather is inside the timed region
+        fence()
+        elapsed_all.append(time.perf_counter() - t0)
+    sums1 = sim.field("stats_sum").clone()
+    elapsed_t = torch.tensor(elapsed_all, dtype=torch.float64, device=sim.device)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(n_launches):
-        control_tick(spl * (k + 1), k)
-    for w in pending:
-        if w is not None:
-            w.wait()                          # every gather is inside the timed region
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=sim.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)      # per repeat: the slowest rank
+    elapsed_all = [float(x) for x in elapsed_t.tolist()]
+    elapsed = float(np.mean(elapsed_all))
 
-    finite = bool(torch.isfinite(sim.field("qpos")).all().item())
-    stats = sim.get_solver_stats()
-    overflow = int(stats[:, 2].sum().item())
+    # what the timed region actually stepped: means over its launches (kernel-side running sums, NMF_STATS_SUM)
+    dsum = (sums1 - sums0).double().sum(dim=0)
+    flags = torch.tensor([float(torch.isfinite(sim.field("qpos")).all().item())], dtype=torch.float64, device=sim.device)
+    if use_dist:
+        dist.all_reduce(dsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    steps_seen = max(float(dsum[0].item()), 1.0)
+    mean_contacts, mean_iters = float(dsum[1].item()) / steps_seen, float(dsum[2].item()) / steps_seen
+    overflow_steps = int(dsum[3].item())
+    finite = bool(flags[0].item() > 0)
+    rccl_ranks = None
+    if use_dist:
+        probe = torch.zeros(world_size, dtype=torch.int32, device=sim.device)
+        dist.all_gather_into_tensor(probe, torch.tensor([rank + 1], dtype=torch.int32, device=sim.device))
+        rccl_ranks = int((probe > 0).sum().item()) if dist.get_world_size() == world_size else 0
+    valid = finite and mean_contacts >= 1.0 and mean_iters > 0.0 and overflow_steps == 0 \
+        and abs(steps_seen - float(total_worlds) * args.steps * repeats) < 0.5
 
+    out = None
     if rank == 0:
         # mean kernel duration over the launches of the timed region (HIP events on the launch stream)
-        ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(n_launches)]))
-        total_worlds = n_local * world_size
+        ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(n_events)]))
         value = total_worlds * args.steps / elapsed
         # SURVEY §8(d) formula on this model's sizes: read qpos + qvel + ctrl + warm start, write qpos + qvel + warm start
         bytes_per_env_step = 4 * (2 * sim.model.nq + 4 * sim.model.nv + sim.model.nu)
         assert args.joint_preset != "legs_only" or bytes_per_env_step == BYTES_PER_ENV_STEP
         achieved = bytes_per_env_step * n_local * spl / (ms * 1e-3) / 1e9
-        # HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
-        # --pmc passes of this very command (profiles/hbm_traffic.json, written by scripts/summarize_profile.py)
-        traffic = issue = None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():
-            rec = json.loads(tfile.read_text())
-            if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch"), rec.get("control")) == (n_local, spl, args.workload) \
-                    and args.terrain == "flat" and not args.odor and not args.cpg_adhesion and args.joint_preset == "legs_only":
-                traffic = rec["traffic_bytes_per_launch"]
-                issue = rec.get("issue") or None
+        traffic, issue = traffic_model(n_local, spl, args)
+        flops = algorithmic_flops(sim.model.nv, sim.model.nb, mean_contacts, mean_iters)
+        kernel_rate = n_local * spl / (ms * 1e-3)           # env-steps/s of the kernel alone on this GPU
+        compute = {
+            "algorithmic_flop_per_env_step": flops,
+            "useful_tflops": flops * kernel_rate / 1e12,
+            "frac_of_f32_vector_peak": flops * kernel_rate / 1e12 / VALU_PEAK_TFLOPS,
+            "peak_tflops": VALU_PEAK_TFLOPS,
+        }
+        if issue and issue.get("valu_insts_per_env_step") and issue.get("valu_cycles_per_inst"):
+            # vector-pipe occupancy from the measured issue cost of a wave64 VALU instruction (scripts/valu_issue_microbench.hip)
+            # and this run's kernel rate: instructions/s x cycles each / (SIMDs x clock)
+            clock = issue.get("shader_clock_hz", 2.4e9)
+            compute["valu_pipe_busy"] = issue["valu_insts_per_env_step"] * kernel_rate * issue["valu_cycles_per_inst"] / (1024 * clock)
         out = {
             "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "valid": valid,
             "config": {
-                "workload": f"{n_local} flies/GPU, {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", " + (f"{args.joint_preset.upper()} fly (nq {sim.model.nq}, nv {sim.model.nv}, nu {sim.model.nu}), {sim.model.ng} geom-plane pairs ")
+                "workload": f"{total_worlds} flies ({n_local}/GPU), {args.terrain} terrain" + (" + odor sensors" if args.odor else "") + (f" + CPG-driven adhesion ({args.cpg_adhesion:g} in stance)" if args.cpg_adhesion > 0 else "") + ", " + (f"{args.joint_preset.upper()} fly (nq {sim.model.nq}, nv {sim.model.nv}, nu {sim.model.nu}), {sim.model.ng} geom-plane pairs ")
                             + ("(capsule geoms)" if args.simplify_geom else "(mesh convex hulls + capsule claws)")
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else
@@ -299,10 +399,14 @@ def main():
                                "(reference benchmark protocol)") + ", adhesion on",
                 "control": args.workload,
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
+                "settle_steps": {"neutral": settle_neutral, "gait": settle_gait, "warmup": args.warmup},
+                "repeats": repeats, "timed_steps_total": args.steps * repeats,
+                "elapsed_s": {"mean": elapsed, "min": min(elapsed_all), "max": max(elapsed_all)},
                 "timestep": sim.timestep, "realtime_factor": value * sim.timestep,
                 "parallelism": f"env-shard x{world_size}" + (", RCCL all-gather of obs per control tick" if use_dist else ""),
-                "state_finite": finite, "contact_overflow_worlds": overflow,
-                "mean_contacts": float(stats[:, 0].mean().item()), "mean_newton_iters": float(stats[:, 1].mean().item()),
+                "rccl_ranks": rccl_ranks,
+                "state_finite": finite, "contact_overflow_steps": overflow_steps,
+                "mean_contacts": mean_contacts, "mean_newton_iters": mean_iters,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -315,14 +419,15 @@ def main():
                 "algorithmic_bytes_per_env_step": bytes_per_env_step,
                 # instruction-issue side of the same kernel, from the SQ counters of the committed profile (profiles/*_summary.md)
                 "issue": issue,
-                "note": "the step is VALU-issue bound by construction (state crosses HBM once per launch); "
-                        "see DESIGN.md for the instruction-side analysis",
+                "compute": compute,
+                "note": "the step is bound by dependent-instruction latency / VALU issue, not by HBM (state crosses HBM once "
+                        "per launch); see DESIGN.md for the instruction-side analysis",
             },
         }
         if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
             n_rows = min(n_local, host_cores())
             rows = np.ascontiguousarray(table[:n_rows, :, :42].cpu().numpy())
-            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), rows, np.arange(42, dtype=np.int32), args.warmup,
+            out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), rows, np.arange(42, dtype=np.int32), settle_neutral,
                                                args.cpu_steps)
     if use_dist:
         dist.barrier()
@@ -335,6 +440,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
+    if not valid:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ INCLUDE = PKG.parent / "include"
 
 FIELDS = dict(
     qpos=0, qvel=1, ctrl=2, qacc_warmstart=3, seg_xpos=4, seg_xquat=5, site_xpos=6,
-    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12,
+    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12, stats_sum=13, contact_geom=14,
 )
 
 _lib = None

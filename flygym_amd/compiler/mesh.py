@@ -24,8 +24,8 @@ from pathlib import Path
 
 import numpy as np
 
-__all__ = ["MeshData", "load_binary_stl", "derive_mesh_data", "capsule_from_inertia_box",
-           "capsule_inertia", "mirror_y"]
+__all__ = ["MeshData", "load_binary_stl", "derive_mesh_data", "capsule_from_inertia_box", "capsule_from_aabb",
+           "capsule_inertia", "convex_mesh_data", "mirror_y"]
 
 
 def load_binary_stl(path: str | Path) -> np.ndarray:
@@ -138,6 +138,27 @@ def capsule_from_inertia_box(m: MeshData) -> tuple[float, float]:
     radius = 0.5 * (b[0] + b[1])
     half = max(0.0, b[2] - 0.5 * radius)
     return float(radius), float(half)
+
+
+def capsule_from_aabb(m: MeshData) -> tuple[float, float, np.ndarray]:
+    """(radius, half_length, centre) of the capsule fitted with ``fitaabb=true``: the same size rule applied to the
+    half sizes of the axis-aligned bounding box of the mesh in its principal frame; the primitive sits at the box centre."""
+    _, R = m.principal()
+    loc = (m.hull_vertices - m.com) @ R
+    lo, hi = loc.min(axis=0), loc.max(axis=0)
+    b = 0.5 * (hi - lo)
+    radius = 0.5 * (b[0] + b[1])
+    half = max(0.0, b[2] - 0.5 * radius)
+    return float(radius), float(half), m.com + R @ (0.5 * (lo + hi))
+
+
+def convex_mesh_data(m: MeshData) -> MeshData:
+    """The same mesh with volume / COM / inertia taken over its convex hull (mesh ``inertia="convex"``)."""
+    vol, com, inertia = _signed_volume_props(m.hull_vertices[m.hull_faces])
+    if vol < 0:
+        vol, com, inertia = _signed_volume_props(m.hull_vertices[m.hull_faces[:, ::-1]])
+    return MeshData(volume=float(vol), com=com, inertia=inertia, hull_vertices=m.hull_vertices, hull_faces=m.hull_faces,
+                    n_vertices=m.n_vertices, n_faces=m.n_faces, hull_volume=m.hull_volume)
 
 
 def capsule_inertia(radius: float, half: float, mass: float) -> np.ndarray:

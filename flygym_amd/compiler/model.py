@@ -30,9 +30,10 @@ from pathlib import Path
 import numpy as np
 
 from . import rigid
-from .mesh import MeshData, capsule_from_inertia_box, capsule_inertia, mirror_y
+from .mesh import (MeshData, capsule_from_aabb, capsule_from_inertia_box, capsule_inertia, convex_mesh_data,
+                   mirror_y)
 
-__all__ = ["CompiledModel", "compile_world", "ASSET_PACK"]
+__all__ = ["CompiledModel", "compile_world", "ASSET_PACK", "EngineSemantics"]
 
 ASSET_PACK = Path(__file__).resolve().parents[1] / "assets" / "nmf_assets.npz"
 
@@ -41,6 +42,65 @@ ACT_POSITION, ACT_ADHESION, ACT_MOTOR = 0, 1, 2
 
 _MAGIC = b"NMFMODEL"
 _VERSION = 3
+
+
+class EngineSemantics:
+    """Named switches for the engine-stage semantics the reference leaves to MuJoCo and that could not be checked here
+    (confidence "L"/"M" rows).  Each one is read by the model compiler, the C oracle and the HIP
+    kernel alike, so a mismatch found with ``tests/golden/make_mujoco_golden.py`` on a box that has MuJoCo is a flag
+    flip on ``world.semantics``, not a rewrite.  Defaults = this build's reading of MuJoCo 3.6's documentation.
+
+    * ``mesh_inertia``: ``"exact"`` (signed tetrahedra over the triangle soup) | ``"convex"`` (inertia of the convex hull);
+    * ``capsule_fit``: ``"inertia_box"`` (``fitaabb=false``: equivalent-inertia box) | ``"aabb"`` (``fitaabb=true``);
+    * ``invweight0``: ``"segment"`` (per named segment at its own COM) | ``"fused_body"`` (per dynamic body after
+      ``fusestatic``, at the merged COM — ADVICE r1);
+    * ``pyramid_R``: ``"2mu2"`` (pyramidal rows regularised by ``2 mu^2 R_n``) | ``"plain"`` (``R_n`` on every edge);
+    * ``adhesion_contacts``: ``"segment_geom"`` (contacts of the adhesion segment's own geom: the MJCF body the actuator
+      names, ``fly.py:434-439``) | ``"fused_body"`` (every contact of the dynamic body it was fused into);
+    * ``sensor_frame``: ``"world"`` (net force / torque in world axes) | ``"contact"`` (in the contact frame: normal,
+      tangent 1, tangent 2 — the reference docstring's wording, ``simulation.py:226-231``);
+    * ``max_hull_contacts``: 1..4 manifold points per plane-hull pair (4 = deepest vertex + up to 3 more within
+      ``hull_skin``; 1 = deepest vertex only);
+    * ``weld_relpose``: ``"spawn"`` (tether target = the root body's spawn pose) | ``"identity"`` (target = world origin,
+      identity orientation).
+    """
+
+    _CHOICES = dict(mesh_inertia=("exact", "convex"), capsule_fit=("inertia_box", "aabb"),
+                    invweight0=("segment", "fused_body"), pyramid_R=("2mu2", "plain"),
+                    adhesion_contacts=("segment_geom", "fused_body"), sensor_frame=("world", "contact"),
+                    weld_relpose=("spawn", "identity"))
+
+    def __init__(self, **kw):
+        self.mesh_inertia = "exact"
+        self.capsule_fit = "inertia_box"
+        self.invweight0 = "segment"
+        self.pyramid_R = "2mu2"
+        self.adhesion_contacts = "segment_geom"
+        self.sensor_frame = "world"
+        self.max_hull_contacts = 4
+        self.weld_relpose = "spawn"
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError(f"unknown engine semantic '{k}'")
+            setattr(self, k, v)
+        self.validate()
+
+    def validate(self):
+        for k, choices in self._CHOICES.items():
+            if getattr(self, k) not in choices:
+                raise ValueError(f"engine semantic {k} must be one of {choices}, got {getattr(self, k)!r}")
+        if int(self.max_hull_contacts) not in (1, 2, 3, 4):
+            raise ValueError("max_hull_contacts must be 1..4")
+
+    def flags(self) -> np.ndarray:
+        """int32[8] blob entry ``sem_options`` read by the oracle and the kernel: pyramid_R plain, adhesion over the fused
+        body, sensor in the contact frame, max hull contacts, 0, 0, 0, 0."""
+        self.validate()
+        return np.array([int(self.pyramid_R == "plain"), int(self.adhesion_contacts == "fused_body"),
+                         int(self.sensor_frame == "contact"), int(self.max_hull_contacts), 0, 0, 0, 0], dtype=np.int32)
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in (*self._CHOICES, "max_hull_contacts")}
 _DT = {np.dtype(np.float64): 0, np.dtype(np.int32): 1}
 
 
@@ -180,18 +240,26 @@ def mesh_for_segment(pack, seg_name: str, mesh_type: str, mirror_left2right=True
 # ----------------------------------------------------------------------------
 # compile
 # ----------------------------------------------------------------------------
-def _segment_inertial(md: MeshData, mass: float, as_capsule: bool, boundinertia: float):
-    """(ipos, principal rotation, principal moments, capsule(r, half)|None) in segment frame."""
+def _segment_inertial(md: MeshData, mass: float, as_capsule: bool, boundinertia: float, sem: "EngineSemantics"):
+    """(ipos, principal rotation, principal moments, capsule(r, half, centre)|None) in segment frame."""
+    if sem.mesh_inertia == "convex":
+        md = convex_mesh_data(md)
     w, R = md.principal()
     cap = None
+    ipos = md.com.copy()
     if as_capsule:
-        r, half = capsule_from_inertia_box(md)
+        if sem.capsule_fit == "aabb":
+            r, half, centre = capsule_from_aabb(md)
+            ipos = centre          # the fitted primitive (and with it the body's inertial frame) sits at the box centre
+        else:
+            r, half = capsule_from_inertia_box(md)
+            centre = md.com.copy()
         moments = capsule_inertia(r, half, mass)
-        cap = (r, half)
+        cap = (r, half, centre)
     else:
         moments = mass * w / md.volume
     moments = np.maximum(moments, boundinertia)
-    return md.com.copy(), R, moments, cap
+    return ipos, R, moments, cap
 
 
 def compile_world(world) -> CompiledModel:
@@ -201,6 +269,8 @@ def compile_world(world) -> CompiledModel:
     fly = next(iter(world.fly_lookup.values()))
     pack = load_asset_pack(fly.asset_pack_path)
     opt = fly.mujoco_globals
+    sem = getattr(world, "semantics", None) or EngineSemantics()
+    sem.validate()
     boundmass = float(opt["compiler"].get("boundmass", 0.0))
     boundinertia = float(opt["compiler"].get("boundinertia", 0.0))
 
@@ -227,7 +297,7 @@ def compile_world(world) -> CompiledModel:
         seg_quat[i] = rigid.quat_normalize(pack["rigging_quat"][r])
         seg_mass[i] = max(float(pack["rigging_mass"][r]), boundmass)
         md = mesh_for_segment(pack, n, fly.mesh_type.value, fly.mirror_left2right)
-        ipos, R, moments, cap = _segment_inertial(md, seg_mass[i], fly.segment_is_capsule(n), boundinertia)
+        ipos, R, moments, cap = _segment_inertial(md, seg_mass[i], fly.segment_is_capsule(n), boundinertia, sem)
         seg_ipos[i], seg_geomR[i] = ipos, R
         seg_imat[i] = R @ np.diag(moments) @ R.T
         seg_capsule[i], seg_mesh[i] = cap, md
@@ -387,6 +457,7 @@ def compile_world(world) -> CompiledModel:
     m["act_forcerange"] = np.array(act_frc, dtype=np.float64).reshape(nu, 2)
     m["act_ctrlrange"] = np.array(act_ctrl, dtype=np.float64).reshape(nu, 2)
     m["act_limited"] = np.array(act_lim, dtype=np.int32).reshape(nu, 2)
+    m["sem_options"] = sem.flags()
 
     # ---- keyframe "neutral" (fly.py:658-678, world.py:151-207) ----------------
     qpos = np.zeros(nv + 1)
@@ -414,9 +485,8 @@ def compile_world(world) -> CompiledModel:
         g_body.append(int(dyn_of_seg[s]))
         g_seg.append(s)
         if seg_capsule[s] is not None:
-            r, half = seg_capsule[s]
+            r, half, c = seg_capsule[s]
             zax = seg_geomR[s][:, 2]
-            c = seg_ipos[s]
             p0 = T_pos + T_mat @ (c - zax * half)
             p1 = T_pos + T_mat @ (c + zax * half)
             g_type.append(GEOM_CAPSULE)
@@ -469,6 +539,12 @@ def compile_world(world) -> CompiledModel:
             if pos in LEGS:
                 g_sensor[gi] = LEGS.index(pos)
     m["geom_sensor"] = g_sensor
+    # adhesion actuators act through the contacts of their own segment's geom (the MJCF body the actuator names,
+    # reference fly.py:434-439; a body an actuator references is not fused away by MuJoCo's fusestatic), not through
+    # every contact of the dynamic body the segment was merged into here.  -1: the segment has no contact geom.
+    geom_of_seg = {s: gi for gi, s in enumerate(contact_segs)}
+    m["act_geom"] = np.array([geom_of_seg.get(seg_index[a["segment"]], -1) if a["kind"] == "adhesion" else -1
+                              for a in fly.actuators], dtype=np.int32).reshape(nu)
     m["n_sensor"] = np.array([6 if world.add_ground_contact_sensors else 0], dtype=np.int32)
 
     # adhesion: actuator index per leg order (simulation.py:387-404)
@@ -492,6 +568,18 @@ def compile_world(world) -> CompiledModel:
         J = rigid.point_jacobian(m, b, com, axis, anchor)
         A = J @ Minv @ J.T
         seg_invw[s] = [np.trace(A[0:3, 0:3]) / 3.0, np.trace(A[3:6, 3:6]) / 3.0]
+    if sem.invweight0 == "fused_body":
+        # fusestatic: geoms of jointless segments take the merged body's invweight0, evaluated at the merged COM
+        body_invw = np.zeros((nb, 2))
+        for b in range(nb):
+            com = xpos[b] + xmat[b] @ body_ipos[b]
+            J = rigid.point_jacobian(m, b, com, axis, anchor)
+            A = J @ Minv @ J.T
+            body_invw[b] = [np.trace(A[0:3, 0:3]) / 3.0, np.trace(A[3:6, 3:6]) / 3.0]
+        referenced = {seg_index[a["segment"]] for a in fly.actuators if a["kind"] == "adhesion"}
+        for s in range(ns):
+            if s not in seg_dofs and s not in referenced:
+                seg_invw[s] = body_invw[int(dyn_of_seg[s])]
     m["seg_invweight0"] = seg_invw
     m["geom_invweight0"] = seg_invw[contact_segs, 0].reshape(ng) if ng else np.zeros(0)
 
@@ -500,7 +588,8 @@ def compile_world(world) -> CompiledModel:
     # the thorax body's invweight0 (translational, rotational).
     root_seg = seg_index[fly.root_segment.name]
     m["weld_active"] = np.array([1 if world.fixed_base else 0], dtype=np.int32)
-    m["weld_params"] = np.concatenate([qpos[0:3], qpos[3:7], [2e-4, 1.0], _solimp5((0.98, 0.99, 1e-5, 0.5, 3.0)),
+    weld_target = np.concatenate([qpos[0:3], qpos[3:7]]) if sem.weld_relpose == "spawn" else np.array([0, 0, 0, 1.0, 0, 0, 0])
+    m["weld_params"] = np.concatenate([weld_target, [2e-4, 1.0], _solimp5((0.98, 0.99, 1e-5, 0.5, 3.0)),
                                        seg_invw[root_seg]])
     # structure summary for the star-of-chains fast path
     m["star"] = _star_structure(m)
@@ -510,6 +599,7 @@ def compile_world(world) -> CompiledModel:
         "dof_names": [d.name for d in jointdofs],
         "actuator_names": [a["name"] for a in fly.actuators],
         "fly_name": fly.name,
+        "semantics": sem.as_dict(),
     }
     return m
 

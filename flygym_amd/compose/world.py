@@ -36,6 +36,9 @@ class BaseWorld(ABC):
         self.fixed_base = False
         self.terrain_type = 0                  # 0 flat, 1 gapped, 2 blocks, 3 mixed (see terrain_height)
         self.terrain_params = (0.0, 0.0, 0.0, 0.0)
+        from ..compiler.model import EngineSemantics
+
+        self.semantics = EngineSemantics()     # engine-stage semantics MuJoCo would decide (see the class docstring)
         self._compiled = None
 
     @property

@@ -82,13 +82,21 @@ extern "C" nmf_model* nmf_model_create(const void* blob, size_t nbytes) {
   memcpy(&version, m->blob.data() + 8, 4);
   memcpy(&n, m->blob.data() + 12, 4);
   if (version != 3) { delete m; fail("nmf_model_create: unsupported blob version"); return nullptr; }
+  if ((uint64_t)n > (nbytes - 16) / sizeof(BlobEntry)) { delete m; fail("nmf_model_create: entry table does not fit the blob"); return nullptr; }
   const BlobEntry* e = (const BlobEntry*)(m->blob.data() + 16);
   for (uint32_t k = 0; k < n; ++k) {
     HostArray a;
     int64_t c = 1;
-    for (uint32_t d = 0; d < e[k].ndim; ++d) c *= e[k].shape[d];
+    bool bad = e[k].ndim > 4 || e[k].dtype > 1 || e[k].offset < 0 || e[k].nbytes < 0;
+    for (uint32_t d = 0; !bad && d < e[k].ndim; ++d) {
+      bad = e[k].shape[d] < 0 || (e[k].shape[d] > 0 && c > (int64_t)nbytes / e[k].shape[d]);
+      c *= e[k].shape[d];
+    }
     a.count = c;
-    if ((size_t)(e[k].offset + e[k].nbytes) > nbytes) { delete m; fail("nmf_model_create: truncated blob"); return nullptr; }
+    const int64_t elem = e[k].dtype == 0 ? 8 : 4;
+    if (bad || (uint64_t)e[k].offset > nbytes || (uint64_t)e[k].nbytes > nbytes - (uint64_t)e[k].offset || c * elem > e[k].nbytes) {
+      delete m; fail("nmf_model_create: truncated or malformed blob entry"); return nullptr;
+    }
     if (e[k].dtype == 0) {
       const double* src = (const double*)(m->blob.data() + e[k].offset);
       a.f.resize((size_t)c);
@@ -164,6 +172,7 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 }
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
+  HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
   dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
   // more worlds than resident waves: the launch runs in rounds; start the costliest worlds first
   b->st.order = nullptr; b->st.sched = nullptr;
@@ -281,6 +290,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     for (int k = 0; k < 2; ++k) d.weld_solref[k] = scalar("weld_params", 7 + k);
     for (int k = 0; k < 5; ++k) d.weld_solimp[k] = scalar("weld_params", 9 + k);
     for (int k = 0; k < 2; ++k) d.weld_invweight[k] = scalar("weld_params", 14 + k); }
+  { const HostArray* so = model->find("sem_options");
+    if (!so || !so->is_int || so->i.size() < 4) { delete b; fail("nmf_batch_create: model lacks sem_options"); return nullptr; }
+    d.sem_pyramid_plain = so->i[0]; d.sem_adhesion_fused = so->i[1]; d.sem_sensor_contact_frame = so->i[2];
+    d.sem_max_hull_contacts = so->i[3] >= 1 && so->i[3] <= 4 ? so->i[3] : 4; }
   { const HostArray* tt = model->find("terrain_type"); d.terrain_type = tt && tt->is_int && !tt->i.empty() ? tt->i[0] : 0; }
   int rc = 0;
 #define UF(n) rc |= upload_f(b, #n, &d.n)
@@ -289,7 +302,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   UI(body_dofadr); UI(body_dofnum); UI(dof_body);
   UF(dof_axis); UF(dof_armature); UF(dof_damping); UF(dof_stiffness); UF(dof_springref);
   UI(seg_body); UF(seg_pos); UF(seg_quat); UI(site_body); UF(site_pos);
-  UI(act_type); UI(act_trn); UI(act_limited); UF(act_gain); UF(act_bias); UF(act_forcerange); UF(act_ctrlrange);
+  UI(act_type); UI(act_trn); UI(act_limited); UI(act_geom); UF(act_gain); UF(act_bias); UF(act_forcerange); UF(act_ctrlrange);
   UF(key_qpos); UF(key_ctrl);
   UI(geom_body); UI(geom_type); UI(geom_hulladr); UI(geom_hullnum); UI(geom_sensor);
   UF(geom_p0); UF(geom_p1); UF(geom_radius); UF(geom_bsphere); UF(geom_invweight0); UF(hull_vert);
@@ -348,6 +361,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   rc |= alloc_field(b, NMF_STATS, 4, &st.stats);
   rc |= alloc_field(b, NMF_QACC, model->nv, &st.qacc);
   rc |= alloc_field(b, NMF_COST, 1, &st.cost);
+  rc |= alloc_field(b, NMF_STATS_SUM, 4, &st.stats_sum);
+  rc |= alloc_field(b, NMF_CONTACT_GEOM, nmf::kMaxCon, &st.contact_geom);
   {
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(int) * (size_t)n_worlds) == hipSuccess) { b->allocs.push_back(p); b->order_buf = (int*)p; }
@@ -424,6 +439,7 @@ extern "C" int nmf_gather(nmf_batch* b, int field, const int32_t* ids_dev, int n
   if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_gather: bad field");
   if (n_ids <= 0) return 0;
   if (group < 1 || !ids_dev || !dst_dev) return fail("nmf_gather: bad arguments");
+  HIP_OK(hipSetDevice(b->device));
   size_t total = (size_t)b->n_worlds * n_ids * group;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(nmf::nmf_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
@@ -436,6 +452,7 @@ extern "C" int nmf_scatter(nmf_batch* b, int field, const int32_t* ids_dev, int 
   if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_scatter: bad field");
   if (n_ids <= 0) return 0;
   if (!ids_dev || !src_dev) return fail("nmf_scatter: bad arguments");
+  HIP_OK(hipSetDevice(b->device));
   size_t total = (size_t)b->n_worlds * n_ids;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(nmf::nmf_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
@@ -521,6 +538,7 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   if (p->n_spheres < 0 || p->n_spheres > nmf::kMaxSpheres || (p->n_spheres > 0 && !spheres_dev)) return fail("nmf_eye_render: bad sphere list");
   if (!(p->checker_size > 0.f) || !(p->fov_deg > 0.f) || p->fov_deg > 360.f) return fail("nmf_eye_render: bad checker size / field of view");
   const nmf_model* m = b->model;
+  HIP_OK(hipSetDevice(b->device));
   if (b->dm.plane[0] != 0.f || b->dm.plane[1] != 0.f || b->dm.plane[2] != 1.f) return fail("nmf_eye_render: the ground plane must be z-up");
   if ((reinterpret_cast<uintptr_t>(plan_dev) | reinterpret_cast<uintptr_t>(frames_out_dev)) & 15u)
     return fail("nmf_eye_render: plan / frames must be 16-byte aligned");
@@ -562,6 +580,7 @@ extern "C" int nmf_odor_intensity(nmf_batch* b, const int32_t* sensor_seg_dev, c
   if (n_sensors <= 0 || n_sources < 0 || n_dims <= 0 || !sensor_seg_dev || !sensor_rel_dev || !out_dev)
     return fail("nmf_odor_intensity: bad arguments");
   int total = b->n_worlds * n_sensors;
+  HIP_OK(hipSetDevice(b->device));
   hipLaunchKernelGGL(nmf::nmf_odor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      b->st.seg_xpos, b->st.seg_xquat, b->model->nseg, sensor_seg_dev, sensor_rel_dev, n_sensors,
                      source_pos_dev, source_peak_dev, n_sources, n_dims, out_dev, b->n_worlds);

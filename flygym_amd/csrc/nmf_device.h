@@ -104,6 +104,9 @@ struct DevModel {
   const int* site_body;
   const float* site_pos;
   const int *act_type, *act_trn, *act_limited;
+  const int* act_geom;      // adhesion actuators: contact geom of the adhesion segment (-1: none)
+  // named engine semantics (blob entry sem_options; flygym_amd.compiler.model.EngineSemantics), shared with the oracle
+  int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
   const float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   const float *key_qpos, *key_ctrl;
   const int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
@@ -115,6 +118,8 @@ struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
       *sensordata, *time, *stats, *qacc;
+  float* stats_sum;        // [n_worlds][4] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps
+  float* contact_geom;     // [n_worlds][kMaxCon] geom index of contact c at the launch's last step (-1 beyond ncon)
   float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
   const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
   struct SchedState* sched;   // launch-duration bookkeeping of the block-order policy (nullptr: off)

@@ -472,6 +472,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
         if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
       }
     }
+    nsel = nsel < m.sem_max_hull_contacts ? nsel : m.sem_max_hull_contacts;
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
@@ -1047,7 +1048,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     float tran = m.geom_invweight0[g];
     float diagA = tran + c.mu * c.mu * tran;
     float Rn = fmaxf((1.f - c.imp) * diagA / c.imp, kMinVal);
-    float Rpy = fmaxf(2.f * c.mu * c.mu * Rn, kMinVal);
+    float Rpy = fmaxf(m.sem_pyramid_plain ? Rn : 2.f * c.mu * c.mu * Rn, kMinVal);
     c.D = 1.0f / Rpy;
     float tc = solref[0], dr = solref[1];
     if (tc > 0.f) {
@@ -1157,12 +1158,17 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     float f;
     if (m.act_type[u] == ACT_ADHESION) {
       f = m.act_gain[u] * ctrl;
-      int body = m.act_trn[u];
-      int c0 = s.body_cstart[body], c1 = s.body_cstart[body + 1];
-      if (c1 > c0) {
-        float k = -f / (float)(c1 - c0);
+      // pulls through the contacts of the adhesion segment's own geom (the MJCF body the actuator names, reference
+      // fly.py:434-439); sem_adhesion_fused: through every contact of the dynamic body the segment was merged into
+      const int body = m.act_trn[u], ag = m.sem_adhesion_fused ? -2 : m.act_geom[u];
+      const int c0 = s.body_cstart[body], c1 = s.body_cstart[body + 1];
+      int cnt = 0;
+      for (int cc = c0; cc < c1; ++cc) cnt += (ag == -2 || info_geom(s.c_info[cc]) == ag) ? 1 : 0;
+      if (cnt > 0) {
+        float k = -f / (float)cnt;
         SV acc = ldsv(s.W[body]);
         for (int cc = c0; cc < c1; ++cc) {
+          if (ag != -2 && info_geom(s.c_info[cc]) != ag) continue;
           V3 r = ld3(s.c_r[cc]);
           acc = acc + k * SV{cross(r, fr.n), fr.n};
         }
@@ -1404,6 +1410,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   // ---- contact sensors (oracle contact_sensors): a pure output, evaluated on the launch's last step only and
   // written straight to HBM.  c_w holds the world-frame contact wrenches about the root origin.
   if (last) {
+    if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = c.on ? (float)info_geom(c.info) : -1.f;
     float* out = &st.sensordata[(size_t)w * 96];
     for (int i = lane; i < 96; i += kWave) out[i] = 0.f;
     WSYNC();
@@ -1426,6 +1433,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
         }
         float* o16 = out + 16 * lane;
         V3 o = ld3(s.xpos[0]);
+        if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
+          F = v3(dot(fr.n, F), dot(fr.t1, F), dot(fr.t2, F));
+          Tq = v3(dot(fr.n, Tq), dot(fr.t1, Tq), dot(fr.t2, Tq));
+        }
         o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, fr.n); st3(o16 + 13, fr.t1);
       }
     }
@@ -1528,6 +1539,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
     q[9] = __int_as_float(K.ia); q[10] = __int_as_float(K.ib); q[11] = 0.f;
   }
   float time;
+  float sum_con = 0.f, sum_it = 0.f, sum_of = 0.f;     // lane 0: running sums over the steps of this launch
   if (mode == 1) {
     for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
     for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
@@ -1558,9 +1570,16 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2
       physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
       STAGE(15);
       time += m.timestep;
+      if (lane == 0) { sum_con += (float)s.ncon; sum_it += (float)s.iters; sum_of += (float)s.overflow; }
     }
   }
   write_outputs(s, m, st, w, lane, time);
+  if (lane == 0) {
+    float* q = &st.stats_sum[4 * (size_t)w];
+    if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
+    else { q[0] += (float)n_steps; q[1] += sum_con; q[2] += sum_it; q[3] += sum_of; }
+  }
+  if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
   if (mode == 0 && lane == 0) {
     st.cost[w] = (float)(__builtin_amdgcn_s_memtime() - t_begin);
     if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());

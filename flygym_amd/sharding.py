@@ -5,7 +5,7 @@ The reference is single-GPU (``src/flygym/warp/utils.py:192-202``); this is new 
 
 from __future__ import annotations
 
-__all__ = ["shard_range", "gather_observations", "OBS_LAYOUT"]
+__all__ = ["shard_range", "gather_observations", "ObsGather", "OBS_LAYOUT"]
 
 # joint angles, joint velocities, position-actuator forces, 6 x 16 contact-sensor floats
 OBS_LAYOUT = (("joint_angles", 66), ("joint_velocities", 66), ("actuator_forces", 42), ("contact", 96))
@@ -34,3 +34,85 @@ def gather_observations(obs_local, out=None):
                           device=obs_local.device)
     dist.all_gather_into_tensor(out, obs_local.contiguous())
     return out
+
+
+class ObsGather:
+    """The one exchange of the multi-GPU path: per control tick every rank packs its observation block
+    ``[n_local, 2 nj + n_act + 96]`` (joint angles, joint velocities, position-actuator forces, contact sensors) and
+    all-gathers it to every rank.  Double-buffered and asynchronous: the gather of tick ``k`` runs on the communication
+    stream (RCCL over xGMI; ``gloo`` on CPU) while the stepping kernel of tick ``k + 1`` already runs; buffer pair
+    ``k & 1`` is reused at tick ``k + 2`` only after its gather has completed.
+
+    Ranks may own different numbers of worlds (``shard_range`` sizes differ by at most one): blocks are padded to
+    ``n_max`` rows and :meth:`rows` maps a gathered buffer back to the global world order.
+    """
+
+    def __init__(self, n_local: int, nj: int, n_act: int, device, *, total_worlds: int | None = None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist, self._group = torch, dist, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world_size = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.n_local, self.nj, self.n_act = int(n_local), int(nj), int(n_act)
+        self.obs_dim = 2 * self.nj + self.n_act + 96
+        self.total_worlds = int(total_worlds) if total_worlds is not None else self.n_local * self.world_size
+        self.n_max = -(-self.total_worlds // self.world_size)
+        if self.n_local > self.n_max:
+            raise ValueError("n_local exceeds the padded shard size")
+        self.local = [torch.zeros((self.n_max, self.obs_dim), dtype=torch.float32, device=device) for _ in range(2)]
+        self.full = [torch.zeros((self.world_size * self.n_max, self.obs_dim), dtype=torch.float32, device=device)
+                     for _ in range(2)]
+        self.pending = [None, None]
+        self.ticks = 0
+
+    def pack(self, out, qpos, qvel, actuator_force, sensordata):
+        """Columns in OBS_LAYOUT order from the engine's raw fields (views; device-side copies only)."""
+        nj, na, n = self.nj, self.n_act, self.n_local
+        out[:n, 0:nj] = qpos[:, 7:7 + nj]
+        out[:n, nj:2 * nj] = qvel[:, 6:6 + nj]
+        out[:n, 2 * nj:2 * nj + na] = actuator_force[:, :na]
+        out[:n, 2 * nj + na:] = sensordata
+        return out
+
+    def tick(self, qpos, qvel, actuator_force, sensordata):
+        """Pack this tick's block and start its gather; returns the tick index (buffer pair = index & 1)."""
+        k = self.ticks
+        slot = k & 1
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()            # the gather that used this buffer pair two ticks ago
+            self.pending[slot] = None
+        ol = self.pack(self.local[slot], qpos, qvel, actuator_force, sensordata)
+        if self.distributed:
+            self.pending[slot] = self._dist.all_gather_into_tensor(self.full[slot], ol, group=self._group, async_op=True)
+        else:
+            self.full[slot].copy_(ol)
+        self.ticks = k + 1
+        return k
+
+    def wait(self, k: int | None = None):
+        """Block the current stream on the gather of tick ``k`` (default: the latest) and return its buffer
+        ``[world_size * n_max, obs_dim]``."""
+        k = self.ticks - 1 if k is None else k
+        if k < 0 or k < self.ticks - 2:
+            raise ValueError("only the two most recent ticks are still buffered")
+        slot = k & 1
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        return self.full[slot]
+
+    def drain(self):
+        for slot in (0, 1):
+            if self.pending[slot] is not None:
+                self.pending[slot].wait()
+                self.pending[slot] = None
+
+    def rows(self):
+        """Index tensor selecting, from a gathered buffer, the rows of the real worlds in global world order."""
+        idx = []
+        for r in range(self.world_size):
+            a, b = shard_range(self.total_worlds, r, self.world_size)
+            idx.extend(range(r * self.n_max, r * self.n_max + (b - a)))
+        return self._torch.as_tensor(idx, dtype=self._torch.long, device=self.full[0].device)

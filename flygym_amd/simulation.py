@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import ctypes
 import warnings
-from time import perf_counter_ns
 
 import numpy as np
 
@@ -51,6 +50,8 @@ class HIPSimulation:
         if not torch.cuda.is_available():
             raise _native.NativeError("HIPSimulation needs a visible MI355X (torch.cuda.is_available() is False)")
         self.device_index = torch.cuda.current_device() if device is None else int(device)
+        if not 0 <= self.device_index < torch.cuda.device_count():
+            raise _native.NativeError(f"no GPU with index {self.device_index} ({torch.cuda.device_count()} visible)")
         self.device = torch.device("cuda", self.device_index)
         self._torch = torch
         self._lib = _native.lib()
@@ -76,7 +77,8 @@ class HIPSimulation:
         self.mj_data = _DataView(self)
         self._curr_step = 0
         self._frames_rendered = 0
-        self._total_physics_time_ns = 0
+        self._profile_events = []
+        self._physics_time_folded_ns = 0
         self._total_render_time_ns = 0
 
     # ---- lifecycle -----------------------------------------------------------------
@@ -183,7 +185,23 @@ class HIPSimulation:
         _native.check(self._lib.nmf_step(self._batch_h, int(n_steps), self._stream()))
 
     def step_replay(self, table, act_ids, start: int, n_steps: int) -> None:
-        """Device-resident replay loop: before step ``s`` load ``ctrl[:, act_ids] = table[:, start+s]``."""
+        """Device-resident replay loop: before step ``s`` load ``ctrl[:, act_ids] = table[:, start+s]``.
+
+        ``table``: float32 ``(n_worlds, table_steps, n_act)`` and ``act_ids``: int32 ``(n_act,)`` engine control ids
+        (:meth:`replay_ids`), both contiguous on this simulation's device — the kernel reads them through raw pointers,
+        so anything else is refused here."""
+        t = self._torch
+        if not (isinstance(table, t.Tensor) and isinstance(act_ids, t.Tensor)):
+            raise ValueError("step_replay takes torch tensors on the simulation's device")
+        if table.dtype != t.float32 or act_ids.dtype != t.int32:
+            raise ValueError(f"step_replay needs a float32 table and int32 ids, got {table.dtype} / {act_ids.dtype}")
+        if table.device != self.device or act_ids.device != self.device:
+            raise ValueError(f"step_replay needs tensors on {self.device}, got {table.device} / {act_ids.device}")
+        if table.ndim != 3 or table.shape[0] != self.n_worlds or act_ids.ndim != 1 or act_ids.numel() != table.shape[2]:
+            raise ValueError(f"Expected a table of shape ({self.n_worlds}, table_steps, n_act) and n_act ids, "
+                             f"but got {tuple(table.shape)} and {tuple(act_ids.shape)}")
+        if not (table.is_contiguous() and act_ids.is_contiguous()):
+            raise ValueError("step_replay needs contiguous tensors")
         _native.check(self._lib.nmf_step_replay(
             self._batch_h, table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr(),
             int(start), int(n_steps), self._stream()))
@@ -197,10 +215,36 @@ class HIPSimulation:
         return ids
 
     def step_with_profile(self) -> None:
-        t0 = perf_counter_ns()
+        """One step bracketed by device events recorded on the launch stream (the reference brackets a synchronous
+        ``mj_step`` with ``perf_counter_ns``, ``simulation.py:78-84``; a launch here is asynchronous, so host clocks
+        would time the enqueue).  No host synchronisation: the events are read when the report is asked for."""
+        t = self._torch
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        stream = t.cuda.current_stream(self.device)
+        e0.record(stream)
         self.step()
-        self._total_physics_time_ns += perf_counter_ns() - t0
+        e1.record(stream)
+        self._profile_events.append((e0, e1))
+        if len(self._profile_events) >= 1024:
+            self._fold_profile_events()
         self._curr_step += 1
+
+    def _fold_profile_events(self) -> None:
+        if self._profile_events:
+            self._profile_events[-1][1].synchronize()
+            self._physics_time_folded_ns += int(sum(a.elapsed_time(b) for a, b in self._profile_events) * 1e6)
+            self._profile_events.clear()
+
+    @property
+    def _total_physics_time_ns(self) -> int:
+        """GPU time of the steps taken with :meth:`step_with_profile` (synchronises on the last of them)."""
+        self._fold_profile_events()
+        return self._physics_time_folded_ns
+
+    @_total_physics_time_ns.setter
+    def _total_physics_time_ns(self, value: int) -> None:
+        self._profile_events.clear()
+        self._physics_time_folded_ns = int(value)
 
     def warmup(self, duration_s: float = 0.05) -> None:
         n = int(duration_s / self.timestep)

@@ -40,7 +40,12 @@ enum nmf_field {
   NMF_STATS = 10,       /* [4]       ncon, solver iterations, overflow flag, nefc (as floats)  */
   NMF_QACC = 11,        /* [nv]                                                                */
   NMF_COST = 12,        /* [1]       shader cycles the world took in the last stepping launch (load metric) */
-  NMF_FIELD_COUNT = 13
+  NMF_STATS_SUM = 13,   /* [4]       since the last reset: physics steps, sum of ncon, sum of solver iterations, steps with
+                                    contact overflow (means over any window = differences of two reads)              */
+  NMF_CONTACT_GEOM = 14, /* [48]     contact list of the launch's last step: index (into the world's contact-geom list,
+                                    reference compose/world.py:300-309 pair order sorted by body) of the geom of contact
+                                    c, as a float; -1 beyond ncon                                                    */
+  NMF_FIELD_COUNT = 15
 };
 
 /* Text of the last error raised on the calling thread ("" if none). */

@@ -128,12 +128,15 @@ typedef struct {
   real *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
   int* seg_body; real *seg_pos, *seg_quat;
   int* site_body; real* site_pos;
-  int *act_type, *act_trn, *act_limited;
+  int *act_type, *act_trn, *act_limited, *act_geom;
   real *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   real *key_qpos, *key_ctrl;
   int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
   real *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
   real *pair_friction, *pair_solref, *pair_solimp, *pair_margin;
+  /* named engine semantics (blob entry sem_options, flygym_amd.compiler.model.EngineSemantics): the low-confidence
+   * rows of SURVEY.md Appendix A as switches, read here and by the HIP kernel alike */
+  int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
 } omodel;
 
 typedef struct {
@@ -168,6 +171,11 @@ typedef struct {
   /* solver stats */
   int solver_iter;
   real solver_cost;
+  /* 0: the stopping rules the HIP kernel shares (tolerance tests + float rounding-floor exits, line search stops when
+   *    a 1-D Newton step keeps the active set);
+   * 1: MuJoCo-documented rules only — gradient / improvement against `tolerance`, line search iterated to its fixed
+   *    point — kept untouched by kernel work so that the converged solution has an independent anchor */
+  int solver_mode;
   /* scratch */
   real *w1, *w2, *w3, *w4, *w5, *H;
 } odata;
@@ -202,6 +210,10 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   m->act_type = blob_int(blob, "act_type", &c); m->nu = (int)c;
   m->act_trn = blob_int(blob, "act_trn", NULL);
   m->act_limited = blob_int(blob, "act_limited", NULL);
+  m->act_geom = blob_int(blob, "act_geom", NULL);
+  { int* so = blob_int(blob, "sem_options", NULL);
+    m->sem_pyramid_plain = so[0]; m->sem_adhesion_fused = so[1]; m->sem_sensor_contact_frame = so[2];
+    m->sem_max_hull_contacts = so[3] >= 1 && so[3] <= 4 ? so[3] : 4; free(so); }
   m->act_gain = blob_real(blob, "act_gain", NULL);
   m->act_bias = blob_real(blob, "act_bias", NULL);
   m->act_forcerange = blob_real(blob, "act_forcerange", NULL);
@@ -590,6 +602,7 @@ static void collide(const omodel* m, odata* d) {
           if (id >= 0) sel[nsel++] = id;
         }
       }
+      if (nsel > m->sem_max_hull_contacts) nsel = m->sem_max_hull_contacts;
       for (int k = 0; k < nsel; k++) {
         const real* v = V + 3 * sel[k];
         real dist = VDIST(sel[k]);
@@ -655,7 +668,7 @@ static void make_constraints(const omodel* m, odata* d) {
     real tran = m->geom_invweight0[g];
     real diagA = tran + mu * mu * tran;                 /* pyramidal edge: (1 + mu²)·tran */
     real Rn = ((real)1 - imp) * diagA / imp; if (Rn < (real)NMF_MINVAL) Rn = (real)NMF_MINVAL;
-    real Rpy = 2 * mu * mu * Rn;                        /* all edges of the pyramid share R */
+    real Rpy = m->sem_pyramid_plain ? Rn : 2 * mu * mu * Rn;   /* all edges of the pyramid share R */
     if (Rpy < (real)NMF_MINVAL) Rpy = (real)NMF_MINVAL;
     real tc = solref[0], dr = solref[1], K, B;
     if (tc > 0) {
@@ -751,7 +764,10 @@ static void actuation(const omodel* m, odata* d) {
       int body = m->act_trn[u], cnt = 0;
       real* mom = d->act_moment + (size_t)u * nv;
       memset(mom, 0, sizeof(real) * (size_t)nv);
-      for (int c = 0; c < d->ncon; c++) if (m->geom_body[d->con_geom[c]] == body) {
+      /* contacts of the adhesion segment's own geom (the MJCF body the actuator names, reference fly.py:434-439);
+       * sem_adhesion_fused: every contact of the dynamic body the segment was merged into */
+      for (int c = 0; c < d->ncon; c++)
+        if (m->sem_adhesion_fused ? m->geom_body[d->con_geom[c]] == body : d->con_geom[c] == m->act_geom[u]) {
         const real* Jn = d->Jc + (size_t)(3 * c) * nv;
         for (int j = 0; j < nv; j++) mom[j] -= Jn[j];
         cnt++;
@@ -836,7 +852,8 @@ static void solve_constraints(const omodel* m, odata* d) {
       real mag = R_FABS(Ma[j]) + R_FABS(d->qfrc_smooth[j]) + R_FABS(jtf);
       gm += mag * mag;
     }
-    if (scale * R_SQRT(gn) < m->tolerance || R_SQRT(gn) <= NMF_NOISE_FACTOR * R_EPS * R_SQRT(gm)) break;
+    if (scale * R_SQRT(gn) < m->tolerance) break;
+    if (d->solver_mode == 0 && R_SQRT(gn) <= NMF_NOISE_FACTOR * R_EPS * R_SQRT(gm)) break;
     factor_tree(m, d->H, d->L, d->Ld);
     for (int j = 0; j < nv; j++) search[j] = -grad[j];
     solve_tree(m, d->L, d->Ld, search);
@@ -858,6 +875,7 @@ static void solve_constraints(const omodel* m, odata* d) {
       if (hi >= 0 && (next <= lo || next >= hi)) { next = (real)0.5 * (lo + hi); bisected = 1; }
       /* phi' is linear while the active set does not change: then `next` is the exact minimiser */
       int same = !bisected;
+      if (d->solver_mode != 0) same = 0;
       for (int i = 0; same && i < nefc; i++)
         same = d->efc_bilateral[i] || (((jar[i] + alpha * jv[i]) < 0) == ((jar[i] + next * jv[i]) < 0));
       real change = R_FABS(next - alpha);
@@ -872,7 +890,8 @@ static void solve_constraints(const omodel* m, odata* d) {
     d->solver_iter = iter + 1;
     real improvement = cost - newcost;
     cost = newcost;
-    if (scale * improvement < m->tolerance || improvement <= NMF_NOISE_FACTOR * R_EPS * R_FABS(cost)) break;
+    if (scale * improvement < m->tolerance) break;
+    if (d->solver_mode == 0 && improvement <= NMF_NOISE_FACTOR * R_EPS * R_FABS(cost)) break;
   }
   d->solver_cost = cost;
   for (int i = 0; i < nefc; i++) {
@@ -912,6 +931,11 @@ static void contact_sensors(const omodel* m, odata* d) {
       for (int k = 0; k < 3; k++) T[k] += t[k];
     }
     out[0] = (real)cnt;
+    if (m->sem_sensor_contact_frame) {   /* net force / torque expressed in the contact frame (normal, t1, t2) */
+      const real* fr = d->con_frame[first];
+      real Fl[3] = {dot3(fr, F), dot3(fr + 3, F), dot3(fr + 6, F)}, Tl[3] = {dot3(fr, T), dot3(fr + 3, T), dot3(fr + 6, T)};
+      memcpy(F, Fl, sizeof(F)); memcpy(T, Tl, sizeof(T));
+    }
     for (int k = 0; k < 3; k++) { out[1 + k] = F[k]; out[4 + k] = T[k]; out[7 + k] = pc[k];
       out[10 + k] = d->con_frame[first][k]; out[13 + k] = d->con_frame[first][3 + k]; }
   }
@@ -1010,6 +1034,8 @@ EXPORT void* SFX(nmfo_ptr)(const void* mv, void* dv, const char* name, int* coun
 #undef F
   *count = 0; return NULL;
 }
+
+EXPORT void SFX(nmfo_set_solver_mode)(void* dv, int mode) { ((odata*)dv)->solver_mode = mode; }
 
 EXPORT void SFX(nmfo_ints)(const void* mv, void* dv, int* out, int* con_geom) {
   (void)mv; odata* d = (odata*)dv;

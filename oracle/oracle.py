@@ -42,6 +42,7 @@ def _lib(precision: str):
             ("nmfo_step_replay", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
             ("nmfo_ptr", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+            ("nmfo_set_solver_mode", None, [ctypes.c_void_p, ctypes.c_int]),
             ("nmfo_ints", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
         ]:
             fn = getattr(lib, name + sfx)
@@ -96,6 +97,11 @@ class Oracle:
         self._call("nmfo_ints", self._m, self._d, out, geoms)
         ncon = out[0]
         return dict(ncon=ncon, nefc=out[1], overflow=out[2], solver_iter=out[3], con_geom=list(geoms)[:ncon])
+
+    def set_solver_mode(self, mode: str):
+        """``"shared"``: the stopping rules the HIP kernel also uses (rounding-floor exits, early line-search exit);
+        ``"documented"``: MuJoCo-documented tolerance tests only, line search to its fixed point."""
+        self._call("nmfo_set_solver_mode", self._d, {"shared": 0, "documented": 1}[mode])
 
     def reset(self):
         self._call("nmfo_reset", self._m, self._d)

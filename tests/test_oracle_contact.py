@@ -161,3 +161,48 @@ def test_reference_acceleration_follows_the_documented_spring_damper(settled):
     assert np.allclose(D, D[:, :1]) and (D > 0).all()
     ratio = (1.0 / D[:, 0]) / ((1 - imp[::4]) / imp[::4])
     assert (ratio > 0).all()                                 # the inverse-inertia factor: positive, geometry dependent
+
+
+def _adhesion_pull_check(oracle_lib, adhesion_contacts):
+    """LEGS_ACTIVE_ONLY fuses tarsus1..5 of a leg into one dynamic body; the adhesion actuator names tarsus5
+    (reference fly.py:434-439).  Returns (model, oracle, expected qfrc of the adhesion actuators, measured)."""
+    from flygym_amd import make_model
+    from flygym_amd.anatomy import JointPreset
+
+    fly, world, _ = make_model(joints_preset=JointPreset.LEGS_ACTIVE_ONLY)
+    world.semantics.adhesion_contacts = adhesion_contacts
+    m = world.compile_model()
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.ctrl[42:] = 5.0
+    o.step(600)
+    o.qpos[2] -= 0.12            # press the tarsi into the ground: tarsus1-4 touch as well as the claws
+    o.qvel[:] = 0.0
+    o.forward()
+    i = o.ints()
+    geoms = np.array(i["con_geom"])
+    J = o.arr("J").reshape(i["nefc"], o.nv)
+    Jn = 0.5 * (J[0::4] + J[1::4])                       # rows are Jn +- mu Jt1: their mean is the normal Jacobian
+    f_act = o.arr("actuator_force")
+    expected = np.zeros(o.nv)
+    for u in range(42, 48):
+        body, ag = int(m["act_trn"][u]), int(m["act_geom"][u])
+        sel = (m["geom_body"][geoms] == body) if adhesion_contacts == "fused_body" else (geoms == ag)
+        if sel.any():
+            expected -= f_act[u] * Jn[sel].mean(axis=0)
+    measured = o.arr("qfrc_actuator").copy()
+    measured[m["act_trn"][:42]] -= f_act[:42]            # position actuators push their own dof
+    return m, geoms, expected, measured
+
+
+def test_adhesion_acts_through_the_adhesion_segments_own_geom(oracle_lib):
+    """with tarsus1-4 touching, the pull is shared by the tarsus5 contacts only (<= 2), not by every
+    contact of the fused tarsus body; the legacy behaviour stays reachable as a named semantic."""
+    m, geoms, expected, measured = _adhesion_pull_check(oracle_lib, "segment_geom")
+    tarsus5 = set(int(g) for g in m["act_geom"][42:])
+    fused = [g for g in geoms if g not in tarsus5 and m["geom_body"][g] in set(m["act_trn"][42:])]
+    assert len(fused) >= 4, "the test state must put tarsus1-4 geoms in contact"
+    assert set(geoms) & tarsus5
+    np.testing.assert_allclose(measured, expected, rtol=1e-9, atol=1e-12)
+    m2, geoms2, expected2, measured2 = _adhesion_pull_check(oracle_lib, "fused_body")
+    np.testing.assert_allclose(measured2, expected2, rtol=1e-9, atol=1e-12)
+    assert np.abs(expected - expected2).max() > 1e-3 * np.abs(expected).max()     # the two readings differ here

@@ -62,3 +62,95 @@ def test_two_rank_gloo_gather(tmp_path):
     order = fly.get_actuated_jointdofs_order("position")
     whole = ReplayTargetData(1e-4, order).make_target_angles_all_worlds(12, 1000)
     np.testing.assert_array_equal(np.load(out), whole[:, 0, :])
+
+
+def _gather_worker(rank, world_size, port, tmp, total_worlds):
+    """Drives bench.py's exchange — flygym_amd.sharding.ObsGather, double-buffered async all-gather — over gloo with
+    stand-in engine fields that are overwritten between ticks, as the stepping kernel overwrites them."""
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+
+    from flygym_amd.sharding import ObsGather, shard_range
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    first, last = shard_range(total_worlds, rank, world_size)
+    n_local, nj, n_act = last - first, 66, 42
+    g = ObsGather(n_local, nj, n_act, "cpu", total_worlds=total_worlds)
+    assert g.world_size == world_size and g.obs_dim == 270
+
+    def fields(tick):          # deterministic per (global world, tick): what a rank's engine would hold after that tick
+        w = torch.arange(first, last, dtype=torch.float32)[:, None]
+        qpos = w * 1000 + tick * 10 + torch.arange(73, dtype=torch.float32)[None, :] * 0.01
+        qvel = -(w * 1000 + tick * 10) + torch.arange(72, dtype=torch.float32)[None, :] * 0.01
+        force = w + tick + torch.arange(48, dtype=torch.float32)[None, :] * 0.5
+        sens = w * 2 + tick + torch.arange(96, dtype=torch.float32)[None, :] * 0.25
+        return qpos, qvel, force, sens
+
+    rows = g.rows()
+    seen = []
+    live = [t.clone() for t in fields(0)]
+    for tick in range(5):
+        for dst, src in zip(live, fields(tick)):
+            dst.copy_(src)                                   # the "kernel" of this tick writes the fields in place
+        k = g.tick(*live)
+        assert k == tick
+        if tick >= 1:                                        # consume the PREVIOUS tick while this one is in flight
+            seen.append(g.wait(tick - 1)[rows].clone())
+    seen.append(g.wait()[rows].clone())
+    g.drain()
+    if rank == 0:
+        np.save(tmp, torch.stack(seen).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_worlds", [12, 7])            # equal shards, and shards that differ by one (padding)
+def test_two_rank_double_buffered_obs_gather(tmp_path, total_worlds):
+    import torch
+    import torch.multiprocessing as mp
+
+    out = tmp_path / "gather.npy"
+    port = 31500 + (os.getpid() + total_worlds) % 2000
+    mp.spawn(_gather_worker, args=(2, port, str(out), total_worlds), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (5, total_worlds, 270)
+    w = np.arange(total_worlds, dtype=np.float32)[:, None]
+    for tick in range(5):
+        qpos = w * 1000 + tick * 10 + np.arange(73, dtype=np.float32)[None, :] * np.float32(0.01)
+        qvel = -(w * 1000 + tick * 10) + np.arange(72, dtype=np.float32)[None, :] * np.float32(0.01)
+        force = w + tick + np.arange(48, dtype=np.float32)[None, :] * np.float32(0.5)
+        sens = w * 2 + tick + np.arange(96, dtype=np.float32)[None, :] * np.float32(0.25)
+        want = np.concatenate([qpos[:, 7:73], qvel[:, 6:72], force[:, :42], sens], axis=1)
+        np.testing.assert_array_equal(got[tick], want.astype(np.float32))
+
+
+def test_bench_entry_self_spawns_and_shards(monkeypatch):
+    """`python bench.py --gpus N` must start N ranks itself: check the launcher command it builds and
+    the strong / weak shard arithmetic, without a GPU."""
+    import importlib
+
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_run(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        class R: returncode = 0
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # strong scaling: 4096 worlds over 8 ranks = 512 each, contiguous
+    spans = [shard_range(4096, r, 8) for r in range(8)]
+    assert spans[0] == (0, 512) and spans[-1] == (3584, 4096)
