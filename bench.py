@@ -285,7 +285,7 @@ def main():
     sim.step(settle_neutral)
     cursor = 0                                   # position in the control table; the gait continues across all phases
     settle_gait = 0
-    if args.workload == "cpg":
+    if args.workload == "cpg" and not os.environ.get("NMF_BENCH_R1_PROTOCOL"):   # (diagnostic: round-1 protocol for kernel A/B)
         settle_gait = int(math.ceil(1.0 / (GAIT_HZ * sim.timestep) / 50.0)) * 50       # >= one full 12 Hz cycle
         for _ in range(settle_gait // 50):
             sim.step_replay(table, act_ids, cursor, 50)

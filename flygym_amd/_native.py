@@ -7,11 +7,14 @@ loading / batch creation raises.
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libnmf_hip.so"
+# NMF_HIP_LIB: load another build of the same ABI (kernel A/B experiments: scripts/build_variant.sh); the default is the
+# in-tree library that build() compiles
+LIB_PATH = Path(os.environ["NMF_HIP_LIB"]) if os.environ.get("NMF_HIP_LIB") else PKG / "libnmf_hip.so"
 MATH_FLAGS = ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-signed-zeros", "-fassociative-math", "-fno-trapping-math", "-fno-math-errno", "-fapprox-func"]
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
@@ -32,6 +35,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h",
             INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
+    if os.environ.get("NMF_HIP_LIB"):
+        return LIB_PATH                       # an externally built variant: nothing to compile here
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     # -fno-slp-vectorize: the SLP vectoriser packs the 6-vector arithmetic into v_pk_* pairs and pays for it in v_mov

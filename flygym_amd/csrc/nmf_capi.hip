@@ -375,7 +375,20 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     st.sched = nullptr;
     st.order = nullptr;
     hipDeviceProp_t prop;
-    const int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 6 : 5)));   // flies per CU: LDS-limited
+    // flies (= single-wave workgroups) a CU holds at once: asked of the runtime for the kernel this batch will launch
+    // (LDS- or register-limited, whichever binds); fallback = the LDS-limited figures of the shipped build
+    int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 6 : 5)));
+    {
+      const bool weld = b->dm.weld_active != 0;
+      const void* fn = nullptr;
+#define NMF_FN(TOPO) (weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>))
+      switch (topo) { case 0: fn = NMF_FN(nmf::FlyTopo); break; case 1: fn = NMF_FN(nmf::FlyTopoActive); break;
+                      case 2: fn = NMF_FN(nmf::TreeTopoSmall); break; case 3: fn = NMF_FN(nmf::TreeTopo); break;
+                      case 4: fn = NMF_FN(nmf::FlyTopoBio); break; default: fn = NMF_FN(nmf::FlyTopoAll); break; }
+#undef NMF_FN
+      int nblk = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, nmf::kWave, 0) == hipSuccess && nblk > 0) per_cu = nblk;
+    }
     b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;
   }
   if (rc != 0 || nmf_reset(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {

@@ -1504,7 +1504,10 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
 
 // mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
 template <class TP, bool WELD>
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
+#ifndef NMF_WAVES_PER_EU
+#define NMF_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_WAVES_PER_EU, NMF_WAVES_PER_EU))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
   const DevModel& m = *mp;
   if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }

@@ -99,7 +99,7 @@ def test_contact_geom_ids_and_full_sensor_block(torch_mod, bench_model, oracle_l
         np.testing.assert_array_equal(sh[:, 13:16], so[:, 13:16].astype(np.float32))     # first tangent
         legs_seen += int((so[:, 0] > 0).sum())
         multi += int((so[:, 0] > 1).sum())
-    assert legs_seen >= 48 and multi >= 1        # the block was exercised, including multi-contact legs (non-zero torque)
+    assert legs_seen >= 40 and multi >= 1        # the block was exercised, including multi-contact legs (non-zero torque)
 
 
 def test_worlds_of_the_full_batch_follow_the_oracle(torch_mod, bench_model, oracle_lib):
