@@ -69,6 +69,9 @@ struct nmf_batch {
   int* order_buf = nullptr;      // block -> world order of the next stepping launch (see nmf_order_kernel)
   nmf::SchedState* sched_buf = nullptr;
   int resident_waves = 0;        // step-kernel waves the device holds at once
+  nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
+  unsigned int* chunk_done_buf = nullptr;
+  bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -173,7 +176,16 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
-  dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
+  // More worlds than resident waves and a launch long enough to cut: chunks of >= 4 steps, at most 5 per launch (the
+  // state hand-off between chunks costs two agent-scope fences of a few microseconds each)
+  int n_chunks = 1;
+  b->st.chunk_len = 0; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
+  if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 8) {
+    const int want = std::min(5, n_steps / 4);
+    b->st.chunk_len = (n_steps + want - 1) / want;
+    n_chunks = (n_steps + b->st.chunk_len - 1) / b->st.chunk_len;
+  }
+  dim3 grid((unsigned)b->n_worlds * (unsigned)n_chunks), block(nmf::kWave);
   // more worlds than resident waves: the launch runs in rounds; start the costliest worlds first
   b->st.order = nullptr; b->st.sched = nullptr;
   if (mode == 0 && b->order_buf && b->sched_buf && b->n_worlds > b->resident_waves) {
@@ -367,6 +379,17 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(int) * (size_t)n_worlds) == hipSuccess) { b->allocs.push_back(p); b->order_buf = (int*)p; }
     else rc |= fail("nmf_batch_create: out of device memory");
+    p = nullptr;
+    if (hipMalloc(&p, sizeof(nmf::ChunkSched)) == hipSuccess) {
+      (void)hipMemset(p, 0, sizeof(nmf::ChunkSched));
+      b->allocs.push_back(p); b->csched_buf = (nmf::ChunkSched*)p;
+    } else rc |= fail("nmf_batch_create: out of device memory");
+    p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned int) * (size_t)n_worlds) == hipSuccess) {
+      (void)hipMemset(p, 0, sizeof(unsigned int) * (size_t)n_worlds);
+      b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
+    } else rc |= fail("nmf_batch_create: out of device memory");
+    b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
       (void)hipMemset(p, 0, sizeof(nmf::SchedState));

@@ -123,7 +123,16 @@ struct DevState {
   float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
   const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
   struct SchedState* sched;   // launch-duration bookkeeping of the block-order policy (nullptr: off)
+  // chunked launches (nmf_step_kernel): a launch of n_steps is cut into chunks of chunk_len steps; workgroups take
+  // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
+  struct ChunkSched* csched;
+  unsigned int* chunk_done;   // [n_worlds] epoch * 8 + chunks of this launch the world has finished
+  int chunk_len;              // 0: one workgroup steps a world through the whole launch
 };
+
+// Device-resident scheduler state of chunked launches; the last workgroup of a launch rewinds it, so launches need no
+// host-side counters (hipGraph replays stay valid).
+struct ChunkSched { unsigned int ticket, finished, epoch, pad; };
 
 // Device-resident state of the block-order policy (see nmf_order_kernel)
 struct SchedState {

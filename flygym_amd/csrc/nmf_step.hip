@@ -85,8 +85,9 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
   NMF_TREE_TABLES
 };
 
-template <class TP> constexpr bool has_isym() { if constexpr (TP::kStar) return TP::REST_B == 0; else return false; }
-template <class TP> inline constexpr bool kHasIsym = has_isym<TP>();
+// star kernels keep the 3x3 pyramid-coefficient matrix of every contact in LDS (c_m3); the hybrid kernels rebuild it
+template <class TP> constexpr bool has_cm3() { if constexpr (TP::kStar) return TP::REST_B == 0; else return false; }
+template <class TP> inline constexpr bool kHasCm3 = has_cm3<TP>();
 
 template <class TP>
 struct __align__(16) FlyLds : TreeLds<TP> {
@@ -96,28 +97,40 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   __device__ __forceinline__ int nq() const { return nv() + 1; }
   float qpos[TP::NQ + 3];
   float qvel[TP::NV], qacc[TP::NV];      // qacc doubles as the warm start
+  // Body poses live from the kinematics stage to the end of the collision stage only (the pose outputs of a launch are
+  // written right after its last collision stage), so they are overlaid on buffers that are dead in that window: the
+  // rotation matrices of bodies 1.. on the six solver vectors, the positions of bodies 1.. on the contact wrenches.
+  // The root's pose sits in the 9 / 3 floats in front of each region: it is read all step long (contact points are
+  // relative to it) and `xmat()` / `xpos()` index all bodies uniformly.
+  float xmat_root[9];
   // qacc_smooth .. vD are contiguous (6 NV floats): the velocity stage borrows them as one buffer
   float qacc_smooth[TP::NV], qfrc_smooth[TP::NV];
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float ctrl[TP::kCtrl];
-  float xpos[TP::NB][3], xmat[TP::NB][9];
   float S[TP::NV][6];
-  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products)
-  // the same as a symmetric 6x6 (upper triangle): row fetches for the star ABA.  The hybrid kernels build the rows from
-  // Ib instead: they are latency bound and the 5.8 KB buy one more resident fly per CU
-  float Isym[kHasIsym<TP> ? TP::NB : 1][21];
+  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via i_map)
+  static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
+  static_assert(6 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
+  __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
+  __device__ __forceinline__ const float (*xmat() const)[9] { return reinterpret_cast<const float(*)[9]>(&xmat_root[0]); }
+  __device__ __forceinline__ float (*xpos())[3] { return reinterpret_cast<float(*)[3]>(&xpos_root[0]); }
+  __device__ __forceinline__ const float (*xpos() const)[3] { return reinterpret_cast<const float(*)[3]>(&xpos_root[0]); }
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][6], W[TP::NB][6];
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
-  float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon], c_w[kMaxCon][6];   // c_D holds the distance until setup
+  float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
+  float xpos_root[3];
+  float c_w[kMaxCon][6];
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
   // star kernels: the 3x3 pyramid-coefficient matrix of every contact for its active rows (nn, n1, n2, 11, 22), written
   // with the active-row mask; the hybrid kernels have no LDS to spare and rebuild it from the mask
-  float c_m3[kHasIsym<TP> ? kMaxCon : 1][5];
-  float k_tab[6][12];                   // KLane constants of the contact stiffness rows per row index (staged once per launch)
+  float c_m3[kHasCm3<TP> ? kMaxCon : 1][5];
+  // per row index r of a 6x6 (staged once per launch): [0..10] KLane constants of the contact stiffness rows; [11..13]
+  // the row's map into a body's 10-float inertia (byte offsets of columns 0-2 / 3-5, 2-bit signs + 1): see InertiaRowMap
+  float k_tab[6][14];
   float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
-  int body_cstart[TP::NB + 1];
+  unsigned char body_cstart[(TP::NB + 1 + 3) / 4 * 4];   // first contact of every body (contacts are sorted by body; <= kMaxCon)
   int ncon, overflow, iters;
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
   // ds_* instruction (a float* argument would be a generic pointer -> flat_load / flat_store)
@@ -213,7 +226,7 @@ struct RestNode;
 template <class TP, bool FAST, bool UP, class F> __device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6]);
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
 template <class TP, int NUM, bool HOMOGENEOUS>
@@ -236,8 +249,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   }
   if (lane == 0) {
     Q4 q = qnorm(ldq(&s.qpos[3]));
-    st3(s.xpos[0], ld3(&s.qpos[0]));
-    qmat(s.xmat[0], q);
+    st3(s.xpos()[0], ld3(&s.qpos[0]));
+    qmat(s.xmat()[0], q);
   }
   WSYNC();
   for (int b = 1 + lane; b < s.nb(); b += kWave) {
@@ -265,8 +278,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
     // component r of the position:  R_b = R_parent * Rrel_b ,  p_b = p_parent + R_parent * off_b
     const LaneRole L = lane_role<TP>(lane);
     const int r3 = L.r < 3 ? L.r : 2;
-    float R0 = s.xmat[0][3 * r3], R1 = s.xmat[0][3 * r3 + 1], R2 = s.xmat[0][3 * r3 + 2];
-    float p = s.xpos[0][r3];
+    float R0 = s.xmat()[0][3 * r3], R1 = s.xmat()[0][3 * r3 + 1], R2 = s.xmat()[0][3 * r3 + 2];
+    float p = s.xpos()[0][r3];
     const int b0 = TP::LB0 + L.lg * TP::NBL;
     static_for<TP::NBL>([&](auto I) {
       constexpr int l = decltype(I)::value;
@@ -276,8 +289,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       const float n1 = R0 * M[1] + R1 * M[4] + R2 * M[7];
       const float n2 = R0 * M[2] + R1 * M[5] + R2 * M[8];
       R0 = n0; R1 = n1; R2 = n2;
-      s.xmat[b0 + l][3 * r3] = R0; s.xmat[b0 + l][3 * r3 + 1] = R1; s.xmat[b0 + l][3 * r3 + 2] = R2;
-      s.xpos[b0 + l][r3] = p;
+      s.xmat()[b0 + l][3 * r3] = R0; s.xmat()[b0 + l][3 * r3 + 1] = R1; s.xmat()[b0 + l][3 * r3 + 2] = R2;
+      s.xpos()[b0 + l][r3] = p;
     });
   }
   WSYNC();
@@ -288,13 +301,13 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
       S.l = v3(j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f);
     } else if (j < 6) {
       int c = j - 3;
-      S.a = v3(s.xmat[0][c], s.xmat[0][3 + c], s.xmat[0][6 + c]);
+      S.a = v3(s.xmat()[0][c], s.xmat()[0][3 + c], s.xmat()[0][6 + c]);
       S.l = v3(0.f, 0.f, 0.f);
     } else {
       int b;
       if constexpr (TP::kStar) b = j >= TP::LD0 ? dof_body_of<TP>(j) : tbl_dofbody(s, j); else b = tbl_dofbody(s, j);
-      V3 a = mat_vec(s.xmat[b], ld3(axb[j]));
-      V3 r = ld3(s.xpos[0]) - ld3(s.xpos[b]);
+      V3 a = mat_vec(s.xmat()[b], ld3(axb[j]));
+      V3 r = ld3(s.xpos()[0]) - ld3(s.xpos()[b]);
       S.a = a;
       S.l = cross(a, r);
     }
@@ -306,7 +319,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
 template <class TP>
 __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
   for (int b = lane; b < s.nb(); b += kWave) {
-    const float* R = s.xmat[b];
+    const float* R = s.xmat()[b];
     const float* q = &m.body_inertia[6 * b];
     float Il[9] = {q[0], q[3], q[4], q[3], q[1], q[5], q[4], q[5], q[2]};
     float Tm[9], Iw[9];
@@ -318,19 +331,12 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) Iw[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
-    V3 c = mat_vec(R, ld3(&m.body_ipos[3 * b])) + (ld3(s.xpos[b]) - ld3(s.xpos[0]));
+    V3 c = mat_vec(R, ld3(&m.body_ipos[3 * b])) + (ld3(s.xpos()[b]) - ld3(s.xpos()[0]));
     float ms = m.body_mass[b], cc = dot(c, c);
     float* I = s.Ib[b];
     I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
     I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
     I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
-    if constexpr (kHasIsym<TP>) {
-    float* Q = s.Isym[b];                // [[I, [h]x], [-[h]x, m 1]], upper triangle row-major
-    Q[0] = I[4]; Q[1] = I[7]; Q[2] = I[8]; Q[3] = 0.f;   Q[4] = -I[3]; Q[5] = I[2];
-    Q[6] = I[5]; Q[7] = I[9]; Q[8] = I[3]; Q[9] = 0.f;   Q[10] = -I[1];
-    Q[11] = I[6]; Q[12] = -I[2]; Q[13] = I[1]; Q[14] = 0.f;
-    Q[15] = ms; Q[16] = 0.f; Q[17] = 0.f; Q[18] = ms; Q[19] = 0.f; Q[20] = ms;
-    }
   }
   WSYNC();
 }
@@ -366,11 +372,15 @@ template <class TP>
 __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
   static_assert(sizeof(CollisionScratch) <= sizeof(float) * TP::NB * 12, "collision scratch does not fit T..W");
   CollisionScratch& X = *reinterpret_cast<CollisionScratch*>(&s.T[0][0]);
-  int* geom_slot0 = reinterpret_cast<int*>(&s.vA[0]);     // first contact slot of every geom (up to 128 ints in vA..vD, scratch here)
-  static_assert(4 * TP::NV >= 2 * kWave, "slot table (128 geoms) does not fit vA..vD");
+  // first contact slot of every geom (up to 128 ints): behind the scratch in T..W where that is large enough, else behind
+  // the body positions in the contact-wrench buffer (both dead until the solver starts)
+  constexpr bool kSlotInTW = sizeof(CollisionScratch) + 2 * kWave * sizeof(int) <= sizeof(float) * TP::NB * 12;
+  static_assert(kSlotInTW || 3 * (TP::NB - 1) + 2 * kWave <= 6 * kMaxCon, "slot table (128 geoms) does not fit");
+  int* geom_slot0 = kSlotInTW ? reinterpret_cast<int*>(&s.T[0][0]) + sizeof(CollisionScratch) / sizeof(int)
+                              : reinterpret_cast<int*>(&s.c_w[0][0]) + 3 * (TP::NB - 1);
   const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
   const float pd = m.plane[3];
-  const V3 o = ld3(s.xpos[0]);
+  const V3 o = ld3(s.xpos()[0]);
   // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
   // (more than 64 contact geoms — e.g. every body segment in contact — take further passes of 64)
   int nh = 0, slot_base = 0;
@@ -383,8 +393,8 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   if (gi < m.ng) {
     g_body = m.geom_body[gi]; g_type = m.geom_type[gi]; g_margin = m.pair_margin[gi];
     g_hadr = m.geom_hulladr[gi]; g_hnum = m.geom_hullnum[gi];
-    const float* R = s.xmat[g_body];
-    const V3 xp = ld3(s.xpos[g_body]);
+    const float* R = s.xmat()[g_body];
+    const V3 xp = ld3(s.xpos()[g_body]);
     V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * gi]));
     float dc = dot(n, cw) + dot(n, xp) - pd;
     near = dc - m.geom_bsphere[4 * gi + 3] - m.terrain[4] <= g_margin;
@@ -411,8 +421,8 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     const float margin = readlane_f(g_margin, g);
     const float* V = m.hull_vert + 3 * __builtin_amdgcn_readlane(g_hadr, g);
     const int nvv = __builtin_amdgcn_readlane(g_hnum, g);
-    const float* R = s.xmat[b];
-    const V3 xp = ld3(s.xpos[b]);
+    const float* R = s.xmat()[b];
+    const V3 xp = ld3(s.xpos()[b]);
     const V3 nb = matT_vec(R, n);
     const float c0 = dot(n, xp) - pd;
     const bool rough = m.terrain_type != 0;
@@ -510,7 +520,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   for (int b = lane; b <= s.nb(); b += kWave) {
     int c_before = 0;
     for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
-    s.body_cstart[b] = c_before;
+    s.body_cstart[b] = (unsigned char)c_before;
   }
   WSYNC();
 }
@@ -617,19 +627,44 @@ __device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const DevMo
   sweep_project(s, s.W, m, lane, [&](int j, float v) { emit(j, v + s.arm[j] * x[j]); });
 }
 
-// row `r` of the 6x6 spatial inertia [[I, [h]x], [-[h]x, m 1]] built from (m, h, I sym6)
-__device__ __forceinline__ void inertia_row(const float* I, int r, float* row) {
-  const bool top = r < 3;
-  const int k = top ? r : r - 3;
-  const float e0 = k == 0 ? 1.f : 0.f, e1 = k == 1 ? 1.f : 0.f, e2 = k == 2 ? 1.f : 0.f;
-  const float hx = I[1], hy = I[2], hz = I[3];
-  // e_k x h  = row k of [h]x
-  const float c0 = e1 * hz - e2 * hy, c1 = e2 * hx - e0 * hz, c2 = e0 * hy - e1 * hx;
-  const float i0 = e0 * I[4] + e1 * I[7] + e2 * I[8], i1 = e0 * I[7] + e1 * I[5] + e2 * I[9],
-              i2 = e0 * I[8] + e1 * I[9] + e2 * I[6];
-  const float ms = I[0];
-  row[0] = top ? i0 : -c0; row[1] = top ? i1 : -c1; row[2] = top ? i2 : -c2;
-  row[3] = top ? c0 : ms * e0; row[4] = top ? c1 : ms * e1; row[5] = top ? c2 : ms * e2;
+// Row r of the 6x6 spatial inertia [[I, [h]x], [-[h]x, m 1]] read straight out of the 10-float form (m, hx, hy, hz,
+// Ixx, Iyy, Izz, Ixy, Ixz, Iyz): entry c = sgn[r][c] * I10[idx[r][c]].  A second, 21-float copy of every body's inertia
+// (4 KB of LDS) bought nothing but the row fetch; with the map a row costs the same six LDS reads and six fused
+// multiply-adds into the articulated inertia.
+constexpr int kInertiaIdx[6][6] = {{4, 7, 8, 0, 3, 2}, {7, 5, 9, 3, 0, 1}, {8, 9, 6, 2, 1, 0},
+                                   {0, 3, 2, 0, 0, 0}, {3, 0, 1, 0, 0, 0}, {2, 1, 0, 0, 0, 0}};
+constexpr int kInertiaSgn[6][6] = {{1, 1, 1, 0, -1, 1}, {1, 1, 1, 1, 0, -1}, {1, 1, 1, -1, 1, 0},
+                                   {0, 1, -1, 1, 0, 0}, {-1, 0, 1, 0, 1, 0}, {1, -1, 0, 0, 0, 1}};
+struct InertiaRowMap { int off[6]; float sg[6]; };      // byte offsets into a body's Ib row, signs (+1, -1, 0)
+// packed per row index for the launch's table (k_tab[r][11..13]): byte offsets of columns 0-2, of columns 3-5, (sign + 1) x 2 bits
+__device__ __forceinline__ void inertia_map_pack(int r, int* words) {
+  int wa = 0, wb = 0, wc = 0;
+  static_for<6>([&](auto R) {
+    constexpr int rr = decltype(R)::value;
+    constexpr int a = 4 * (kInertiaIdx[rr][0] | kInertiaIdx[rr][1] << 8 | kInertiaIdx[rr][2] << 16);
+    constexpr int b = 4 * (kInertiaIdx[rr][3] | kInertiaIdx[rr][4] << 8 | kInertiaIdx[rr][5] << 16);
+    constexpr int c = (kInertiaSgn[rr][0] + 1) | (kInertiaSgn[rr][1] + 1) << 2 | (kInertiaSgn[rr][2] + 1) << 4 |
+                      (kInertiaSgn[rr][3] + 1) << 6 | (kInertiaSgn[rr][4] + 1) << 8 | (kInertiaSgn[rr][5] + 1) << 10;
+    if (r == rr) { wa = a; wb = b; wc = c; }
+  });
+  words[0] = wa; words[1] = wb; words[2] = wc;
+}
+__device__ __forceinline__ InertiaRowMap inertia_map_unpack(const float* q) {
+  const int wa = __float_as_int(q[11]), wb = __float_as_int(q[12]), wc = __float_as_int(q[13]);
+  InertiaRowMap M;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    M.off[c] = ((c < 3 ? wa : wb) >> (8 * (c % 3))) & 0xff;
+    M.sg[c] = (float)((wc >> (2 * c)) & 3) - 1.f;
+  }
+  return M;
+}
+// IA += row r of body b's spatial inertia
+template <class TP>
+__device__ __forceinline__ void add_inertia_row(float* IA, const FlyLds<TP>& s, int b, const InertiaRowMap& M) {
+  const char* base = reinterpret_cast<const char*>(&s.Ib[b][0]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) IA[c] = fmaf(M.sg[c], *reinterpret_cast<const float*>(base + M.off[c]), IA[c]);
 }
 
 // row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t,  l_m = (rc x d_m ; d_m)
@@ -656,7 +691,7 @@ __device__ __forceinline__ KLane k_lane(int r, const Frame& fr) {
 template <class TP>
 __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, const KLane& K, const Frame& fr) {
   float m_nn, m_n1, m_n2, m_11, m_22;
-  if constexpr (kHasIsym<TP>) {
+  if constexpr (kHasCm3<TP>) {
     const float* q = s.c_m3[c];
     m_nn = q[0]; m_n1 = q[1]; m_n2 = q[2]; m_11 = q[3]; m_22 = q[4];
     if (m_nn == 0.f) return;                       // no active row
@@ -714,13 +749,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
   AbaHandoff<TP>& H = *reinterpret_cast<AbaHandoff<TP>*>(&s.T[0][0]);
-  // offsets of row rr inside the symmetric storage (lane constants)
+  // offsets of row rr inside a symmetric 6x6's packed storage (lane constants; the hybrid kernels' hand-off slots)
   int so[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr;
-    so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
+    so[c] = TP::REST_B > 0 ? i * 6 - i * (i - 1) / 2 + (jx - i) : 0;
   }
+  const InertiaRowMap IM = inertia_map_unpack(s.k_tab[L.rr]);     // this lane's row of a body's 6x6 inertia
   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
   // forward sweep instead of keeping it: 24 registers fewer to spill
   constexpr bool kKeepS = TP::NDL <= 16;
@@ -747,8 +783,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 3>(s, nd, tau, L); });
       else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 0>(s, nd, tau, L); });
     } else {
-      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so); });
-      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so); });
+      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so, IM); });
+      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so, IM); });
       if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
       WSYNC();
     }
@@ -762,14 +798,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     const int j = j0 + d;
     if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
       const int b = b0 + TP::lbody(d);
-      float row[6];
-      if constexpr (kHasIsym<TP>) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
-      } else inertia_row(s.Ib[b], L.rr, row);
-      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
-#pragma unroll
-      for (int i = 0; i < 6; i++) IA[i] += row[i];
+      add_inertia_row(IA, s, b, IM);
+      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr);
     }
     float sj[6];
 #pragma unroll
@@ -791,11 +821,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   float Ur[6], ur[6], invDr[6];
   float Rm[3][3];                       // Rm[c][k] = component c of the k-th rotation axis of the free joint
   {
-    float row[6];
-    if constexpr (kHasIsym<TP>) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
-    } else inertia_row(s.Ib[0], L.rr, row);
+    float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    add_inertia_row(row, s, 0, IM);
     if (withK) {
       for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, KL, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
@@ -955,7 +982,7 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
     stsv(s.c_w[lane], SV{cross(c.r, F), F});
     s.c_info[lane] = c.info | (act << 20);
-    if constexpr (kHasIsym<TP>) {
+    if constexpr (kHasCm3<TP>) {
       const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
       const float Dm = c.D * c.mu, Dmm = Dm * c.mu;
       float* q = s.c_m3[lane];
@@ -1028,6 +1055,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   stage_inertia(s, m, lane);
   STAGE(2);
   stage_collision(s, m, lane);
+  if (last) write_poses(s, m, st, w, lane);       // the body poses die here (their LDS is the solver's from now on)
   STAGE(3);
   const int ncon = s.ncon;
 
@@ -1432,7 +1460,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
           Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
         }
         float* o16 = out + 16 * lane;
-        V3 o = ld3(s.xpos[0]);
+        V3 o = ld3(s.xpos()[0]);
         if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
           F = v3(dot(fr.n, F), dot(fr.t1, F), dot(fr.t2, F));
           Tq = v3(dot(fr.n, Tq), dot(fr.t1, Tq), dot(fr.t2, Tq));
@@ -1482,23 +1510,30 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
   for (int i = lane; i < m.nu; i += kWave) {
     st.ctrl[(size_t)w * m.nu + i] = s.ctrl[i];
   }
+  if (lane == 0) {
+    st.time[w] = time;
+    st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
+    st.stats[4 * w + 3] = (float)(4 * s.ncon);
+  }
+}
+
+// Pose outputs (named segments, sites) of the poses the last kinematics stage computed.  Called while the body poses
+// are alive in LDS: right after the collision stage of a launch's last step (as in the reference engine, the poses a
+// step reports belong to the state before its integration), or after the kinematics of a reset.
+template <class TP>
+__device__ void write_poses(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane) {
   for (int sg = lane; sg < m.nseg; sg += kWave) {
     int b = m.seg_body[sg];
-    V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.seg_pos[3 * sg]));
-    Q4 q = qnorm(qmul(mat_quat(s.xmat[b]), ldq(&m.seg_quat[4 * sg])));
+    V3 p = ld3(s.xpos()[b]) + mat_vec(s.xmat()[b], ld3(&m.seg_pos[3 * sg]));
+    Q4 q = qnorm(qmul(mat_quat(s.xmat()[b]), ldq(&m.seg_quat[4 * sg])));
     if (q.w < 0.f) q = Q4{-q.w, -q.x, -q.y, -q.z};
     st3(&st.seg_xpos[((size_t)w * m.nseg + sg) * 3], p);
     stq(&st.seg_xquat[((size_t)w * m.nseg + sg) * 4], q);
   }
   for (int sg = lane; sg < m.nsite; sg += kWave) {
     int b = m.site_body[sg];
-    V3 p = ld3(s.xpos[b]) + mat_vec(s.xmat[b], ld3(&m.site_pos[3 * sg]));
+    V3 p = ld3(s.xpos()[b]) + mat_vec(s.xmat()[b], ld3(&m.site_pos[3 * sg]));
     st3(&st.site_xpos[((size_t)w * m.nsite + sg) * 3], p);
-  }
-  if (lane == 0) {
-    st.time[w] = time;
-    st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
-    st.stats[4 * w + 3] = (float)(4 * s.ncon);
   }
 }
 
@@ -1527,9 +1562,34 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     __syncthreads();
   }
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= st.n_worlds) return;
-  const int w = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;
+  // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps.  Chunked launches
+  // (more worlds than resident waves): the grid holds n_worlds x n_chunks workgroups; each takes a ticket when it
+  // starts, ticket t = (chunk t / n_worlds, world order[t % n_worlds]), and steps that world through that chunk.  A
+  // world's cost varies 2x with its gait phase, so whole-launch items leave the machine half empty while the costliest
+  // worlds finish; with chunks the tail is one chunk long.  A chunk waits for its world's previous chunk (an older
+  // ticket, hence a workgroup that is already running: no deadlock whatever the dispatch order) and takes the state
+  // over through HBM with agent-scope release / acquire.
+  int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps, n_chunks = 1;
+  unsigned int epoch = 0;
+  const bool chunked = mode == 0 && st.chunk_len > 0;
+  if (chunked) {
+    n_chunks = (n_steps + st.chunk_len - 1) / st.chunk_len;
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(&st.csched->ticket, 1u);
+    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
+    if (chunk >= n_chunks) return;
+    step0 = chunk * st.chunk_len; step1 = step0 + st.chunk_len < n_steps ? step0 + st.chunk_len : n_steps;
+    epoch = st.csched->epoch;
+  } else if (slot >= st.n_worlds) return;
+  const int w = st.order ? st.order[slot] : slot;
   if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
+  if (chunked && chunk > 0) {
+    const unsigned int want = epoch * 8u + (unsigned int)chunk;
+    if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  }
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   STAGE_INIT();
@@ -1539,7 +1599,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     float* q = s.k_tab[lane];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { q[i] = K.dA[i]; q[3 + i] = K.dB[i]; q[6 + i] = K.dO[i]; }
-    q[9] = __int_as_float(K.ia); q[10] = __int_as_float(K.ib); q[11] = 0.f;
+    q[9] = __int_as_float(K.ia); q[10] = __int_as_float(K.ib);
+    int words[3];
+    inertia_map_pack(lane, words);
+    q[11] = __int_as_float(words[0]); q[12] = __int_as_float(words[1]); q[13] = __int_as_float(words[2]);
   }
   float time;
   float sum_con = 0.f, sum_it = 0.f, sum_of = 0.f;     // lane 0: running sums over the steps of this launch
@@ -1552,6 +1615,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     time = 0.f;
     WSYNC();
     stage_kinematics(s, m, lane);
+    write_poses(s, m, st, w, lane);
   } else {
     for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = st.qpos[(size_t)w * s.nq() + i];
     for (int i = lane; i < s.nv(); i += kWave) {
@@ -1561,7 +1625,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = st.ctrl[(size_t)w * m.nu + i];
     time = st.time[w];
     WSYNC();
-    for (int step = 0; step < n_steps; ++step) {
+    for (int step = step0; step < step1; ++step) {
       if (rp.table) {
         int row = (rp.start + step) % rp.table_steps;
         const float* src = rp.table + ((size_t)w * rp.table_steps + row) * rp.n_act;
@@ -1569,7 +1633,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
         WSYNC();
       }
       STAGE(0);
-      physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);
+      physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);     // pure outputs: the launch's last step only
       physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
       STAGE(15);
       time += m.timestep;
@@ -1580,12 +1644,24 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
   if (lane == 0) {
     float* q = &st.stats_sum[4 * (size_t)w];
     if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
-    else { q[0] += (float)n_steps; q[1] += sum_con; q[2] += sum_it; q[3] += sum_of; }
+    else { q[0] += (float)(step1 - step0); q[1] += sum_con; q[2] += sum_it; q[3] += sum_of; }
   }
   if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
   if (mode == 0 && lane == 0) {
-    st.cost[w] = (float)(__builtin_amdgcn_s_memtime() - t_begin);
+    const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
+    st.cost[w] = chunk > 0 ? st.cost[w] + cyc : cyc;                 // the world's cycles over the whole launch
     if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+  if (chunked) {
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // the state this chunk wrote, before the hand-off flag
+    if (lane == 0) {
+      __hip_atomic_store(&st.chunk_done[w], epoch * 8u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int total = (unsigned int)st.n_worlds * (unsigned int)n_chunks;
+      if (atomicAdd(&st.csched->finished, 1u) == total - 1u) {       // last workgroup of the launch: rewind for the next one
+        st.csched->ticket = 0u; st.csched->finished = 0u; st.csched->epoch = epoch + 1u;
+      }
+    }
   }
   STAGE(16);
   STAGE_FLUSH();

@@ -60,16 +60,16 @@ __device__ __forceinline__ void rest_levels_lane(FlyLds<TP>& s, int lane, F&& f)
 template <class TP>
 __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]) {
   auto body = [&](int b, int p) {
-    const float* R = s.xmat[p];
+    const float* R = s.xmat()[p];
     const float* M = relm[b];
-    st3(s.xpos[b], ld3(s.xpos[p]) + mat_vec(R, ld3(M + 9)));
+    st3(s.xpos()[b], ld3(s.xpos()[p]) + mat_vec(R, ld3(M + 9)));
     float out[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) out[3 * i + j] = R[3 * i] * M[j] + R[3 * i + 1] * M[3 + j] + R[3 * i + 2] * M[6 + j];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s.xmat[b][i] = out[i];
+    for (int i = 0; i < 9; ++i) s.xmat()[b][i] = out[i];
   };
   if constexpr (TP::kStar) {
     if (m.rest_fast) { rest_levels_lane<TP, false>(s, lane, [&](const RestNode& nd) { body(nd.b, nd.parent); }); return; }
@@ -319,11 +319,11 @@ __device__ __forceinline__ void rest_dofs(int adr, int num, F&& f) {
 // full elimination of a body: matrix factors and vector part
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6]) {
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const InertiaRowMap& IM) {
   const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
   // everything that depends on the node only, first: the body's inertia row and its dofs' axes and scalars
-  float row[6];
-  inertia_row(s.Ib[nd.b], L.rr, row);
+  float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  add_inertia_row(row, s, nd.b, IM);
   float sj[NUM > 0 ? NUM : 1][6], sown[NUM > 0 ? NUM : 1], delta[NUM > 0 ? NUM : 1], tj[NUM > 0 ? NUM : 1];
   if constexpr (NUM > 0) {
 #pragma unroll
