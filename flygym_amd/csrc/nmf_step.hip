@@ -1499,19 +1499,26 @@ __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STA
   WSYNC();
 }
 
+// The state a world carries from one workgroup to the next inside a chunked launch (qpos, qvel, warm start, controls,
+// clock, running sums) crosses HBM with agent-scope accesses: such loads / stores bypass the caches that are not
+// coherent between XCDs, so the hand-off needs no L2 write-back / invalidate fence (which costs tens of microseconds
+// with every wave of the chip fencing) — only "stores done before the flag", i.e. s_waitcnt vmcnt(0).
+__device__ __forceinline__ float ld_state(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <class TP>
 __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time) {
-  for (int i = lane; i < s.nq(); i += kWave) st.qpos[(size_t)w * s.nq() + i] = s.qpos[i];
+  for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
-    st.qvel[(size_t)w * s.nv() + i] = s.qvel[i];
-    st.qacc_ws[(size_t)w * s.nv() + i] = s.qacc[i];
+    st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
+    st_state(&st.qacc_ws[(size_t)w * s.nv() + i], s.qacc[i]);
     st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
   }
   for (int i = lane; i < m.nu; i += kWave) {
-    st.ctrl[(size_t)w * m.nu + i] = s.ctrl[i];
+    st_state(&st.ctrl[(size_t)w * m.nu + i], s.ctrl[i]);
   }
   if (lane == 0) {
-    st.time[w] = time;
+    st_state(&st.time[w], time);
     st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
     st.stats[4 * w + 3] = (float)(4 * s.ncon);
   }
@@ -1587,7 +1594,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
   if (chunked && chunk > 0) {
     const unsigned int want = epoch * 8u + (unsigned int)chunk;
     if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
     __syncthreads();
   }
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -1617,13 +1624,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     stage_kinematics(s, m, lane);
     write_poses(s, m, st, w, lane);
   } else {
-    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = st.qpos[(size_t)w * s.nq() + i];
+    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
     for (int i = lane; i < s.nv(); i += kWave) {
-      s.qvel[i] = st.qvel[(size_t)w * s.nv() + i];
-      s.qacc[i] = st.qacc_ws[(size_t)w * s.nv() + i];
+      s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
+      s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
     }
-    for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = st.ctrl[(size_t)w * m.nu + i];
-    time = st.time[w];
+    for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
+    time = ld_state(&st.time[w]);
     WSYNC();
     for (int step = step0; step < step1; ++step) {
       if (rp.table) {
@@ -1644,17 +1651,20 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
   if (lane == 0) {
     float* q = &st.stats_sum[4 * (size_t)w];
     if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
-    else { q[0] += (float)(step1 - step0); q[1] += sum_con; q[2] += sum_it; q[3] += sum_of; }
+    else {
+      st_state(q, ld_state(q) + (float)(step1 - step0)); st_state(q + 1, ld_state(q + 1) + sum_con);
+      st_state(q + 2, ld_state(q + 2) + sum_it); st_state(q + 3, ld_state(q + 3) + sum_of);
+    }
   }
   if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
   if (mode == 0 && lane == 0) {
     const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
-    st.cost[w] = chunk > 0 ? st.cost[w] + cyc : cyc;                 // the world's cycles over the whole launch
+    st_state(&st.cost[w], chunk > 0 ? ld_state(&st.cost[w]) + cyc : cyc);     // the world's cycles over the whole launch
     if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
   if (chunked) {
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // the state this chunk wrote, before the hand-off flag
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this chunk wrote (agent-scope stores) is out
+    __syncthreads();                                                  // ... for every lane, before the hand-off flag
     if (lane == 0) {
       __hip_atomic_store(&st.chunk_done[w], epoch * 8u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned int total = (unsigned int)st.n_worlds * (unsigned int)n_chunks;
