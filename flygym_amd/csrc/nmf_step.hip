@@ -85,9 +85,13 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
   NMF_TREE_TABLES
 };
 
-// star kernels keep the 3x3 pyramid-coefficient matrix of every contact in LDS (c_m3); the hybrid kernels rebuild it
+// star kernels (register-bound at 8 flies per CU, LDS to spare) keep two row-fetch accelerators in LDS: the 3x3
+// pyramid-coefficient matrix of every contact (c_m3) and every body's inertia as a symmetric 6x6 (Isym: six reads with
+// lane-constant offsets that the compiler pairs into ds_read2); the hybrid kernels (LDS-bound) rebuild the former from
+// the active-row mask and read inertia rows through InertiaRowMap
 template <class TP> constexpr bool has_cm3() { if constexpr (TP::kStar) return TP::REST_B == 0; else return false; }
 template <class TP> inline constexpr bool kHasCm3 = has_cm3<TP>();
+template <class TP> inline constexpr bool kHasIsym = has_cm3<TP>();
 
 template <class TP>
 struct __align__(16) FlyLds : TreeLds<TP> {
@@ -108,7 +112,8 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float ctrl[TP::kCtrl];
   float S[TP::NV][6];
-  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via i_map)
+  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap)
+  float Isym[kHasIsym<TP> ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
   static_assert(6 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
   __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
@@ -130,7 +135,10 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // the row's map into a body's 10-float inertia (byte offsets of columns 0-2 / 3-5, 2-bit signs + 1): see InertiaRowMap
   float k_tab[6][14];
   float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
-  unsigned char body_cstart[(TP::NB + 1 + 3) / 4 * 4];   // first contact of every body (contacts are sorted by body; <= kMaxCon)
+  // first contact of every body (contacts are sorted by body; <= kMaxCon): ints for the star kernels (the ABA fetches a
+  // leg's nine in paired reads), bytes where LDS is what limits residency
+  using cstart_t = std::conditional_t<kHasIsym<TP>, int, unsigned char>;
+  cstart_t body_cstart[(TP::NB + 1 + 3) / 4 * 4];
   int ncon, overflow, iters;
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
   // ds_* instruction (a float* argument would be a generic pointer -> flat_load / flat_store)
@@ -337,6 +345,13 @@ __device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
     I[0] = ms; I[1] = ms * c.x; I[2] = ms * c.y; I[3] = ms * c.z;
     I[4] = Iw[0] + ms * (cc - c.x * c.x); I[5] = Iw[4] + ms * (cc - c.y * c.y); I[6] = Iw[8] + ms * (cc - c.z * c.z);
     I[7] = Iw[1] - ms * c.x * c.y; I[8] = Iw[2] - ms * c.x * c.z; I[9] = Iw[5] - ms * c.y * c.z;
+    if constexpr (kHasIsym<TP>) {
+      float* Q = s.Isym[b];                // [[I, [h]x], [-[h]x, m 1]], upper triangle row-major
+      Q[0] = I[4]; Q[1] = I[7]; Q[2] = I[8]; Q[3] = 0.f;   Q[4] = -I[3]; Q[5] = I[2];
+      Q[6] = I[5]; Q[7] = I[9]; Q[8] = I[3]; Q[9] = 0.f;   Q[10] = -I[1];
+      Q[11] = I[6]; Q[12] = -I[2]; Q[13] = I[1]; Q[14] = 0.f;
+      Q[15] = ms; Q[16] = 0.f; Q[17] = 0.f; Q[18] = ms; Q[19] = 0.f; Q[20] = ms;
+    }
   }
   WSYNC();
 }
@@ -520,7 +535,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   for (int b = lane; b <= s.nb(); b += kWave) {
     int c_before = 0;
     for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
-    s.body_cstart[b] = (unsigned char)c_before;
+    s.body_cstart[b] = (typename FlyLds<TP>::cstart_t)c_before;
   }
   WSYNC();
 }
@@ -754,9 +769,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr;
-    so[c] = TP::REST_B > 0 ? i * 6 - i * (i - 1) / 2 + (jx - i) : 0;
+    so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
   }
-  const InertiaRowMap IM = inertia_map_unpack(s.k_tab[L.rr]);     // this lane's row of a body's 6x6 inertia
+  InertiaRowMap IM{};                                              // this lane's row of a body's 6x6 inertia, read out of Ib
+  if constexpr (!kHasIsym<TP>) IM = inertia_map_unpack(s.k_tab[L.rr]);
   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
   // forward sweep instead of keeping it: 24 registers fewer to spill
   constexpr bool kKeepS = TP::NDL <= 16;
@@ -798,8 +814,17 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     const int j = j0 + d;
     if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
       const int b = b0 + TP::lbody(d);
-      add_inertia_row(IA, s, b, IM);
-      for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr);
+      if constexpr (kHasIsym<TP>) {
+        float row[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
+        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
+#pragma unroll
+        for (int i = 0; i < 6; i++) IA[i] += row[i];
+      } else {
+        add_inertia_row(IA, s, b, IM);
+        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr);
+      }
     }
     float sj[6];
 #pragma unroll
@@ -822,7 +847,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   float Rm[3][3];                       // Rm[c][k] = component c of the k-th rotation axis of the free joint
   {
     float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    add_inertia_row(row, s, 0, IM);
+    if constexpr (kHasIsym<TP>) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
+    } else add_inertia_row(row, s, 0, IM);
     if (withK) {
       for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, KL, fr);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row

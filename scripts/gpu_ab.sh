@@ -1,9 +1,22 @@
 #!/bin/bash
-# A/B on the GPU box: for each prebuilt variant lib in gpurun_out/variants/*.so run the parity tests + bench
+# quick kernel A/B on the GPU box: bench lines for the in-tree library (and any NMF_HIP_LIB variants passed as args)
 cd $GRAFT_REPO_ROOT
-for so in variants/*.so; do
-  echo "=== $so"
-  cp $so flygym_amd/libnmf_hip.so
-  python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-  python bench.py --no-cpu-baseline --steps 500 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value %.3e  ms/launch %.2f  iters %.2f contacts %.2f' % (d['value'], d['roofline']['kernel_ms_per_launch'], d['config']['mean_newton_iters'], d['config']['mean_contacts']))"
+mkdir -p gpurun_out
+B="python bench.py --no-cpu-baseline"
+line() { grep '^{"metric"' | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); c = d['config']
+    print(sys.argv[1], round(d['value'] / 1e6, 2), 'M', 'ms/launch', round(d['roofline']['kernel_ms_per_launch'], 3), 'contacts', round(c['mean_contacts'], 2), 'iters', round(c['mean_newton_iters'], 2), 'valid', d.get('valid'))
+" "$1"; }
+{
+for lib in "" "$@"; do
+  if [ -n "$lib" ]; then export NMF_HIP_LIB=$PWD/build/libnmf_$lib.so; fi
+  tag=${lib:-tree}
+  NMF_NO_CHUNKS=1 timeout 200 $B 2>/dev/null | line "$tag no chunks (cpg)"
+  timeout 200 $B 2>/dev/null | line "$tag chunks (cpg)"
+  timeout 200 $B --steps 20 --warmup 5 2>/dev/null | line "$tag chunks (cpg, driver args)"
+  timeout 200 $B --workload replay 2>/dev/null | line "$tag chunks (replay)"
 done
+} > gpurun_out/ab.log 2>&1
+cat gpurun_out/ab.log
