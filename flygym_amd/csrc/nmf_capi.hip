@@ -72,6 +72,7 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
+  int max_chunks = 5, min_chunk_steps = 4;   // NMF_MAX_CHUNKS (<= 7) / NMF_MIN_CHUNK_STEPS: tuning experiments
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -180,8 +181,8 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
   // state hand-off between chunks costs two agent-scope fences of a few microseconds each)
   int n_chunks = 1;
   b->st.chunk_len = 0; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
-  if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 8) {
-    const int want = std::min(5, n_steps / 4);
+  if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {
+    const int want = std::min(b->max_chunks, n_steps / b->min_chunk_steps);
     b->st.chunk_len = (n_steps + want - 1) / want;
     n_chunks = (n_steps + b->st.chunk_len - 1) / b->st.chunk_len;
   }
@@ -390,6 +391,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
+    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(7, atoi(e)));
+    if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
       (void)hipMemset(p, 0, sizeof(nmf::SchedState));
