@@ -185,8 +185,10 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
     const int want = std::min(b->max_chunks, n_steps / b->min_chunk_steps);
     b->st.chunk_len = (n_steps + want - 1) / want;
     n_chunks = (n_steps + b->st.chunk_len - 1) / b->st.chunk_len;
+    if (n_chunks < 2) { b->st.chunk_len = 0; n_chunks = 1; }
   }
-  dim3 grid((unsigned)b->n_worlds * (unsigned)n_chunks), block(nmf::kWave);
+  // chunked: one persistent workgroup per resident wave pulls (chunk, world) items; plain: one workgroup per world
+  dim3 grid(n_chunks > 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks) : (unsigned)b->n_worlds), block(nmf::kWave);
   // more worlds than resident waves: the launch runs in rounds; start the costliest worlds first
   b->st.order = nullptr; b->st.sched = nullptr;
   if (mode == 0 && b->order_buf && b->sched_buf && b->n_worlds > b->resident_waves) {

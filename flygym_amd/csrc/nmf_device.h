@@ -130,9 +130,9 @@ struct DevState {
   int chunk_len;              // 0: one workgroup steps a world through the whole launch
 };
 
-// Device-resident scheduler state of chunked launches; the last workgroup of a launch rewinds it, so launches need no
+// Device-resident scheduler state of chunked launches; the last workgroup to run out of tickets rewinds it, so launches need no
 // host-side counters (hipGraph replays stay valid).
-struct ChunkSched { unsigned int ticket, finished, epoch, pad; };
+struct ChunkSched { unsigned int ticket, exited, epoch, pad; };
 
 // Device-resident state of the block-order policy (see nmf_order_kernel)
 struct SchedState {

@@ -1597,36 +1597,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     __syncthreads();
   }
   const int lane = threadIdx.x;
-  // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps.  Chunked launches
-  // (more worlds than resident waves): the grid holds n_worlds x n_chunks workgroups; each takes a ticket when it
-  // starts, ticket t = (chunk t / n_worlds, world order[t % n_worlds]), and steps that world through that chunk.  A
-  // world's cost varies 2x with its gait phase, so whole-launch items leave the machine half empty while the costliest
-  // worlds finish; with chunks the tail is one chunk long.  A chunk waits for its world's previous chunk (an older
-  // ticket, hence a workgroup that is already running: no deadlock whatever the dispatch order) and takes the state
-  // over through HBM with agent-scope release / acquire.
-  int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps, n_chunks = 1;
-  unsigned int epoch = 0;
-  const bool chunked = mode == 0 && st.chunk_len > 0;
-  if (chunked) {
-    n_chunks = (n_steps + st.chunk_len - 1) / st.chunk_len;
-    unsigned int t = 0;
-    if (lane == 0) t = atomicAdd(&st.csched->ticket, 1u);
-    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-    chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
-    if (chunk >= n_chunks) return;
-    step0 = chunk * st.chunk_len; step1 = step0 + st.chunk_len < n_steps ? step0 + st.chunk_len : n_steps;
-    epoch = st.csched->epoch;
-  } else if (slot >= st.n_worlds) return;
-  const int w = st.order ? st.order[slot] : slot;
-  if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
-  if (chunked && chunk > 0) {
-    const unsigned int want = epoch * 8u + (unsigned int)chunk;
-    if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
-    __syncthreads();
-  }
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   STAGE_INIT();
   for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
   if (lane < 6) {
@@ -1639,67 +1609,99 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     inertia_map_pack(lane, words);
     q[11] = __int_as_float(words[0]); q[12] = __int_as_float(words[1]); q[13] = __int_as_float(words[2]);
   }
-  float time;
-  float sum_con = 0.f, sum_it = 0.f, sum_of = 0.f;     // lane 0: running sums over the steps of this launch
-  if (mode == 1) {
-    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
-    for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
-    for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
-    for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
-    if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
-    time = 0.f;
-    WSYNC();
-    stage_kinematics(s, m, lane);
-    write_poses(s, m, st, w, lane);
-  } else {
-    for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
-    for (int i = lane; i < s.nv(); i += kWave) {
-      s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
-      s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
-    }
-    for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
-    time = ld_state(&st.time[w]);
-    WSYNC();
-    for (int step = step0; step < step1; ++step) {
-      if (rp.table) {
-        int row = (rp.start + step) % rp.table_steps;
-        const float* src = rp.table + ((size_t)w * rp.table_steps + row) * rp.n_act;
-        for (int a = lane; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
-        WSYNC();
+  // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps and exits.  Chunked
+  // launches (more worlds than resident waves): the launch is cut into n_chunks chunks of chunk_len steps, the grid is
+  // one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket counter until the
+  // counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost varies 2x with its gait
+  // phase, so whole-launch items leave the machine half empty while the costliest worlds finish; with chunks the tail is
+  // one chunk long.  An item waits for its world's previous chunk (an older ticket, hence taken by a workgroup that is
+  // running or done: no deadlock whatever the dispatch order) and takes the state over through HBM (ld_state / st_state).
+  // The model constants staged above stay in LDS from item to item.
+  const bool chunked = mode == 0 && st.chunk_len > 0;
+  const int n_chunks = chunked ? (n_steps + st.chunk_len - 1) / st.chunk_len : 1;
+  const unsigned int epoch = chunked ? st.csched->epoch : 0u;
+  for (;;) {
+    int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
+    if (chunked) {
+      unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(&st.csched->ticket, 1u);
+      t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= (unsigned int)st.n_worlds * (unsigned int)n_chunks) {
+        // out of items.  The last workgroup to get here rewinds the counters for the next launch (no host-side state,
+        // so hipGraph replays stay valid); every workgroup has taken its final ticket by then.
+        if (lane == 0 && atomicAdd(&st.csched->exited, 1u) == gridDim.x - 1u) {
+          st.csched->ticket = 0u; st.csched->exited = 0u; st.csched->epoch = epoch + 1u;
+        }
+        break;
       }
-      STAGE(0);
-      physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);     // pure outputs: the launch's last step only
-      physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
-      STAGE(15);
-      time += m.timestep;
-      if (lane == 0) { sum_con += (float)s.ncon; sum_it += (float)s.iters; sum_of += (float)s.overflow; }
+      chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
+      step0 = chunk * st.chunk_len; step1 = step0 + st.chunk_len < n_steps ? step0 + st.chunk_len : n_steps;
+    } else if (slot >= st.n_worlds) return;
+    const int w = st.order ? st.order[slot] : slot;
+    if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
+    if (chunked && chunk > 0) {
+      const unsigned int want = epoch * 8u + (unsigned int)chunk;
+      if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
+      __syncthreads();
     }
-  }
-  write_outputs(s, m, st, w, lane, time);
-  if (lane == 0) {
-    float* q = &st.stats_sum[4 * (size_t)w];
-    if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
-    else {
-      st_state(q, ld_state(q) + (float)(step1 - step0)); st_state(q + 1, ld_state(q + 1) + sum_con);
-      st_state(q + 2, ld_state(q + 2) + sum_it); st_state(q + 3, ld_state(q + 3) + sum_of);
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    float time;
+    float sum_con = 0.f, sum_it = 0.f, sum_of = 0.f;     // lane 0: running sums over the steps of this item
+    if (mode == 1) {
+      for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
+      for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
+      for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
+      for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
+      if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
+      time = 0.f;
+      WSYNC();
+      stage_kinematics(s, m, lane);
+      write_poses(s, m, st, w, lane);
+    } else {
+      for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
+      for (int i = lane; i < s.nv(); i += kWave) {
+        s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
+        s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
+      }
+      for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
+      time = ld_state(&st.time[w]);
+      WSYNC();
+      for (int step = step0; step < step1; ++step) {
+        if (rp.table) {
+          int row = (rp.start + step) % rp.table_steps;
+          const float* src = rp.table + ((size_t)w * rp.table_steps + row) * rp.n_act;
+          for (int a = lane; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
+          WSYNC();
+        }
+        STAGE(0);
+        physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);     // pure outputs: the launch's last step only
+        physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
+        STAGE(15);
+        time += m.timestep;
+        if (lane == 0) { sum_con += (float)s.ncon; sum_it += (float)s.iters; sum_of += (float)s.overflow; }
+      }
     }
-  }
-  if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
-  if (mode == 0 && lane == 0) {
-    const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
-    st_state(&st.cost[w], chunk > 0 ? ld_state(&st.cost[w]) + cyc : cyc);     // the world's cycles over the whole launch
-    if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
-  if (chunked) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this chunk wrote (agent-scope stores) is out
-    __syncthreads();                                                  // ... for every lane, before the hand-off flag
+    write_outputs(s, m, st, w, lane, time);
     if (lane == 0) {
-      __hip_atomic_store(&st.chunk_done[w], epoch * 8u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int total = (unsigned int)st.n_worlds * (unsigned int)n_chunks;
-      if (atomicAdd(&st.csched->finished, 1u) == total - 1u) {       // last workgroup of the launch: rewind for the next one
-        st.csched->ticket = 0u; st.csched->finished = 0u; st.csched->epoch = epoch + 1u;
+      float* q = &st.stats_sum[4 * (size_t)w];
+      if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
+      else {
+        st_state(q, ld_state(q) + (float)(step1 - step0)); st_state(q + 1, ld_state(q + 1) + sum_con);
+        st_state(q + 2, ld_state(q + 2) + sum_it); st_state(q + 3, ld_state(q + 3) + sum_of);
       }
     }
+    if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
+    if (mode == 0 && lane == 0) {
+      const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
+      st_state(&st.cost[w], chunk > 0 ? ld_state(&st.cost[w]) + cyc : cyc);     // the world's cycles over the whole launch
+      if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    if (!chunked) break;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this item wrote (agent-scope stores) is out
+    __syncthreads();                                                  // ... for every lane, before the hand-off flag
+    if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 8u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   STAGE(16);
   STAGE_FLUSH();
