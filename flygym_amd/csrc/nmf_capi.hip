@@ -72,7 +72,7 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  int max_chunks = 5, min_chunk_steps = 4;   // NMF_MAX_CHUNKS (<= 7) / NMF_MIN_CHUNK_STEPS: tuning experiments
+  int max_chunks = 5, min_chunk_steps = 4;   // NMF_MAX_CHUNKS (<= 31) / NMF_MIN_CHUNK_STEPS: tuning experiments
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -393,7 +393,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
-    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(7, atoi(e)));
+    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(31, atoi(e)));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {

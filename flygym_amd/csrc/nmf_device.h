@@ -126,7 +126,7 @@ struct DevState {
   // chunked launches (nmf_step_kernel): a launch of n_steps is cut into chunks of chunk_len steps; workgroups take
   // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
   struct ChunkSched* csched;
-  unsigned int* chunk_done;   // [n_worlds] epoch * 8 + chunks of this launch the world has finished
+  unsigned int* chunk_done;   // [n_worlds] epoch * 32 + chunks of this launch the world has finished
   int chunk_len;              // 0: one workgroup steps a world through the whole launch
 };
 

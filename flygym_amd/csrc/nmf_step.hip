@@ -1640,7 +1640,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     const int w = st.order ? st.order[slot] : slot;
     if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
     if (chunked && chunk > 0) {
-      const unsigned int want = epoch * 8u + (unsigned int)chunk;
+      const unsigned int want = epoch * 32u + (unsigned int)chunk;
       if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
       __syncthreads();
@@ -1701,7 +1701,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     if (!chunked) break;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this item wrote (agent-scope stores) is out
     __syncthreads();                                                  // ... for every lane, before the hand-off flag
-    if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 8u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 32u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   STAGE(16);
   STAGE_FLUSH();
