@@ -72,7 +72,7 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  int max_chunks = 5, min_chunk_steps = 4;   // NMF_MAX_CHUNKS (<= 31) / NMF_MIN_CHUNK_STEPS: tuning experiments
+  int max_chunks = 7, min_chunk_steps = 2;   // NMF_MAX_CHUNKS (<= 31) / NMF_MIN_CHUNK_STEPS: tuning experiments
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -177,8 +177,9 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
-  // More worlds than resident waves and a launch long enough to cut: chunks of >= 4 steps, at most 5 per launch (the
-  // state hand-off between chunks costs two agent-scope fences of a few microseconds each)
+  // More worlds than resident waves and a launch long enough to cut: at most 7 chunks of >= 2 steps per launch (measured
+  // on 4096 worlds: 20-step launches 32.0 -> 36.3 M env-steps/s, 50-step launches 31.9 -> 38.3 M; more, shorter chunks lose
+  // to the per-item cost of taking a ticket and moving the state through HBM, ~10 us)
   int n_chunks = 1;
   b->st.chunk_len = 0; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
   if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {
