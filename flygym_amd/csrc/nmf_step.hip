@@ -1534,19 +1534,22 @@ __device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STA
 __device__ __forceinline__ float ld_state(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// `final`: this item ends the launch.  Pure outputs (plain stores: qacc, stats — like the pose / sensor / force outputs of
+// the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
+// otherwise reach memory after the final one's.
 template <class TP>
-__device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time) {
+__device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time, bool final) {
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
     st_state(&st.qacc_ws[(size_t)w * s.nv() + i], s.qacc[i]);
-    st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
+    if (final) st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
   }
   for (int i = lane; i < m.nu; i += kWave) {
     st_state(&st.ctrl[(size_t)w * m.nu + i], s.ctrl[i]);
   }
-  if (lane == 0) {
-    st_state(&st.time[w], time);
+  if (lane == 0) st_state(&st.time[w], time);
+  if (lane == 0 && final) {
     st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
     st.stats[4 * w + 3] = (float)(4 * s.ncon);
   }
@@ -1683,7 +1686,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
         if (lane == 0) { sum_con += (float)s.ncon; sum_it += (float)s.iters; sum_of += (float)s.overflow; }
       }
     }
-    write_outputs(s, m, st, w, lane, time);
+    write_outputs(s, m, st, w, lane, time, step1 == n_steps);
     if (lane == 0) {
       float* q = &st.stats_sum[4 * (size_t)w];
       if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
