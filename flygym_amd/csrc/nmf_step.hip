@@ -93,6 +93,29 @@ template <class TP> constexpr bool has_cm3() { if constexpr (TP::kStar) return T
 template <class TP> inline constexpr bool kHasCm3 = has_cm3<TP>();
 template <class TP> inline constexpr bool kHasIsym = has_cm3<TP>();
 
+// Row widths (in floats) of the per-dof motion subspaces S[NV][.] and the per-body twists / wrenches T, W[NB][.].  Six
+// floats are used; the width decides the LDS banks.  In every chain sweep lane (leg g, component r) reads row
+// (leg base + g * rows per leg), column r, so a 32-lane half of the wave (4 legs x 8 lanes) is conflict-free iff the four
+// 6-bank windows at g * rows_per_leg * width (mod 32) do not overlap.  With width 6 the LEGS_ONLY strides are 66 and 48
+// dwords = 2 and 16 (mod 32): up to 3 lanes per bank, 17-18 % of all LDS cycles were conflict cycles (profiles r1m,
+// r2a).  Width 7 gives 77 = 13 and 56 = 24 (mod 32): disjoint windows.  Chosen per topology at compile time; the hybrid
+// / tree kernels (LDS-bound) keep 6.
+constexpr bool rows_conflict_free(int rows_per_leg, int width, int nleg) {
+  const int ng = nleg < 4 ? nleg : 4;
+  for (int a = 0; a < ng; ++a)
+    for (int b = a + 1; b < ng; ++b) {
+      const int d = (((b - a) * rows_per_leg * width) % 32 + 32) % 32;
+      if (d < 6 || d > 26) return false;
+    }
+  return true;
+}
+constexpr int conflict_free_width(int rows_per_leg, int nleg) {
+  for (int w = 6; w <= 9; ++w) if (rows_conflict_free(rows_per_leg, w, nleg)) return w;
+  return 6;
+}
+template <class TP> constexpr int row_width_s() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NDL, TP::NLEG) : 6; else return 6; }
+template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6; else return 6; }
+
 template <class TP>
 struct __align__(16) FlyLds : TreeLds<TP> {
   // sizes: compile-time constants for the chain-star kernels, run-time values of the model for the tree kernel
@@ -111,7 +134,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float qacc_smooth[TP::NV], qfrc_smooth[TP::NV];
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float ctrl[TP::kCtrl];
-  float S[TP::NV][6];
+  float S[TP::NV][row_width_s<TP>()];
   float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap)
   float Isym[kHasIsym<TP> ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
@@ -122,7 +145,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   __device__ __forceinline__ const float (*xpos() const)[3] { return reinterpret_cast<const float(*)[3]>(&xpos_root[0]); }
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
-  float T[TP::NB][6], W[TP::NB][6];
+  float T[TP::NB][row_width_tw<TP>()], W[TP::NB][row_width_tw<TP>()];
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
   float xpos_root[3];
@@ -213,15 +236,15 @@ __device__ __forceinline__ LaneRole lane_role(int lane) {
 // general-tree sweeps (nmf_tree.h, included at the end of this file)
 template <class TP> __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]);
 template <class TP> __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane);
-template <class TP> __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane);
 template <class TP, class Extra, class Emit>
-__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit);
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra, Emit&& emit);
 template <class TP, bool WELD>
 __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane);
 template <class TP> __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane);
-template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane);
 template <class TP, class Extra>
-__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra);
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra);
 template <class S, class F> __device__ __forceinline__ void tree_down(const S& s, int lane, F&& f);
 template <class S, class F> __device__ __forceinline__ void tree_up(const S& s, int lane, F&& f);
 struct Frame;
@@ -572,7 +595,7 @@ __device__ __forceinline__ SV rest_inertia_mul(const FlyLds<TP>& s, SV t) {
 }
 
 template <class TP>
-__device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+__device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
   if constexpr (!TP::kStar) { tree_sweep_twists(s, x, T, m, lane); return; } else {
   const LaneRole L = lane_role<TP>(lane);
   float t = 0.f;
@@ -593,7 +616,7 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const
 // W[b] <- sum of W over the subtree of b (in place), then emit(j, S_j · W[body(j)]) for every dof j
 // (the projection and whatever the caller does with it share one pass: no intermediate vector, no extra sync)
 template <class TP, class Emit>
-__device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Emit&& emit) {
+__device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Emit&& emit) {
   if constexpr (!TP::kStar) { tree_sweep_project(s, W, m, lane, [](int, SV w) { return w; }, emit); return; } else {
   const bool red = rest_reduced(s);
   if constexpr (TP::REST_B > 0) { if (!red) tree_gather_levels(s, W, m, lane, [](int, SV w) { return w; }); }

@@ -125,7 +125,7 @@ __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int 
 
 // T[b] = twist of body b under the generalized vector x
 template <class TP>
-__device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+__device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
   if (lane == 0) {
     SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
     for (int j = 0; j < 6; ++j) t = t + x[j] * ldsv(s.S[j]);
@@ -136,7 +136,7 @@ __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[6], 
 }
 
 template <class TP>
-__device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[6], const DevModel& m, int lane) {
+__device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
   tree_down(s, lane, [&](int b) {
     const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
     SV t = ldsv(T[(int)s.t_parent[b]]);
@@ -147,7 +147,7 @@ __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*
 
 // W[b] <- extra(b, W[b]) + sum of the children's W, for the bodies below the root, deepest level first
 template <class TP, class Extra>
-__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra) {
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra) {
   tree_up(s, lane, [&](int b) {
     SV w = extra(b, ldsv(W[b]));
     const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[6],
 
 // W[b] <- sum over the subtree of b (in place; `extra(b)` adds a per-body term first), then emit(j, S_j . W[body(j)])
 template <class TP, class Extra, class Emit>
-__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[6], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
   tree_gather_levels(s, W, m, lane, extra);
   if (lane == 0) {
     SV w = extra(0, ldsv(W[0]));
