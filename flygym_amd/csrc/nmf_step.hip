@@ -135,10 +135,12 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float vA[TP::NV], vB[TP::NV], vC[TP::NV], vD[TP::NV];
   float ctrl[TP::kCtrl];
   float S[TP::NV][row_width_s<TP>()];
-  float Ib[TP::NB][10];                 // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap)
+  // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap).  Rows are 11
+  // floats apart where LDS allows: lane = body loops then hit 32 different banks (stride 10: bodies b and b + 16 collide)
+  float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
   float Isym[kHasIsym<TP> ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
-  static_assert(6 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
+  static_assert(7 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
   __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
   __device__ __forceinline__ const float (*xmat() const)[9] { return reinterpret_cast<const float(*)[9]>(&xmat_root[0]); }
   __device__ __forceinline__ float (*xpos())[3] { return reinterpret_cast<float(*)[3]>(&xpos_root[0]); }
@@ -149,7 +151,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
   float xpos_root[3];
-  float c_w[kMaxCon][6];
+  float c_w[kMaxCon][7];     // contact wrenches (6 used; odd stride: lane = contact stores hit 32 different banks)
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
   // star kernels: the 3x3 pyramid-coefficient matrix of every contact for its active rows (nn, n1, n2, 11, 22), written
   // with the active-row mask; the hybrid kernels have no LDS to spare and rebuild it from the mask
@@ -413,7 +415,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   // first contact slot of every geom (up to 128 ints): behind the scratch in T..W where that is large enough, else behind
   // the body positions in the contact-wrench buffer (both dead until the solver starts)
   constexpr bool kSlotInTW = sizeof(CollisionScratch) + 2 * kWave * sizeof(int) <= sizeof(float) * TP::NB * 12;
-  static_assert(kSlotInTW || 3 * (TP::NB - 1) + 2 * kWave <= 6 * kMaxCon, "slot table (128 geoms) does not fit");
+  static_assert(kSlotInTW || 3 * (TP::NB - 1) + 2 * kWave <= 7 * kMaxCon, "slot table (128 geoms) does not fit");
   int* geom_slot0 = kSlotInTW ? reinterpret_cast<int*>(&s.T[0][0]) + sizeof(CollisionScratch) / sizeof(int)
                               : reinterpret_cast<int*>(&s.c_w[0][0]) + 3 * (TP::NB - 1);
   const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
