@@ -265,10 +265,10 @@ def main():
         src = rng.uniform(-20, 20, (3, 3)); src[:, 2] = rng.uniform(0.5, 3.0, 3)
         odor = OdorSensors(sim, fly.name, src, rng.uniform(0.1, 1.0, (3, 2)))
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
-    replay = ReplayTargetData(sim.timestep, order)
     if args.workload == "replay":
         table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
-        table = torch.as_tensor(replay.make_target_angles_all_worlds(n_local, table_steps, first_world=first_world), device=sim.device)
+        replay = ReplayTargetData(sim.timestep, order, device=sim.device)      # smoothed + resampled on the GPU
+        table = replay.make_target_angles_all_worlds(n_local, table_steps, first_world=first_world)
     else:
         from flygym_amd.controllers import TripodCPG
 

@@ -33,7 +33,7 @@ class NativeError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h",
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_replay.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h",
             INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
     if os.environ.get("NMF_HIP_LIB"):
         return LIB_PATH                       # an externally built variant: nothing to compile here
@@ -91,6 +91,7 @@ def lib():
             "nmf_eye_params_size": (ctypes.c_size_t, []),
             "nmf_eye_render": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
             "nmf_odor_intensity": (ci, [vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
+            "nmf_replay_resample": (ci, [vp, ci, ci, ctypes.c_double, ctypes.c_double, vp, ci, ci, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

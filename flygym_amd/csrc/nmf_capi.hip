@@ -17,6 +17,7 @@
 #include "nmf_step.hip"
 #include "nmf_sensors.hip"
 #include "nmf_eyes.hip"
+#include "nmf_replay.hip"
 
 namespace {
 
@@ -626,6 +627,18 @@ extern "C" int nmf_odor_intensity(nmf_batch* b, const int32_t* sensor_seg_dev, c
   hipLaunchKernelGGL(nmf::nmf_odor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      b->st.seg_xpos, b->st.seg_xquat, b->model->nseg, sensor_seg_dev, sensor_rel_dev, n_sensors,
                      source_pos_dev, source_peak_dev, n_sources, n_dims, out_dev, b->n_worlds);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nmf_replay_resample(const float* clip_dev, int n_frames, int n_cols, double fps, double out_dt,
+                                   const double* sg_taps_dev, int window, int n_out, float* out_dev, void* stream) {
+  if (!clip_dev || !sg_taps_dev || !out_dev) return fail("nmf_replay_resample: null buffer");
+  if (n_frames < 6 || n_frames > nmf::kReplayMaxFrames) return fail("nmf_replay_resample: need 6 <= n_frames <= 1536");
+  if (window < 3 || !(window & 1) || window > n_frames) return fail("nmf_replay_resample: the filter window must be odd, >= 3 and <= n_frames");
+  if (n_cols <= 0 || n_out <= 0 || !(fps > 0.0) || !(out_dt > 0.0)) return fail("nmf_replay_resample: bad sizes / rates");
+  hipLaunchKernelGGL(nmf::nmf_replay_resample_kernel, dim3((unsigned)n_cols), dim3(nmf::kReplayThreads), 0, (hipStream_t)stream,
+                     clip_dev, n_frames, n_cols, fps, out_dt, sg_taps_dev, window, n_out, out_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }

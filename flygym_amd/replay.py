@@ -11,7 +11,29 @@ import numpy as np
 
 from .anatomy import JointDOF
 
-__all__ = ["MotionSnippet", "ReplayTargetData"]
+__all__ = ["MotionSnippet", "ReplayTargetData", "savgol_taps"]
+
+
+def savgol_taps(window: int, polyorder: int) -> np.ndarray:
+    """Constants of ``scipy.signal.savgol_filter(mode="interp")`` as one float64 vector (the layout
+    ``nmf_replay_resample`` takes): ``window`` interior taps, then ``window // 2`` rows of ``window`` taps for the first
+    frames (value at frame ``i`` of the polynomial fitted to the first window), then as many rows for the last frames.
+    Plain least squares: the tap for sample ``k`` when evaluating at offset ``x0`` is ``A (A^T A)^-1 x0^p``."""
+    half = window // 2
+    x = np.arange(-half, half + 1, dtype=np.float64)
+    A = np.vander(x, polyorder + 1, increasing=True)
+    pinv = A @ np.linalg.inv(A.T @ A)                       # (window, polyorder + 1)
+
+    def at(x0):
+        return pinv @ (float(x0) ** np.arange(polyorder + 1))
+
+    # interior taps exactly as scipy.signal.savgol_coeffs obtains them (a minimum-norm least-squares solve of the moment
+    # conditions, LAPACK gelsd): the same float64 values to the last bit, hence the same float32 smoothed frames
+    order = np.arange(polyorder + 1).reshape(-1, 1)
+    unit = np.zeros(polyorder + 1); unit[0] = 1.0
+    mid = np.linalg.lstsq(x[::-1] ** order, unit, rcond=None)[0]
+    rows = [mid] + [at(i - half) for i in range(half)] + [at(p + 1) for p in range(half)]
+    return np.concatenate(rows)
 
 
 class MotionSnippet:
@@ -67,17 +89,57 @@ class MotionSnippet:
         legs, dofs = np.array(cols, dtype=np.int64).T
         return dense[:, legs, dofs]
 
+    def get_joint_angles_device(self, output_timestep: float, output_dof_order: list[JointDOF], device, *,
+                                sgfilter_window_sec: float = 0.03, sgfilter_polyorder: int = 3):
+        """The same table computed on the GPU (``nmf_replay_resample``: Savitzky-Golay + not-a-knot cubic spline in
+        float64, one workgroup per column): float32 torch tensor ``(n_output_steps, len(output_dof_order))`` on
+        ``device``.  Only the clip (660 x 42 floats) and the filter constants cross PCIe."""
+        import torch
+
+        from . import _native
+
+        window = int(sgfilter_window_sec * self.data_fps)
+        window += 1 - (window % 2)
+        cols = [
+            (self.legs.index(d.child.pos), self.dofs_per_leg.index((d.parent.link, d.child.link, d.axis.value)))
+            for d in output_dof_order
+        ]
+        legs, dofs = np.array(cols, dtype=np.int64).T
+        n = self.joint_angles.shape[0]
+        clip = torch.as_tensor(np.ascontiguousarray(self.joint_angles[:, legs, dofs], dtype=np.float32), device=device)
+        taps = torch.as_tensor(savgol_taps(window, sgfilter_polyorder), device=device)
+        n_out = len(np.arange(0, n / self.data_fps, output_timestep))
+        out = torch.empty((n_out, len(cols)), dtype=torch.float32, device=device)
+        with torch.cuda.device(clip.device):
+            stream = torch.cuda.current_stream(clip.device).cuda_stream
+            _native.check(_native.lib().nmf_replay_resample(clip.data_ptr(), n, len(cols), float(self.data_fps),
+                                                            float(output_timestep), taps.data_ptr(), window, n_out,
+                                                            out.data_ptr(), stream))
+        return out
+
 
 class ReplayTargetData:
     """World ``w`` replays clip partition ``w % n_partitions`` (benchmark :73-86)."""
 
-    def __init__(self, sim_timestep: float, output_dof_order: list[JointDOF]):
+    def __init__(self, sim_timestep: float, output_dof_order: list[JointDOF], device=None):
+        """``device``: build the table on that GPU (``MotionSnippet.get_joint_angles_device``) instead of with scipy
+        on the host; ``make_target_angles_all_worlds`` then returns a device tensor."""
         self.snippet = MotionSnippet()
-        self.dof_angles = self.snippet.get_joint_angles(sim_timestep, output_dof_order)
+        self.device = device
+        if device is None:
+            self.dof_angles = self.snippet.get_joint_angles(sim_timestep, output_dof_order)
+        else:
+            self.dof_angles = self.snippet.get_joint_angles_device(sim_timestep, output_dof_order, device)
         self.n_total_steps, self.n_dofs = self.dof_angles.shape
 
     def make_target_angles_all_worlds(self, n_worlds: int, sim_steps: int, first_world: int = 0) -> np.ndarray:
         n_partitions = self.n_total_steps // sim_steps
+        if self.device is not None:
+            import torch
+
+            part = (first_world + torch.arange(n_worlds, device=self.dof_angles.device)) % n_partitions
+            idx = part[:, None] * sim_steps + torch.arange(sim_steps, device=self.dof_angles.device)[None, :]
+            return self.dof_angles[idx].contiguous()
         part = (first_world + np.arange(n_worlds)) % n_partitions
         idx = part[:, None] * sim_steps + np.arange(sim_steps)[None, :]
         return np.ascontiguousarray(self.dof_angles[idx].astype(np.float32))

@@ -158,6 +158,17 @@ int nmf_odor_intensity(nmf_batch* batch, const int32_t* sensor_seg_dev, const fl
                        const float* source_pos_dev, const float* source_peak_dev, int n_sources, int n_dims,
                        float* out_dev, void* stream);
 
+/* Kinematic-replay data path on the device.  Replaces MotionSnippet.get_joint_angles (reference
+ * src/flygym_demo/spotlight_data/preprocessing.py:80-142: scipy savgol_filter + interp1d(kind="cubic") on the host):
+ * Savitzky-Golay smoothing of the recorded joint angles, the not-a-knot cubic spline through the smoothed frames, its
+ * values at t = k * out_dt (k < n_out; the last frame's value beyond the last knot), in float64, stored as float32.
+ * clip_dev[n_frames][n_cols] float32; out_dev[n_out][n_cols] float32;
+ * sg_taps_dev (float64, device): window interior taps, then window/2 rows of `window` taps for the first window/2 frames
+ * (polynomial fit over the first window), then window/2 rows for the last window/2 frames — the constants of
+ * savgol_filter(mode="interp"), computed by the caller (flygym_amd.replay.savgol_taps). */
+int nmf_replay_resample(const float* clip_dev, int n_frames, int n_cols, double fps, double out_dt,
+                        const double* sg_taps_dev, int window, int n_out, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -444,3 +444,31 @@ def test_chunked_launches_are_bitwise_the_plain_ones(torch_mod, bench_model, mon
         assert torch.equal(graphed[k], plain[k]), f"graph replay of a chunked launch differs in {k}"
     assert float(plain["stats_sum"][:, 0].min()) == 500 + 350 + 20 + 9 + 120
     assert float(plain["time"].min()) == pytest.approx(0.0999, rel=1e-3)
+
+
+def test_replay_table_resampled_on_the_device(torch_mod, bench_model):
+    """MotionSnippet's Savitzky-Golay + cubic resample on the GPU (nmf_replay_resample) against the
+    reference pipeline's table (scipy on the host; tests/golden/replay_42.npz pins it to the reference): float32 values
+    bit-identical but for a few that are one ulp off, and the per-world tables built from it on the device equal the
+    host-built ones."""
+    torch = torch_mod
+    from pathlib import Path
+    from flygym_amd.replay import MotionSnippet, ReplayTargetData
+
+    fly, _, _ = bench_model
+    order = fly.get_actuated_jointdofs_order("position")
+    ms = MotionSnippet()
+    dev = ms.get_joint_angles_device(1e-4, order, "cuda:0")
+    host = ms.get_joint_angles(1e-4, order).astype(np.float32)
+    got = dev.cpu().numpy()
+    assert got.shape == host.shape == (20000, 42) and got.dtype == np.float32
+    neq = got.view(np.uint32) != host.view(np.uint32)
+    assert neq.mean() < 1e-3, f"{int(neq.sum())} of {neq.size} values differ"
+    assert np.abs(got - host).max() <= 2.4e-7
+    gold = np.load(Path(__file__).parent / "golden" / "replay_42.npz")
+    assert (got[:2000].view(np.uint32) == gold["head"].view(np.uint32)).mean() > 0.999
+    a = ReplayTargetData(1e-4, order, device="cuda:0").make_target_angles_all_worlds(45, 1000, first_world=3)
+    b = ReplayTargetData(1e-4, order).make_target_angles_all_worlds(45, 1000, first_world=3)
+    assert tuple(a.shape) == (45, 1000, 42) and a.dtype == torch.float32 and a.is_contiguous()
+    assert np.abs(a.cpu().numpy() - b).max() <= 2.4e-7
+    assert torch.equal(a[20], a[0]) and not torch.equal(a[1], a[0])          # world w <- partition w % 20
