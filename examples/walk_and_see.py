@@ -41,7 +41,7 @@ table = cpg.targets(n, 2500, device=sim.device, adhesion=(stance, 20.0, 1.0))   
 ids = sim.replay_ids(fly.name, with_adhesion=True)
 odor = OdorSensors(sim, fly.name, source_positions=[(15, 0, 1.5), (-5, 12, 1.5), (4, -9, 1.5)],
                    peak_intensities=[(1.0, 0.0), (0.0, 1.0), (0.5, 0.5)])
-eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(10.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]))
+eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(10.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]))  # sees the ground, the sphere and its own legs
 x0 = sim.get_body_positions(fly.name)[:, 0, 0].clone()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()

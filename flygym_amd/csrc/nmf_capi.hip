@@ -570,7 +570,8 @@ extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_
 
 extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 
-extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int16_t* id_map_dev,
+extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int32_t* capsule_seg_dev,
+                              const float* capsule_geom_dev, const int16_t* id_map_dev,
                               const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
                               uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {
   if (!b || !p) return fail("nmf_eye_render: null batch / params");
@@ -579,6 +580,8 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   if (p->height <= 0 || p->width <= 0 || (p->height * p->width) % 16) return fail("nmf_eye_render: height * width must be a positive multiple of 16");
   if (n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia) return fail("nmf_eye_render: need 0 < n_ommatidia <= 1024");
   if (p->n_spheres < 0 || p->n_spheres > nmf::kMaxSpheres || (p->n_spheres > 0 && !spheres_dev)) return fail("nmf_eye_render: bad sphere list");
+  if (p->n_capsules < 0 || p->n_capsules > nmf::kMaxCaps || (p->n_capsules > 0 && (!capsule_seg_dev || !capsule_geom_dev)))
+    return fail("nmf_eye_render: bad body-capsule list (at most 64)");
   if (!(p->checker_size > 0.f) || !(p->fov_deg > 0.f) || p->fov_deg > 360.f) return fail("nmf_eye_render: bad checker size / field of view");
   const nmf_model* m = b->model;
   HIP_OK(hipSetDevice(b->device));
@@ -603,13 +606,17 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   }
   A.checker_size = p->checker_size; A.ground_z = b->dm.plane[3];
   A.n_spheres = p->n_spheres; A.sphere_stride = p->spheres_per_world ? 4 * p->n_spheres : 0;
+  A.n_caps = p->n_capsules;
+  A.terrain_kind = p->terrain_relief ? b->dm.terrain_type : 0;          // the relief the physics of this batch collides with
+  for (int k = 0; k < 5; ++k) A.terrain[k] = b->dm.terrain[k];
   for (int c = 0; c < 4; ++c) {
     A.rgb[0][c] = c < 3 ? p->sky_rgb[c] : 0; A.rgb[1][c] = c < 3 ? p->ground_rgb[0][c] : 0; A.rgb[2][c] = c < 3 ? p->ground_rgb[1][c] : 0;
-    for (int s = 0; s < nmf::kMaxSpheres; ++s) A.rgb[3 + s][c] = c < 3 ? p->sphere_rgb[s][c] : 0;
+    A.rgb[3][c] = c < 3 ? p->wall_rgb[c] : 0; A.rgb[4][c] = c < 3 ? p->body_rgb[c] : 0;
+    for (int s = 0; s < nmf::kMaxSpheres; ++s) A.rgb[5 + s][c] = c < 3 ? p->sphere_rgb[s][c] : 0;
   }
   hipLaunchKernelGGL(nmf::nmf_eye_kernel, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A,
                      b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,
-                     reinterpret_cast<const nmf::u32x4*>(plan_dev),
+                     capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),
                      reinterpret_cast<const int*>(static_cast<const char*>(plan_dev) + (size_t)(p->height * p->width / 16) * 16),
                      id_map_dev, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev);
   HIP_OK(hipGetLastError());

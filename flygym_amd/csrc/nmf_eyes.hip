@@ -6,9 +6,12 @@
 //  and pinned by the numpy oracle oracle/sensors_oracle.py::render_eye_frames.
 //
 // One workgroup per (world, eye).  A lane owns 16 consecutive raw pixels (the resample's chunk, same run plan):
-// per pixel it builds the equidistant-fisheye ray, rotates it into the world, intersects the ground plane (checker
-// texture) and the spheres, takes the green or blue byte of the hit material and adds it to the chunk's run sums;
-// three integer LDS atomics per chunk.  The 1.4 MB raw frame per fly never exists unless the caller asks for it
+// per pixel it builds the equidistant-fisheye ray, rotates it into the world, intersects the ground — the flat plane
+// (checker texture) or, on the build-defined terrains, the relief the physics collides with (constant-height cells of
+// h(x, y) followed cell by cell, side walls included) — the spheres and the fly's own body (the visible segments as
+// capsules, reference scene: warp/rendering.py:385-441 renders the whole model; flygym 1.x hid the segments around the
+// eyes, legacy/flygym1_config.yaml:147-161), takes the green or blue byte of the nearest hit's material and adds it to
+// the chunk's run sums; three integer LDS atomics per chunk.  The 1.4 MB raw frame per fly never exists unless the caller asks for it
 // (frames_out, for inspection and for the parity tests): compute-bound instead of HBM-bound.
 #include "nmf_device.h"
 
@@ -16,6 +19,9 @@ namespace nmf {
 
 constexpr int kEyeThreads = 512;
 constexpr int kMaxSpheres = 8;
+constexpr int kMaxCaps = 64;            // capsules of the fly's own body an eye can see
+constexpr int kMaxTerrainCells = 64;    // cells a ray is followed through the relief before the far field is taken as flat
+constexpr float kTerrainEps = 1e-4f;    // the cell a ray is in at parameter t holds its point at t + eps (mm)
 
 struct EyeArgs {
   int height, width;
@@ -25,8 +31,40 @@ struct EyeArgs {
   float rel_mat[2][9];     // camera axes in the parent segment frame (columns: right, up, back)
   float checker_size, ground_z;
   int n_spheres, sphere_stride;      // floats between consecutive worlds in `spheres` (0: shared by all worlds)
-  unsigned char rgb[3 + kMaxSpheres][4];   // materials: 0 sky, 1 ground A, 2 ground B, 3.. spheres
+  int terrain_kind;                  // 0 flat plane, 1 gapped, 2 blocks, 3 mixed (flygym_amd/compose/world.py)
+  float terrain[5];                  // its parameters + highest level
+  int n_caps;                        // body capsules (cap_seg / cap_geom)
+  unsigned char rgb[5 + kMaxSpheres][4];   // materials: 0 sky, 1 ground A, 2 ground B, 3 terrain side wall, 4 own body, 5.. spheres
 };
+
+// constant-height cell of h(x, y) that holds (x, y): bounds (+-inf where unbounded) and level — the same arithmetic as
+// the physics' terrain_height (nmf_step.hip) and as oracle/sensors_oracle.py::terrain_cell
+struct TerrainCell { float x0, x1, y0, y1, h; };
+__device__ __forceinline__ TerrainCell cell_gapped(float block, float gap, float depth, float x) {
+  const float period = block + gap;
+  const float base = floorf(x / period) * period;
+  const bool on = x - base < block;
+  return TerrainCell{on ? base : base + block, on ? base + block : base + period, -INFINITY, INFINITY, on ? 0.f : -depth};
+}
+__device__ __forceinline__ TerrainCell cell_blocks(float size, float height, float x, float y) {
+  const float i = floorf(x / size), j = floorf(y / size);
+  const float sum = i + j;
+  const float par = sum - 2.f * floorf(sum / 2.f);
+  return TerrainCell{i * size, (i + 1.f) * size, j * size, (j + 1.f) * size, par != 0.f ? height : 0.f};
+}
+__device__ __forceinline__ TerrainCell terrain_cell(int kind, const float* p, float x, float y) {
+  if (kind == 1) return cell_gapped(p[0], p[1], p[2], x);
+  if (kind == 2) return cell_blocks(p[0], p[1], x, y);
+  if (kind == 3) {
+    const float st = floorf(x / p[3]);
+    const float k = st - 3.f * floorf(st / 3.f);
+    const float s0 = st * p[3], s1 = (st + 1.f) * p[3];
+    if (k == 1.f) { TerrainCell c = cell_gapped(1.0f, p[1], p[2], x); c.x0 = fmaxf(c.x0, s0); c.x1 = fminf(c.x1, s1); return c; }
+    if (k == 2.f) { TerrainCell c = cell_blocks(p[0], 0.35f, x, y); c.x0 = fmaxf(c.x0, s0); c.x1 = fminf(c.x1, s1); return c; }
+    return TerrainCell{s0, s1, -INFINITY, INFINITY, 0.f};
+  }
+  return TerrainCell{-INFINITY, INFINITY, -INFINITY, INFINITY, 0.f};
+}
 
 // camera-frame ray of a raw pixel (equidistant fisheye).  (A per-pixel ray table shared by all worlds was tried: 16 B
 // per ray through L2 is slower than recomputing the lens model, 5.5 vs 2.4 ms per 8192 eye views.)
@@ -41,17 +79,22 @@ __device__ __forceinline__ V3 eye_ray(int row, int col, float cx, float cy, floa
 
 __global__ void __launch_bounds__(kEyeThreads)
 nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __restrict__ seg_xquat, int nseg,
-               const float* __restrict__ spheres, const u32x4* __restrict__ plan, const int* __restrict__ active,
+               const float* __restrict__ spheres, const int* __restrict__ cap_seg, const float* __restrict__ cap_geom,
+               const u32x4* __restrict__ plan, const int* __restrict__ active,
                const int16_t* __restrict__ id_map,
                const uint8_t* __restrict__ pale, const float* __restrict__ inv_norm, int n_omm,
                uint8_t* __restrict__ frames_out, float* __restrict__ omm_out) {
   __shared__ unsigned int acc[kMaxOmmatidia];
   __shared__ float sph[kMaxSpheres][4];
-  __shared__ unsigned int mats[4 + kMaxSpheres];        // [0] black (outside the fisheye), [1 + m] material m
+  __shared__ unsigned int mats[6 + kMaxSpheres];        // [0] black (outside the fisheye), [1 + m] material m
+  // body capsules relative to the camera, world axes: 0-2 pa, 3-5 ba = pb - pa, 6 ba.ba, 7 -ba.pa, 8 quadratic's constant,
+  // 9-11 pb, 12 pa.pa - r^2, 13 pb.pb - r^2, 14-16 unit direction to the bounding sphere's centre, 17 / 18 cos / sin of its
+  // angular radius (+ margin)
+  __shared__ float capd[kMaxCaps][20];
   const int w = blockIdx.x >> 1, eye = blockIdx.x & 1;
   for (int i = threadIdx.x; i < n_omm; i += kEyeThreads) acc[i] = 0u;
   if (threadIdx.x < A.n_spheres * 4) (&sph[0][0])[threadIdx.x] = spheres[(size_t)w * A.sphere_stride + threadIdx.x];
-  if (threadIdx.x < 4 + kMaxSpheres)
+  if (threadIdx.x < 6 + kMaxSpheres)
     mats[threadIdx.x] = threadIdx.x == 0 ? 0u : *reinterpret_cast<const unsigned int*>(A.rgb[threadIdx.x - 1]);
   __syncthreads();
   // camera pose (uniform over the workgroup)
@@ -78,6 +121,27 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   }
   __syncthreads();
   if (threadIdx.x < A.n_spheres) { float* q = sph[threadIdx.x]; q[0] = oc.x; q[1] = oc.y; q[2] = oc.z; q[3] = cc; }
+  if (threadIdx.x < A.n_caps) {
+    const int c = threadIdx.x, cs = cap_seg[c];
+    const float* g = cap_geom + 7 * c;
+    float Rc[9];
+    qmat(Rc, ldq(seg_xquat + ((size_t)w * nseg + cs) * 4));
+    const V3 xp = ld3(seg_xpos + ((size_t)w * nseg + cs) * 3);
+    const V3 pa = (xp + mat_vec(Rc, ld3(g))) - cam, pb = (xp + mat_vec(Rc, ld3(g + 3))) - cam;
+    const float r = g[6];
+    const V3 ba = pb - pa;
+    const float baba = dot(ba, ba), baoa = -dot(ba, pa), oaoa = dot(pa, pa);
+    float* q = capd[c];
+    q[0] = pa.x; q[1] = pa.y; q[2] = pa.z; q[3] = ba.x; q[4] = ba.y; q[5] = ba.z; q[6] = baba; q[7] = baoa;
+    q[8] = baba * oaoa - baoa * baoa - r * r * baba;
+    q[9] = pb.x; q[10] = pb.y; q[11] = pb.z; q[12] = oaoa - r * r; q[13] = dot(pb, pb) - r * r;
+    const V3 mid = 0.5f * (pa + pb);
+    const float dist = sqrtf(dot(mid, mid)), Rb = 0.5f * sqrtf(baba) + r;
+    const float inv = dist > 1e-6f ? 1.0f / dist : 0.f;
+    q[14] = mid.x * inv; q[15] = mid.y * inv; q[16] = mid.z * inv;
+    const float ang = dist > Rb ? asinf(Rb / dist) + 0.03f : 3.2f;       // camera inside the bound: always a candidate
+    q[17] = ang < 3.1f ? cosf(ang) : -2.f; q[18] = ang < 3.1f ? sinf(ang) : 0.f; q[19] = 0.f;
+  }
   __syncthreads();
   uint8_t* fout = frames_out ? frames_out + (size_t)blockIdx.x * n_pix * 3 : nullptr;
   // readings only: visit just the chunks that touch an ommatidium (43 % of the frame lies outside the lattice)
@@ -89,6 +153,26 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     int row = (ch * 16) / A.width, col = ch * 16 - row * A.width;
     unsigned int tot = 0u, sA = 0u, sAB = 0u;
     unsigned int obytes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // body capsules this chunk can see: the chunk's 16 rays lie in a cone about the mean of its first and last ray (a
+    // chunk that wraps to the next image row takes every capsule)
+    unsigned long long cand = 0ull;
+    if (A.n_caps > 0) {
+      const int row_l = (ch * 16 + 15) / A.width, col_l = ch * 16 + 15 - row_l * A.width;
+      float th0, th1;
+      const V3 c0 = eye_ray(row, col, cx, cy, inv_half_h, A.half_fov, th0), c1 = eye_ray(row_l, col_l, cx, cy, inv_half_h, A.half_fov, th1);
+      V3 cm = c0 + c1;
+      const float cl = __builtin_amdgcn_rsqf(fmaxf(dot(cm, cm), 1e-12f));
+      cm = cl * cm;
+      const V3 cw = v3(R[0] * cm.x + R[1] * cm.y + R[2] * cm.z, R[3] * cm.x + R[4] * cm.y + R[5] * cm.z, R[6] * cm.x + R[7] * cm.y + R[8] * cm.z);
+      const float ch_cos = fminf(dot(cm, c0), 1.f), ch_sin = sqrtf(fmaxf(1.f - ch_cos * ch_cos, 0.f));
+      const bool wrapped = row_l != row;
+      for (int c = 0; c < A.n_caps; ++c) {
+        const float* q = capd[c];
+        const float ca = q[14] * cw.x + q[15] * cw.y + q[16] * cw.z;      // cos of the angle between the cone axis and the capsule
+        const float lim = ch_cos * q[17] - ch_sin * q[18];               // cos(chunk half-angle + capsule angular radius)
+        if (wrapped || q[17] < -1.5f || ca >= lim || ch_cos * q[17] < ch_sin * q[18]) cand |= 1ull << c;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       float theta;
@@ -102,13 +186,58 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       const int par = ((int)floorf(ghit ? gx : 0.f) + (int)floorf(ghit ? gy : 0.f)) & 1;
       int mat = ghit ? 1 + par : 0;
       float tbest = ghit ? t : INFINITY;
+      if (A.terrain_kind != 0 && d.z < 0.f) {
+        // relief: follow the ray through the cells of h(x, y) from the highest level down; a cell entered below its level
+        // is a side wall, else its top is hit if the ray reaches the level before leaving the cell
+        const float rdz = 1.0f / d.z;
+        float tc = fmaxf(0.f, (A.ground_z + A.terrain[4] - cam.z) * rdz);
+#pragma unroll 1
+        for (int it = 0; it < kMaxTerrainCells; ++it) {
+          const float tp = tc + kTerrainEps;
+          const TerrainCell c = terrain_cell(A.terrain_kind, A.terrain, cam.x + tp * d.x, cam.y + tp * d.y);
+          const float h = c.h + A.ground_z;
+          const float z_in = cam.z + tc * d.z;
+          if (z_in < h) { tbest = tc; mat = 3; break; }
+          const float tx = d.x > 0.f ? (c.x1 - cam.x) / d.x : (d.x < 0.f ? (c.x0 - cam.x) / d.x : INFINITY);
+          const float ty = d.y > 0.f ? (c.y1 - cam.y) / d.y : (d.y < 0.f ? (c.y0 - cam.y) / d.y : INFINITY);
+          const float t_out = fminf(tx, ty);
+          const float t_h = (h - cam.z) * rdz;
+          if (t_h <= t_out) {
+            const float qx = (cam.x + t_h * d.x) * inv_cs, qy = (cam.y + t_h * d.y) * inv_cs;
+            tbest = t_h; mat = 1 + (((int)floorf(qx) + (int)floorf(qy)) & 1);
+            break;
+          }
+          tc = t_out;
+        }
+      }
 #pragma unroll 1
       for (int s = 0; s < A.n_spheres; ++s) {
         const float b = sph[s][0] * d.x + sph[s][1] * d.y + sph[s][2] * d.z;
         const float disc = b * b - sph[s][3];
         const float ts = -b - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
         const bool ok = disc > 0.f && ts > 0.f && ts < tbest;
-        tbest = ok ? ts : tbest; mat = ok ? 3 + s : mat;
+        tbest = ok ? ts : tbest; mat = ok ? 5 + s : mat;
+      }
+      for (unsigned long long cm = cand; cm; cm &= cm - 1ull) {
+        const float* q = capd[__ffsll((long long)cm) - 1];
+        const float bard = q[3] * d.x + q[4] * d.y + q[5] * d.z;
+        const float rdoa = -(q[0] * d.x + q[1] * d.y + q[2] * d.z);
+        const float a = q[6] - bard * bard;
+        const float b = q[6] * rdoa - q[7] * bard;
+        const float hq = b * b - a * q[8];
+        const float tb = (-b - sqrtf(fmaxf(hq, 0.f))) / a;
+        const float yy = q[7] + tb * bard;
+        const bool cyl = hq >= 0.f && a > 1e-12f;
+        float tcap = INFINITY;
+        if (cyl && yy > 0.f && yy < q[6] && tb > 0.f) tcap = tb;
+        else {
+          const bool use_a = !(yy > 0.f) || !cyl;
+          const float bb = use_a ? rdoa : -(q[9] * d.x + q[10] * d.y + q[11] * d.z);
+          const float hh = bb * bb - (use_a ? q[12] : q[13]);
+          const float te = -bb - sqrtf(fmaxf(hh, 0.f));
+          if (hh > 0.f && te > 0.f) tcap = te;
+        }
+        if (tcap < tbest) { tbest = tcap; mat = 4; }
       }
       mat = theta > 3.14159265f ? -1 : mat;                                  // behind the fisheye's full sphere: black
       const unsigned int rgbw = mats[mat + 1];

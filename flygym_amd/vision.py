@@ -11,8 +11,13 @@ turned the two eye-camera images into ommatidia readings; this snapshot keeps on
 * the lens is an equidistant fisheye: a pixel's ray makes the angle ``rho * fov / 2`` with the optical axis, ``rho``
   = distance from the image centre in units of half the image height, ``fov`` = 157 degrees (``fovy_per_eye``); the
   legacy pinhole + distortion-coefficient pipeline is not reproduced;
-* the scene is the world's ground plane with the reference's checker texture (4 mm squares of grey 0.3 / 0.4,
-  ``compose/world.py:234-248``), a uniform sky and up to 8 opaque spheres (visual objects), unlit flat colours;
+* the scene is the world's ground with the reference's checker texture (4 mm squares of grey 0.3 / 0.4,
+  ``compose/world.py:234-248``) — the flat plane, or on the gapped / blocks / mixed worlds the very height map the
+  physics collides with, side walls included (``Scene.terrain_relief``) — a uniform sky, up to 8 opaque spheres (visual
+  objects) and the fly's own body: every segment flygym 1.x did not hide from the eye cameras
+  (``legacy/flygym1_config.yaml:147-161`` hides the head, the antennae, the front coxae, the thorax) as the capsule
+  fitted to its mesh (``body_capsules``; the reference's batch renderer sees the whole model,
+  ``warp/rendering.py:385-441``); unlit flat colours;
 * a raw frame has one ray per pixel, colours rounded to uint8; the ommatidia readings are ``Retina``'s resample of
   that frame — computed in the same kernel, so the 2 x 691 KB of raw frames per fly never touch HBM unless
   ``render_frames`` is called.
@@ -37,7 +42,35 @@ class _EyeParams(ctypes.Structure):
         ("checker_size", ctypes.c_float),
         ("sky_rgb", ctypes.c_uint8 * 4), ("ground_rgb", (ctypes.c_uint8 * 4) * 2), ("sphere_rgb", (ctypes.c_uint8 * 4) * 8),
         ("n_spheres", ctypes.c_int32), ("spheres_per_world", ctypes.c_int32),
+        ("wall_rgb", ctypes.c_uint8 * 4), ("body_rgb", ctypes.c_uint8 * 4),
+        ("n_capsules", ctypes.c_int32), ("terrain_relief", ctypes.c_int32),
     ]
+
+
+# segments flygym 1.x hid from the eye cameras (legacy/flygym1_config.yaml:147-161, in this build's segment names)
+HIDDEN_SEGMENTS = ("lf_coxa", "l_eye", "l_arista", "l_funiculus", "l_pedicel", "rf_coxa", "r_eye", "r_arista", "r_funiculus",
+                   "r_pedicel", "c_head", "c_rostrum", "c_haustellum", "c_thorax")
+
+
+def body_capsules(fly, hidden=HIDDEN_SEGMENTS):
+    """The fly's own body as the eyes see it: for every segment not in ``hidden`` the capsule fitted to its mesh (the
+    equivalent-inertia-box fit of the model compiler).  Returns ``(segment indices (K,), geometry (K, 7))``: end points
+    p0, p1 in the segment frame and the radius."""
+    from .compiler.mesh import capsule_from_inertia_box
+    from .compiler.model import load_asset_pack, mesh_for_segment
+
+    pack = load_asset_pack(fly.asset_pack_path)
+    names = [s.name for s in fly.get_bodysegs_order()]
+    seg, geom = [], []
+    for i, n in enumerate(names):
+        if n in hidden:
+            continue
+        md = mesh_for_segment(pack, n, fly.mesh_type.value, fly.mirror_left2right)
+        r, half = capsule_from_inertia_box(md)
+        axis = md.principal()[1][:, 2]
+        seg.append(i)
+        geom.append([*(md.com - half * axis), *(md.com + half * axis), r])
+    return np.asarray(seg, dtype=np.int32), np.asarray(geom, dtype=np.float32).reshape(-1, 7)
 
 
 def _euler_xyz_extrinsic_quat(e) -> np.ndarray:
@@ -61,10 +94,15 @@ class Scene:
     """What the eyes see: ground checker, sky colour, spheres ``(x, y, z, radius)`` with colours (floats in [0, 1])."""
 
     def __init__(self, checker_size: float = 4.0, ground_rgb=((0.3, 0.3, 0.3), (0.4, 0.4, 0.4)), sky_rgb=(0.55, 0.7, 0.9),
-                 spheres=(), sphere_rgb=()):
+                 spheres=(), sphere_rgb=(), wall_rgb=(0.2, 0.2, 0.2), body_rgb=(0.47, 0.35, 0.24), terrain_relief=True,
+                 own_body=True):
+        """``terrain_relief``: render the world's height map (gapped / blocks / mixed worlds) instead of a flat plane;
+        ``own_body``: render the fly's visible segments (``body_capsules``)."""
         self.checker_size = float(checker_size)
         self.ground_rgb = tuple(_u8(c) for c in ground_rgb)
         self.sky_rgb = _u8(sky_rgb)
+        self.wall_rgb, self.body_rgb = _u8(wall_rgb), _u8(body_rgb)
+        self.terrain_relief, self.own_body = bool(terrain_relief), bool(own_body)
         self.spheres = np.asarray(spheres, dtype=np.float32).reshape(-1, 4)
         self.sphere_rgb = tuple(_u8(c) for c in sphere_rgb)
         if len(self.spheres) != len(self.sphere_rgb) or len(self.spheres) > 8:
@@ -96,9 +134,17 @@ class EyeRenderer:
         for i in range(3):
             p.sky_rgb[i] = self.scene.sky_rgb[i]
             p.ground_rgb[0][i], p.ground_rgb[1][i] = self.scene.ground_rgb[0][i], self.scene.ground_rgb[1][i]
+            p.wall_rgb[i], p.body_rgb[i] = self.scene.wall_rgb[i], self.scene.body_rgb[i]
             for s, c in enumerate(self.scene.sphere_rgb):
                 p.sphere_rgb[s][i] = c[i]
         p.n_spheres, p.spheres_per_world = len(self.scene.spheres), 0
+        p.terrain_relief = int(self.scene.terrain_relief)
+        self.capsule_seg, self.capsule_geom = body_capsules(fly) if self.scene.own_body else (np.zeros(0, np.int32), np.zeros((0, 7), np.float32))
+        p.n_capsules = len(self.capsule_seg)
+        self._cap_seg = torch.as_tensor(self.capsule_seg, device=sim.device) if p.n_capsules else None
+        self._cap_geom = torch.as_tensor(self.capsule_geom, device=sim.device) if p.n_capsules else None
+        if ctypes.sizeof(_EyeParams) != _native.lib().nmf_eye_params_size():
+            raise _native.NativeError("nmf_eye_params layout mismatch between vision.py and libnmf_hip.so")
         self._params = p
         self._spheres = torch.as_tensor(self.scene.spheres, device=sim.device) if len(self.scene.spheres) else None
 
@@ -124,6 +170,8 @@ class EyeRenderer:
         _native.check(_native.lib().nmf_eye_render(
             self.sim._batch_h, ctypes.byref(self._params),
             self._spheres.data_ptr() if self._spheres is not None else None,
+            self._cap_seg.data_ptr() if self._cap_seg is not None else None,
+            self._cap_geom.data_ptr() if self._cap_geom is not None else None,
             id_map.data_ptr(), plan.data_ptr(), pale.data_ptr(), inv_norm.data_ptr(), self.retina.num_ommatidia,
             frames.data_ptr() if frames is not None else None, omm.data_ptr() if omm is not None else None, self.sim._stream()))
 

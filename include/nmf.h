@@ -126,8 +126,10 @@ int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_map_dev, co
 /* Compound-eye renderer fused with the ommatidia resample (no reference counterpart in this snapshot: the eye cameras,
  * like the resample, survive only as constants in src/flygym/assets/model/legacy/flygym1_config.yaml:141-173; the
  * reference's image path is rendering.py / warp/rendering.py -> MuJoCo / MJWarp renderers).  Build-defined (DESIGN.md
- * section 7): each eye is an equidistant-fisheye camera attached to a body segment; the scene is the ground plane with a
- * checker texture, a uniform sky and up to 8 spheres.  Reads the segment poses of the last nmf_step / nmf_reset. */
+ * section 7): each eye is an equidistant-fisheye camera attached to a body segment; the scene is the ground (checker
+ * plane, or the terrain relief of the batch's world), a uniform sky, up to 8 spheres and the fly's own body as up to 64
+ * capsules rigidly attached to segments (what reference warp/rendering.py:385-441 gives the batch renderer: the whole
+ * model).  Reads the segment poses of the last nmf_step / nmf_reset. */
 typedef struct nmf_eye_params {
   int32_t height, width;        /* raw frame size in pixels; height * width a multiple of 16                           */
   float fov_deg;                /* full angle seen along the vertical image axis (ray angle is proportional to radius)   */
@@ -138,6 +140,10 @@ typedef struct nmf_eye_params {
   uint8_t sky_rgb[4], ground_rgb[2][4], sphere_rgb[8][4];   /* colours (4th byte unused)                                */
   int32_t n_spheres;            /* 0..8                                                                                  */
   int32_t spheres_per_world;    /* 1: spheres_dev is [n_worlds][n_spheres][4]; 0: [n_spheres][4] shared by all worlds   */
+  uint8_t wall_rgb[4], body_rgb[4];   /* side walls of the terrain relief; the fly's own body                          */
+  int32_t n_capsules;           /* 0..64 capsules of the fly's own body (capsule_seg_dev / capsule_geom_dev)            */
+  int32_t terrain_relief;       /* 1: the ground is the height map the batch's physics collides with (gapped / blocks /
+                                   mixed worlds: constant-height cells with side walls); 0: the flat checker plane      */
 } nmf_eye_params;
 
 /* sizeof(nmf_eye_params) as this library was compiled: lets a foreign-language binding verify its struct layout. */
@@ -146,9 +152,11 @@ size_t nmf_eye_params_size(void);
 /* spheres_dev: (x, y, z, radius) per sphere, float32.  id_map / plan / pale / inv_norm as for nmf_retina_resample (the
  * plan is required).  frames_out_dev: NULL or uint8 [n_worlds][2][height*width][3] raw eye frames;
  * omm_out_dev: NULL or float32 [n_worlds][2][n_ommatidia][2].  Rendering frames and resampling them with
- * nmf_retina_resample gives bit-identical ommatidia readings (integer sums). */
+ * nmf_retina_resample gives bit-identical ommatidia readings (integer sums).
+ * capsule_seg_dev[n_capsules] int32 segment index, capsule_geom_dev[n_capsules][7] float32 (end points p0, p1 in the
+ * segment frame, radius) — NULL when n_capsules is 0. */
 int nmf_eye_render(nmf_batch* batch, const nmf_eye_params* params, const float* spheres_dev,
-                   const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev,
+                   const int32_t* capsule_seg_dev, const float* capsule_geom_dev, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev,
                    int n_ommatidia, uint8_t* frames_out_dev, float* omm_out_dev, void* stream);
 
 /* Odor intensity at n_sensors points rigidly attached to named segments (sensor_seg = index into the

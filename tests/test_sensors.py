@@ -140,6 +140,115 @@ def test_eye_render_oracle_known_answers():
     assert (L @ [0, 1, 0])[2] > 0.999 and (Rr @ [0, 1, 0])[2] > 0.999
 
 
+def _world_capsules(eyes, xpos_w, xquat_w):
+    import sensors_oracle as so
+
+    caps = []
+    for sg, g in zip(eyes.capsule_seg, eyes.capsule_geom.astype(np.float64)):
+        Rm = so.quat_to_mat(xquat_w[sg])
+        caps.append((xpos_w[sg] + Rm @ g[0:3], xpos_w[sg] + Rm @ g[3:6], g[6]))
+    return caps
+
+
+def test_eye_render_oracle_terrain_and_body_known_answers():
+    """The relief and body parts of the renderer's specification against geometry worked by hand."""
+    import sensors_oracle as so
+
+    H, W, fov = 512, 450, 157.0
+    sky, ground, wall, body = (140, 178, 230), ((77, 77, 77), (102, 102, 102)), (51, 51, 51), (120, 90, 60)
+    down = np.eye(3)
+    gapped = (1, (1.0, 0.3, 2.0, 0.0), 0.0)
+    # straight above the middle of a 1 mm block (x = 0.5): the centre pixels see its top, i.e. the flat answer
+    flat = so.render_eye_frames((0.5, 0.5, 2.0), down, H, W, fov, 4.0, 0.0, sky, ground)
+    fr = so.render_eye_frames((0.5, 0.5, 2.0), down, H, W, fov, 4.0, 0.0, sky, ground, terrain=gapped, wall_rgb=wall)
+    assert (fr[250:262, 219:231] == flat[250:262, 219:231]).all()
+    # straight above the middle of a gap (x = 1.15, 2 mm deep, 0.3 mm wide): the centre sees the gap floor (a top surface,
+    # checker colour), a ray that leaves the gap sideways before reaching the floor sees a wall
+    fr = so.render_eye_frames((1.15, 0.5, 2.0), down, H, W, fov, 4.0, 0.0, sky, ground, terrain=gapped, wall_rgb=wall)
+    assert tuple(fr[256, 225]) in ground
+    # along the middle row (varying x): the ray with tan(angle) = 0.15 / 4 just reaches the floor's edge; beyond it -> wall
+    ang_edge = np.arctan(0.15 / 4.0)
+    col_edge = W / 2 + ang_edge / np.radians(fov / 2) * H / 2
+    assert tuple(fr[256, int(col_edge) + 3]) == wall and tuple(fr[256, int(col_edge) - 3]) in ground
+    # walls are seen only on the relief
+    assert not (flat == wall).all(axis=-1).any() and (fr == wall).all(axis=-1).mean() > 0.05
+    # blocks: above the corner of four squares each quadrant of the centre shows tops at two different levels -> the raised
+    # squares look larger (closer): count of raised-top pixels > count of low-top pixels near the centre
+    blocks = (2, (1.3, 0.35, 0.0, 0.0), 0.35)
+    frb = so.render_eye_frames((1.3, 1.3, 2.0), down, H, W, fov, 100.0, 0.0, sky, ground, terrain=blocks, wall_rgb=wall)
+    assert (frb == wall).all(axis=-1).any()
+    # a capsule along x right below the camera: its silhouette is about (length + 2 r) x 2 r at distance 1
+    cap = [((0.2, 0.5, 1.0), (0.8, 0.5, 1.0), 0.1)]
+    frc = so.render_eye_frames((0.5, 0.5, 2.0), down, H, W, fov, 4.0, 0.0, sky, ground, capsules=cap, body_rgb=body)
+    mask = (frc == body).all(axis=-1)
+    px_per_rad = H / 2 / np.radians(fov / 2)
+    want = (2 * np.arctan(0.3 / 0.9)) * (2 * np.arcsin(0.1 / 1.0)) * px_per_rad ** 2
+    assert 0.75 * want < mask.sum() < 1.15 * want
+    rows, cols = np.where(mask)
+    assert abs(rows.mean() - 255.5) < 1.0 and abs(cols.mean() - 224.5) < 1.0 and np.ptp(cols) > 2.5 * np.ptp(rows)
+    # nearest hit wins: a capsule below the ground plane is hidden
+    hidden = so.render_eye_frames((0.5, 0.5, 2.0), down, H, W, fov, 4.0, 0.0, sky, ground, capsules=[((0.2, 0.5, -1.0), (0.8, 0.5, -1.0), 0.1)], body_rgb=body)
+    assert (hidden == flat).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_cls", ["FlatGroundWorld", "GappedTerrainWorld", "BlocksTerrainWorld", "MixedTerrainWorld"])
+def test_eye_renderer_sees_the_simulated_world(world_cls):
+    """the eyes see what is simulated — the terrain relief the physics collides with and the fly's own legs,
+    abdomen and wings — HIP frames vs the numpy specification, readings vs the resample of those frames."""
+    import torch
+    import sensors_oracle as so
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.utils.math import Rotation3D
+    from flygym_amd.vision import EyeRenderer, Scene
+
+    fly, world, _ = make_model()
+    if world_cls != "FlatGroundWorld":
+        world = getattr(C, world_cls)()
+        world.add_fly(fly, (0.4, 0.1, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    n = 2
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    sim.field("qvel")[:, :6] = torch.as_tensor(np.random.default_rng(7).normal(0, 15, (n, 6)), dtype=torch.float32, device=sim.device)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    sim.step(250)
+    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0)], sphere_rgb=[(0.9, 0.2, 0.1)])
+    eyes = EyeRenderer(sim, fly.name, scene)
+    assert len(eyes.capsule_seg) == 55
+    frames, omm = eyes.render_frames(with_readings=True)
+    assert torch.equal(omm, eyes.retina.raw_image_to_hex_pxls(frames)) and torch.equal(omm, eyes.render())
+    names = [s.name for s in fly.get_bodysegs_order()]
+    xpos = sim.field("seg_xpos").cpu().numpy().reshape(n, 69, 3).astype(np.float64)
+    xquat = sim.field("seg_xquat").cpu().numpy().reshape(n, 69, 4).astype(np.float64)
+    fr = frames.cpu().numpy()
+    terrain = None
+    if sim.model["terrain_type"][0] != 0:
+        tp = sim.model["terrain_params"]
+        terrain = (int(sim.model["terrain_type"][0]), tuple(float(v) for v in tp[:4]), float(tp[4]))
+    body_seen = wall_seen = 0
+    for w in range(n):
+        caps = _world_capsules(eyes, xpos[w], xquat[w])
+        for e, (seg, pos, quat) in enumerate(eyes.cameras):
+            Rs = so.quat_to_mat(xquat[w, names.index(seg)])
+            cam = xpos[w, names.index(seg)] + Rs @ pos
+            want = so.render_eye_frames(cam, Rs @ so.quat_to_mat(quat), 512, 450, 157.0, 4.0, 0.0, scene.sky_rgb, scene.ground_rgb,
+                                        scene.spheres, scene.sphere_rgb, terrain=terrain, wall_rgb=scene.wall_rgb,
+                                        capsules=caps, body_rgb=scene.body_rgb)
+            diff = (fr[w, e] != want).any(axis=-1).mean()
+            assert diff < 5e-3, f"{world_cls} world {w} eye {e}: {diff:.2e} of the pixels differ"
+            ref = so.retina_resample(want, eyes.retina.id_map, eyes.retina.pale_mask, eyes.retina.inv_norm)
+            assert np.abs(omm[w, e].cpu().numpy() - ref).max() < 1e-2
+            body_seen += int((want == np.array(scene.body_rgb, dtype=np.uint8)).all(axis=-1).sum())
+            wall_seen += int((want == np.array(scene.wall_rgb, dtype=np.uint8)).all(axis=-1).sum())
+    assert body_seen > 2000                                  # legs / abdomen / wings are in view
+    assert (wall_seen > 500) == (terrain is not None and terrain[0] in (1, 2, 3))
+    # switching both off gives back the bare scene
+    bare = EyeRenderer(sim, fly.name, Scene(spheres=[(6.0, 4.0, 1.5, 1.0)], sphere_rgb=[(0.9, 0.2, 0.1)], terrain_relief=False, own_body=False))
+    frb = bare.render_frames().cpu().numpy()
+    assert not (frb == np.array(scene.body_rgb, dtype=np.uint8)).all(axis=-1).any()
+    assert not (frb == np.array(scene.wall_rgb, dtype=np.uint8)).all(axis=-1).any()
+
+
 @pytest.mark.gpu
 def test_eye_renderer_matches_oracle_and_resample(bench_model):
     """HIP eye renderer: raw frames vs the numpy specification (ray-exact up to float32 rounding at material edges),
@@ -154,7 +263,7 @@ def test_eye_renderer_matches_oracle_and_resample(bench_model):
     sim = HIPSimulation(world, n_worlds=n, device=0)
     sim.field("qvel")[:, :6] = torch.as_tensor(np.random.default_rng(5).normal(0, 20, (n, 6)), dtype=torch.float32, device=sim.device)
     sim.step(60)                                                       # three different head poses
-    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0), (5.0, -6.0, 0.8, 0.8)], sphere_rgb=[(0.05, 0.05, 0.05), (0.9, 0.2, 0.1)])
+    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0), (5.0, -6.0, 0.8, 0.8)], sphere_rgb=[(0.05, 0.05, 0.05), (0.9, 0.2, 0.1)], own_body=False)
     eyes = EyeRenderer(sim, fly.name, scene)
     frames, omm = eyes.render_frames(with_readings=True)
     assert frames.shape == (n, 2, 512, 450, 3) and omm.shape == (n, 2, 721, 2)
