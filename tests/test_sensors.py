@@ -237,7 +237,8 @@ def test_eye_renderer_sees_the_simulated_world(world_cls):
             diff = (fr[w, e] != want).any(axis=-1).mean()
             assert diff < 5e-3, f"{world_cls} world {w} eye {e}: {diff:.2e} of the pixels differ"
             ref = so.retina_resample(want, eyes.retina.id_map, eyes.retina.pale_mask, eyes.retina.inv_norm)
-            assert np.abs(omm[w, e].cpu().numpy() - ref).max() < 1e-2
+            # an ommatidium averages ~300 pixels; relief multiplies the material edges (float32 rays land on either side)
+            assert np.abs(omm[w, e].cpu().numpy() - ref).max() < (1e-2 if terrain is None else 3e-2)
             body_seen += int((want == np.array(scene.body_rgb, dtype=np.uint8)).all(axis=-1).sum())
             wall_seen += int((want == np.array(scene.wall_rgb, dtype=np.uint8)).all(axis=-1).sum())
     assert body_seen > 2000                                  # legs / abdomen / wings are in view
