@@ -22,6 +22,7 @@ constexpr int kMaxSpheres = 8;
 constexpr int kMaxCaps = 64;            // capsules of the fly's own body an eye can see
 constexpr int kMaxTerrainCells = 64;    // cells a ray is followed through the relief before the far field is taken as flat
 constexpr float kTerrainEps = 1e-4f;    // the cell a ray is in at parameter t holds its point at t + eps (mm)
+constexpr float kTerrainWallTol = 1e-4f;   // entered through the side wall: this far below the cell's level (levels differ by >= 0.3 mm)
 
 struct EyeArgs {
   int height, width;
@@ -197,7 +198,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           const TerrainCell c = terrain_cell(A.terrain_kind, A.terrain, cam.x + tp * d.x, cam.y + tp * d.y);
           const float h = c.h + A.ground_z;
           const float z_in = cam.z + tc * d.z;
-          if (z_in < h) { tbest = tc; mat = 3; break; }
+          if (z_in < h - kTerrainWallTol) { tbest = tc; mat = 3; break; }
           const float tx = d.x > 0.f ? (c.x1 - cam.x) / d.x : (d.x < 0.f ? (c.x0 - cam.x) / d.x : INFINITY);
           const float ty = d.y > 0.f ? (c.y1 - cam.y) / d.y : (d.y < 0.f ? (c.y0 - cam.y) / d.y : INFINITY);
           const float t_out = fminf(tx, ty);

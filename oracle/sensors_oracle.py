@@ -57,6 +57,7 @@ def euler_xyz_extrinsic_to_mat(e):
 
 MAX_TERRAIN_CELLS = 64       # cells a ray is followed through the relief before the far field is taken as flat
 TERRAIN_EPS = 1e-4           # the cell a ray is in at parameter t is the one that holds its point at t + eps (mm)
+TERRAIN_WALL_TOL = 1e-4      # a cell is entered through its side wall if the ray is this far below its level (levels differ by >= 0.3 mm)
 
 
 def terrain_cell(kind, p, x, y):
@@ -180,7 +181,7 @@ def render_eye_frames(cam_pos, cam_mat, height, width, fov_deg, checker_size, gr
             x0, x1, y0, y1, h = terrain_cell(kind, tp, np.where(live, px, 0), np.where(live, py, 0))
             h = (h + f(ground_z)).astype(f)
             z_in = (cam[2] + tcur * d[..., 2]).astype(f)
-            wall = live & (z_in < h)
+            wall = live & (z_in < h - f(TERRAIN_WALL_TOL))
             with np.errstate(divide="ignore", invalid="ignore"):
                 tx = np.where(d[..., 0] > 0, (x1 - cam[0]) / d[..., 0], np.where(d[..., 0] < 0, (x0 - cam[0]) / d[..., 0], np.inf)).astype(f)
                 ty = np.where(d[..., 1] > 0, (y1 - cam[1]) / d[..., 1], np.where(d[..., 1] < 0, (y0 - cam[1]) / d[..., 1], np.inf)).astype(f)
