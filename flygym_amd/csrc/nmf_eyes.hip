@@ -154,24 +154,37 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     int row = (ch * 16) / A.width, col = ch * 16 - row * A.width;
     unsigned int tot = 0u, sA = 0u, sAB = 0u;
     unsigned int obytes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    // body capsules this chunk can see: the chunk's 16 rays lie in a cone about the mean of its first and last ray (a
-    // chunk that wraps to the next image row takes every capsule)
+    // body capsules this chunk can see: its rays lie in a cone about the mean of its first and last ray — two cones for
+    // a chunk that wraps to the next image row (one per row piece).  A capsule is a candidate if its bounding sphere's
+    // angular disc reaches into a cone.
     unsigned long long cand = 0ull;
     if (A.n_caps > 0) {
       const int row_l = (ch * 16 + 15) / A.width, col_l = ch * 16 + 15 - row_l * A.width;
-      float th0, th1;
-      const V3 c0 = eye_ray(row, col, cx, cy, inv_half_h, A.half_fov, th0), c1 = eye_ray(row_l, col_l, cx, cy, inv_half_h, A.half_fov, th1);
-      V3 cm = c0 + c1;
-      const float cl = __builtin_amdgcn_rsqf(fmaxf(dot(cm, cm), 1e-12f));
-      cm = cl * cm;
-      const V3 cw = v3(R[0] * cm.x + R[1] * cm.y + R[2] * cm.z, R[3] * cm.x + R[4] * cm.y + R[5] * cm.z, R[6] * cm.x + R[7] * cm.y + R[8] * cm.z);
-      const float ch_cos = fminf(dot(cm, c0), 1.f), ch_sin = sqrtf(fmaxf(1.f - ch_cos * ch_cos, 0.f));
       const bool wrapped = row_l != row;
+      V3 cw[2]; float ch_cos[2], ch_sin[2];
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece) {
+        const int ra = piece == 0 ? row : row_l, ca_ = piece == 0 ? col : 0;
+        const int rb = piece == 0 ? row : row_l, cb_ = piece == 0 ? (wrapped ? A.width - 1 : col_l) : col_l;
+        float th0, th1;
+        const V3 c0 = eye_ray(ra, ca_, cx, cy, inv_half_h, A.half_fov, th0), c1 = eye_ray(rb, cb_, cx, cy, inv_half_h, A.half_fov, th1);
+        V3 cm = c0 + c1;
+        cm = __builtin_amdgcn_rsqf(fmaxf(dot(cm, cm), 1e-12f)) * cm;
+        cw[piece] = v3(R[0] * cm.x + R[1] * cm.y + R[2] * cm.z, R[3] * cm.x + R[4] * cm.y + R[5] * cm.z, R[6] * cm.x + R[7] * cm.y + R[8] * cm.z);
+        ch_cos[piece] = fminf(dot(cm, c0), 1.f); ch_sin[piece] = sqrtf(fmaxf(1.f - ch_cos[piece] * ch_cos[piece], 0.f));
+      }
       for (int c = 0; c < A.n_caps; ++c) {
         const float* q = capd[c];
-        const float ca = q[14] * cw.x + q[15] * cw.y + q[16] * cw.z;      // cos of the angle between the cone axis and the capsule
-        const float lim = ch_cos * q[17] - ch_sin * q[18];               // cos(chunk half-angle + capsule angular radius)
-        if (wrapped || q[17] < -1.5f || ca >= lim || ch_cos * q[17] < ch_sin * q[18]) cand |= 1ull << c;
+        const float qx = q[14], qy = q[15], qz = q[16], qc = q[17], qs = q[18];
+        bool hit = qc < -1.5f;                                              // camera inside the bound
+#pragma unroll
+        for (int piece = 0; piece < 2; ++piece) {
+          if (piece == 1 && !wrapped) break;
+          const float ca = qx * cw[piece].x + qy * cw[piece].y + qz * cw[piece].z;   // cos(angle between the cone axis and the capsule)
+          const float lim = ch_cos[piece] * qc - ch_sin[piece] * qs;       // cos(cone half-angle + capsule angular radius)
+          hit = hit || ca >= lim || ch_cos[piece] * qc < ch_sin[piece] * qs;
+        }
+        if (hit) cand |= 1ull << c;
       }
     }
 #pragma unroll
