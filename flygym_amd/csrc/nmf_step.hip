@@ -148,7 +148,9 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][row_width_tw<TP>()], W[TP::NB][row_width_tw<TP>()];
-  float arm[TP::NV], damp[TP::NV];      // dof_armature / dof_damping, staged once per launch
+  // dof_armature / dof_damping, staged once per launch.  The LDS-bound kernels (hybrid, tree) keep only the armature:
+  // damping enters one passive-force pass and the Euler solve of a step, which read it from the model (dof_damp())
+  float arm[TP::NV], damp[kHasCm3<TP> ? TP::NV : 1];
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
   float xpos_root[3];
   float c_w[kMaxCon][7];     // contact wrenches (6 used; odd stride: lane = contact stores hit 32 different banks)
@@ -179,6 +181,14 @@ struct __align__(16) FlyLds : TreeLds<TP> {
     }
   }
 };
+template <class TP> __device__ __forceinline__ float dof_damp(const FlyLds<TP>& s, const DevModel& m, int j) {
+  if constexpr (kHasCm3<TP>) return s.damp[j]; else return m.dof_damping[j];
+}
+// diagonal term of an articulated-body solve: armature + hdamp * damping (hdamp = 0 except in the Euler step's solve)
+template <class TP> __device__ __forceinline__ float dof_delta(const FlyLds<TP>& s, const DevModel& m, int j, float hdamp) {
+  if constexpr (kHasCm3<TP>) return s.arm[j] + hdamp * s.damp[j];
+  else return hdamp != 0.f ? fmaf(hdamp, m.dof_damping[j], s.arm[j]) : s.arm[j];
+}
 template <class TP> __device__ __forceinline__ int tbl_dofbody(const FlyLds<TP>& s, int j) { if constexpr (TP::kNFact > 1) return s.t_dofbody[j]; else return 0; }
 template <class TP> __device__ __forceinline__ int tbl_dofadr(const FlyLds<TP>& s, int b) { if constexpr (TP::kNFact > 1) return s.t_dofadr[b]; else return 0; }
 template <class TP> __device__ __forceinline__ int tbl_dofnum(const FlyLds<TP>& s, int b) { if constexpr (TP::kNFact > 1) return s.t_dofnum[b]; else return 0; }
@@ -259,7 +269,7 @@ struct RestNode;
 template <class TP, bool FAST, bool UP, class F> __device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM);
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM, const DevModel& m);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
 template <class TP, int NUM, bool HOMOGENEOUS>
@@ -824,8 +834,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 3>(s, nd, tau, L); });
       else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 0>(s, nd, tau, L); });
     } else {
-      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so, IM); });
-      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so, IM); });
+      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so, IM, m); });
+      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so, IM, m); });
       if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
       WSYNC();
     }
@@ -856,7 +866,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
     const float sown = s.S[j][L.rr];
     if constexpr (kKeepS) Sreg[d] = sown;
-    aba_step(IA, pA, sj, sown, L.mask, s.arm[j] + hdamp * s.damp[j], tau[j], Ureg[d], ureg[d], invDreg[d]);
+    aba_step(IA, pA, sj, sown, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d], invDreg[d]);
   });
 #pragma unroll
   for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
@@ -1265,7 +1275,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
   }
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) {
-    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - s.damp[j] * s.qvel[j];
+    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - dof_damp(s, m, j) * s.qvel[j];
     s.qfrc_smooth[j] = v + passive + s.vA[j];
   });
   STAGE(6);
@@ -1626,7 +1636,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
   }
   const int lane = threadIdx.x;
   STAGE_INIT();
-  for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; s.damp[j] = m.dof_damping[j]; }
+  for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; if constexpr (kHasCm3<TP>) s.damp[j] = m.dof_damping[j]; }
   if (lane < 6) {
     const KLane K = k_lane(lane, make_frame(v3(m.plane[0], m.plane[1], m.plane[2])));
     float* q = s.k_tab[lane];

@@ -228,7 +228,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
 #pragma unroll
     for (int i = 0; i < 6; ++i) sj[i] = s.S[j][i];
     sym6_mul(IA, sj, U);
-    float D = j < 6 ? 0.f : s.arm[j] + hdamp * s.damp[j], sp = 0.f;
+    float D = j < 6 ? 0.f : dof_delta(s, m, j, hdamp), sp = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) { D += sj[i] * U[i]; sp += sj[i] * pA[i]; }
     const float invD = __builtin_amdgcn_rcpf(D), u = tau[j] - sp;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void rest_dofs(int adr, int num, F&& f) {
 // full elimination of a body: matrix factors and vector part
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const InertiaRowMap& IM) {
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const InertiaRowMap& IM, const DevModel& m) {
   const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
   // everything that depends on the node only, first: the body's inertia row and its dofs' axes and scalars
   float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -331,7 +331,7 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
       const int j = nd.adr + d;
 #pragma unroll
       for (int i = 0; i < 6; ++i) sj[d][i] = s.S[j][i];
-      sown[d] = s.S[j][L.rr]; delta[d] = s.arm[j] + hdamp * s.damp[j]; tj[d] = tau[j];
+      sown[d] = s.S[j][L.rr]; delta[d] = dof_delta(s, m, j, hdamp); tj[d] = tau[j];
     }
   }
   float pA = 0.f;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
 #pragma unroll
       for (int i = 0; i < 6; ++i) s1[i] = s.S[j][i];
       float U, u, invD;
-      aba_step(row, pA, s1, s.S[j][L.rr], L.mask, s.arm[j] + hdamp * s.damp[j], tau[j], U, u, invD);
+      aba_step(row, pA, s1, s.S[j][L.rr], L.mask, dof_delta(s, m, j, hdamp), tau[j], U, u, invD);
       float* f = s.fact[j - TP::kFact0];
       if (L.r < 6) f[L.rr] = U;
       if (L.r == 0) { f[6] = u; f[7] = invD; }
