@@ -1,6 +1,7 @@
 #!/bin/bash
+# usage: gpu_profile.sh <tag>   -> prof_<tag>_s20 (the driver's arguments) and prof_<tag> (default arguments)
 cd $GRAFT_REPO_ROOT
-rocprofv3 -L 2>/dev/null | grep -o "SQ_THREAD_CYCLES_VALU\|SQ_INST_CYCLES_SALU\|SQ_BUSY_CU_CYCLES\|SQ_INSTS_VMEM\b\|SQ_INSTS_SMEM\|SQ_WAIT_INST_LDS\|SQ_ACTIVE_INST_SCA\|SQ_INST_CYCLES_VALU" | sort | uniq -c > gpurun_out/counters_available.txt
-bash scripts/profile_bench.sh r2a_s20 --steps 20 --warmup 5
-bash scripts/profile_bench.sh r2a
-cat gpurun_out/counters_available.txt
+TAG=${1:-r2b}
+bash scripts/profile_bench.sh ${TAG}_s20 --steps 20 --warmup 5 > /dev/null
+bash scripts/profile_bench.sh ${TAG} > /dev/null
+grep -h '"metric"' gpurun_out/prof_${TAG}*/bench_trace.log | cut -c1-140
