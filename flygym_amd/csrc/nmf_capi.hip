@@ -73,7 +73,8 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  int max_chunks = 7, min_chunk_steps = 2;   // NMF_MAX_CHUNKS (<= 31) / NMF_MIN_CHUNK_STEPS: tuning experiments
+  int max_chunks = 8, min_chunk_steps = 2;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
+  double chunk_div = 3.0;
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -178,16 +179,25 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
   HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
-  // More worlds than resident waves and a launch long enough to cut: at most 7 chunks of >= 2 steps per launch (measured
-  // on 4096 worlds: 20-step launches 32.0 -> 36.3 M env-steps/s, 50-step launches 31.9 -> 38.3 M; more, shorter chunks lose
-  // to the per-item cost of taking a ticket and moving the state through HBM, ~10 us)
+  // More worlds than resident waves and a launch long enough to cut: chunks whose lengths shrink towards the end of the
+  // launch ("guided" sizes: each takes 1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks)
+  // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds,
+  // equal chunks: 20-step launches 32.0 -> 36.3 M env-steps/s, 50-step launches 31.9 -> 38.3 M (7 chunks; more, shorter
+  // chunks lose to the per-item cost of taking a ticket and moving the state through HBM, ~10 us).
   int n_chunks = 1;
-  b->st.chunk_len = 0; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
+  b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
   if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {
-    const int want = std::min(b->max_chunks, n_steps / b->min_chunk_steps);
-    b->st.chunk_len = (n_steps + want - 1) / want;
-    n_chunks = (n_steps + b->st.chunk_len - 1) / b->st.chunk_len;
-    if (n_chunks < 2) { b->st.chunk_len = 0; n_chunks = 1; }
+    int start = 0, c = 0;
+    while (start < n_steps && c < b->max_chunks) {
+      int len = (int)std::ceil((n_steps - start) / b->chunk_div);
+      len = std::max(len, b->min_chunk_steps);
+      if (c == b->max_chunks - 1 || n_steps - start - len < b->min_chunk_steps) len = n_steps - start;
+      b->st.chunk_start[c++] = start;
+      start += len;
+    }
+    b->st.chunk_start[c] = n_steps;
+    n_chunks = c;
+    b->st.n_chunks = c;
   }
   // chunked: one persistent workgroup per resident wave pulls (chunk, world) items; plain: one workgroup per world
   dim3 grid(n_chunks > 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks) : (unsigned)b->n_worlds), block(nmf::kWave);
@@ -395,7 +405,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
-    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(31, atoi(e)));
+    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {

@@ -127,7 +127,8 @@ struct DevState {
   // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
   struct ChunkSched* csched;
   unsigned int* chunk_done;   // [n_worlds] epoch * 32 + chunks of this launch the world has finished
-  int chunk_len;              // 0: one workgroup steps a world through the whole launch
+  int n_chunks;               // 1: one workgroup steps a world through the whole launch
+  int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 
 // Device-resident scheduler state of chunked launches; the last workgroup to run out of tickets rewinds it, so launches need no

@@ -1648,15 +1648,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
     q[11] = __int_as_float(words[0]); q[12] = __int_as_float(words[1]); q[13] = __int_as_float(words[2]);
   }
   // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps and exits.  Chunked
-  // launches (more worlds than resident waves): the launch is cut into n_chunks chunks of chunk_len steps, the grid is
+  // launches (more worlds than resident waves): the launch is cut into n_chunks chunks (long first, short last), the grid is
   // one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket counter until the
   // counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost varies 2x with its gait
   // phase, so whole-launch items leave the machine half empty while the costliest worlds finish; with chunks the tail is
   // one chunk long.  An item waits for its world's previous chunk (an older ticket, hence taken by a workgroup that is
   // running or done: no deadlock whatever the dispatch order) and takes the state over through HBM (ld_state / st_state).
   // The model constants staged above stay in LDS from item to item.
-  const bool chunked = mode == 0 && st.chunk_len > 0;
-  const int n_chunks = chunked ? (n_steps + st.chunk_len - 1) / st.chunk_len : 1;
+  const bool chunked = mode == 0 && st.n_chunks > 1;
+  const int n_chunks = chunked ? st.n_chunks : 1;
   const unsigned int epoch = chunked ? st.csched->epoch : 0u;
   for (;;) {
     int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
@@ -1673,7 +1673,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
         break;
       }
       chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
-      step0 = chunk * st.chunk_len; step1 = step0 + st.chunk_len < n_steps ? step0 + st.chunk_len : n_steps;
+      step0 = st.chunk_start[chunk]; step1 = st.chunk_start[chunk + 1];
     } else if (slot >= st.n_worlds) return;
     const int w = st.order ? st.order[slot] : slot;
     if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;

@@ -9,13 +9,11 @@ for l in sys.stdin:
     print(sys.argv[1], round(d['value'] / 1e6, 2), 'M', 'ms/launch', round(d['roofline']['kernel_ms_per_launch'], 3))
 " "$1"; }
 {
-for mc in 7 10 20; do for ms in 1 2; do
-  NMF_MAX_CHUNKS=$mc NMF_MIN_CHUNK_STEPS=$ms timeout 200 $B --steps 20 --warmup 5 2>/dev/null | line "20-step launches, max_chunks $mc min_steps $ms"
+for div in 1.5 2 2.5 3 4 7; do for mc in 6 8 12; do
+  NMF_CHUNK_DIV=$div NMF_MAX_CHUNKS=$mc timeout 200 $B --steps 20 --warmup 5 2>/dev/null | line "20-step launches, div $div max_chunks $mc"
 done; done
-for mc in 7 10 17 25; do
-  NMF_MAX_CHUNKS=$mc NMF_MIN_CHUNK_STEPS=1 timeout 200 $B 2>/dev/null | line "50-step launches, max_chunks $mc"
-done
-NMF_MAX_CHUNKS=25 NMF_MIN_CHUNK_STEPS=1 timeout 200 $B --workload replay 2>/dev/null | line "50-step launches replay, max_chunks 25"
-NMF_MAX_CHUNKS=10 NMF_MIN_CHUNK_STEPS=1 timeout 200 $B --workload replay 2>/dev/null | line "50-step launches replay, max_chunks 10"
+for div in 2 2.5 3 4 7; do for mc in 8 12; do
+  NMF_CHUNK_DIV=$div NMF_MAX_CHUNKS=$mc timeout 200 $B 2>/dev/null | line "50-step launches, div $div max_chunks $mc"
+done; done
 } > gpurun_out/chunks.log 2>&1
 cat gpurun_out/chunks.log
