@@ -74,7 +74,7 @@ struct nmf_batch {
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
   int max_chunks = 8, min_chunk_steps = 2;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
-  double chunk_div = 3.0;
+  double chunk_div = 2.0;
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -181,9 +181,10 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
   HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
   // More worlds than resident waves and a launch long enough to cut: chunks whose lengths shrink towards the end of the
   // launch ("guided" sizes: each takes 1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks)
-  // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds,
-  // equal chunks: 20-step launches 32.0 -> 36.3 M env-steps/s, 50-step launches 31.9 -> 38.3 M (7 chunks; more, shorter
-  // chunks lose to the per-item cost of taking a ticket and moving the state through HBM, ~10 us).
+  // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds:
+  // whole-launch items 32.0 / 31.9 M env-steps/s (20- / 50-step launches), 7 equal chunks 36.3 / 38.3 M, halving chunks
+  // (chunk_div 2: 10 + 5 + 3 + 2 steps) 36.9 / 38.8 M; more, shorter chunks lose to the per-item cost of taking a
+  // ticket and moving the state through HBM (~10 us).
   int n_chunks = 1;
   b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
   if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {

@@ -123,7 +123,7 @@ struct DevState {
   float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
   const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
   struct SchedState* sched;   // launch-duration bookkeeping of the block-order policy (nullptr: off)
-  // chunked launches (nmf_step_kernel): a launch of n_steps is cut into chunks of chunk_len steps; workgroups take
+  // chunked launches (nmf_step_kernel): a launch of n_steps is cut into chunks (chunk_start); workgroups take
   // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
   struct ChunkSched* csched;
   unsigned int* chunk_done;   // [n_worlds] epoch * 32 + chunks of this launch the world has finished

@@ -1706,11 +1706,17 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_
       for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
       time = ld_state(&st.time[w]);
       WSYNC();
+      // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
+      // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path
+      const float* tab = rp.table ? rp.table + (size_t)w * rp.table_steps * rp.n_act : nullptr;
+      const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[lane] : -1;
+      float next_ctrl = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;
       for (int step = step0; step < step1; ++step) {
-        if (rp.table) {
-          int row = (rp.start + step) % rp.table_steps;
-          const float* src = rp.table + ((size_t)w * rp.table_steps + row) * rp.n_act;
-          for (int a = lane; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
+        if (tab) {
+          if (my_ctrl >= 0) s.ctrl[my_ctrl] = next_ctrl;
+          const float* src = tab + (size_t)((rp.start + step) % rp.table_steps) * rp.n_act;
+          for (int a = lane + kWave; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
+          if (my_ctrl >= 0 && step + 1 < step1) next_ctrl = tab[(size_t)((rp.start + step + 1) % rp.table_steps) * rp.n_act + lane];
           WSYNC();
         }
         STAGE(0);
