@@ -1,0 +1,23 @@
+#!/bin/bash
+# the workload table of DESIGN.md §3: batch-size sweep under the reference protocol + the other configurations
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+B="python bench.py --no-cpu-baseline"
+line() { grep '^{"metric"' | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); c = d['config']
+    print(sys.argv[1], round(d['value'] / 1e6, 3), 'M', 'ms/launch', round(d['roofline']['kernel_ms_per_launch'], 3), 'contacts', round(c['mean_contacts'], 2), 'iters', round(c['mean_newton_iters'], 2), 'valid', d.get('valid'))
+" "$1"; }
+{
+for n in 16 64 256 1024 2048 4096 8192 16384; do timeout 300 $B --workload replay --worlds-per-gpu $n 2>/dev/null | line "replay worlds $n"; done
+for t in gapped blocks mixed; do timeout 300 $B --terrain $t 2>/dev/null | line "cpg terrain $t"; done
+timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 2>/dev/null | line "config5 mixed+odor+adhesion 4096"
+timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 --worlds-per-gpu 128 2>/dev/null | line "config5 mixed+odor+adhesion 128"
+timeout 300 $B --joint-preset legs_active_only 2>/dev/null | line "legs_active_only"
+timeout 300 $B --joint-preset all_biological 2>/dev/null | line "all_biological"
+timeout 300 $B --steps-per-launch 250 2>/dev/null | line "cpg 250-step launches"
+timeout 300 python scripts/bench_vision.py 2>/dev/null | tail -1 | cut -c1-400
+timeout 300 python scripts/bench_vision.py --render 2>/dev/null | tail -1 | cut -c1-400
+} > gpurun_out/workloads.log 2>&1
+cat gpurun_out/workloads.log
