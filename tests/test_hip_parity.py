@@ -316,23 +316,35 @@ def test_terrain_worlds_parity(torch_mod, oracle_lib, world_cls):
     # comparison is re-synchronised: every 20 steps the float64 oracle's state is pushed into the engine, both advance
     # 20 steps under the same controls, and the positions are compared.  Nearly all segments must agree to float32
     # rounding; a segment that contains an edge event may differ more, but never by much.
-    errs, ncon_equal = [], []
+    # Round 2: the float32 oracle runs every segment from the same state too.  A segment counts as agreeing if the engine
+    # follows EITHER oracle to rounding — an edge event that float32 and float64 resolve differently is then not held
+    # against the engine — which lets the bar rise from 85 % to 94 % of the segments (a systematic edge-case bug in a few
+    # per cent of the segments no longer fits under it).
+    o32 = oracle_lib.Oracle(sim.model.to_blob(), "f32")
+    o32.ctrl[42:] = 1.0
+    errs, errs64, ncon_equal = [], [], []
 
     def segment(run_sim, run_oracle):
         _push_state(sim, torch, o.qpos, o.qvel, o.ctrl, o.arr("qacc_warmstart"))
-        run_oracle(); run_sim()
-        errs.append(np.abs(sim.field("qpos").cpu().numpy() - o.qpos[None]).max())
-        ncon_equal.append(int(sim.field("stats")[0, 0].item()) == o.ints()["ncon"])
+        for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+            o32.arr(k)[:] = o.arr(k)
+        run_oracle(o); run_oracle(o32); run_sim()
+        q = sim.field("qpos").cpu().numpy()
+        e64, e32 = np.abs(q - o.qpos[None]).max(), np.abs(q - o32.qpos[None]).max()
+        errs64.append(e64)
+        errs.append(min(e64, e32))
+        ncon_equal.append(int(sim.field("stats")[0, 0].item()) in (o.ints()["ncon"], o32.ints()["ncon"]))
 
     for k in range(20):                                    # the drop onto the terrain and settling (400 steps)
-        segment(lambda: sim.step(20), lambda: o.step(20))
+        segment(lambda: sim.step(20), lambda orc: orc.step(20))
     for k in range(15):                                    # CPG walking across it (300 steps)
         segment(lambda k=k: sim.step_replay(tdev, ids, 20 * k, 20),
-                lambda k=k: o.step_replay(table[0], np.arange(42), 20 * k, 20))
-    errs = np.array(errs)
-    assert (errs < 2e-5).mean() >= 0.85, f"{world_cls}: segment errors {np.sort(errs)[-8:]}"
-    assert errs.max() < 5e-3, f"{world_cls}: worst segment {errs.max():.2e}"
-    assert np.mean(ncon_equal) >= 0.85
+                lambda orc, k=k: orc.step_replay(table[0], np.arange(42), 20 * k, 20))
+    errs, errs64 = np.array(errs), np.array(errs64)
+    assert (errs < 2e-5).mean() >= 0.94, f"{world_cls}: segment errors {np.sort(errs)[-8:]}"
+    assert (errs64 < 2e-5).mean() >= 0.85, f"{world_cls}: segment errors vs float64 {np.sort(errs64)[-8:]}"
+    assert errs64.max() < 5e-3, f"{world_cls}: worst segment {errs64.max():.2e}"
+    assert np.mean(ncon_equal) >= 0.94
     assert np.isfinite(sim.field("qpos").cpu().numpy()).all()
     assert o.qpos[0] > 0.3 + 0.1                           # the fly actually walked forward over the terrain
 
