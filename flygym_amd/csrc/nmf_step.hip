@@ -1610,12 +1610,20 @@ __device__ void write_poses(FlyLds<TP>& s, const DevModel& m, const DevState& st
   }
 }
 
+// Waves per SIMD the register allocation aims at.  Two (256 VGPRs) everywhere except the 48-dof leg-chain skeleton, whose
+// 12.3 KB of LDS lets twelve flies share a CU: three waves per SIMD with 168 VGPRs are 18 % faster there although the
+// compiler spills (measured); on the 72-dof skeleton the LDS array saturates instead and nothing is gained.
+template <class TP> constexpr int waves_per_simd() {
+#ifdef NMF_WAVES_PER_EU
+  return NMF_WAVES_PER_EU;
+#else
+  if constexpr (TP::kStar) return (TP::REST_B == 0 && TP::NV <= 48) ? 3 : 2; else return 2;
+#endif
+}
+
 // mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
 template <class TP, bool WELD>
-#ifndef NMF_WAVES_PER_EU
-#define NMF_WAVES_PER_EU 2
-#endif
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NMF_WAVES_PER_EU, NMF_WAVES_PER_EU))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(waves_per_simd<TP>(), waves_per_simd<TP>()))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
   const DevModel& m = *mp;
   if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }
