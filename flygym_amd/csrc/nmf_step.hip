@@ -1610,14 +1610,15 @@ __device__ void write_poses(FlyLds<TP>& s, const DevModel& m, const DevState& st
   }
 }
 
-// Waves per SIMD the register allocation aims at.  Two (256 VGPRs) everywhere except the 48-dof leg-chain skeleton, whose
-// 12.3 KB of LDS lets twelve flies share a CU: three waves per SIMD with 168 VGPRs are 18 % faster there although the
-// compiler spills (measured); on the 72-dof skeleton the LDS array saturates instead and nothing is gained.
+// Waves per SIMD the register allocation aims at: two (256 VGPRs).  Three (168 VGPRs) were measured on both leg-chain
+// skeletons (-DNMF_WAVES_PER_EU=3): the 72-dof kernel gains nothing (the LDS array saturates), the
+// 48-dof one +18 % with 70 spilled registers in an early round-2 build but -12 % with the 116 the persistent item loop
+// leaves it — not shipped.
 template <class TP> constexpr int waves_per_simd() {
 #ifdef NMF_WAVES_PER_EU
   return NMF_WAVES_PER_EU;
 #else
-  if constexpr (TP::kStar) return (TP::REST_B == 0 && TP::NV <= 48) ? 3 : 2; else return 2;
+  return 2;
 #endif
 }
 
