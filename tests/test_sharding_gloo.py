@@ -154,3 +154,27 @@ def test_bench_entry_self_spawns_and_shards(monkeypatch):
     # strong scaling: 4096 worlds over 8 ranks = 512 each, contiguous
     spans = [shard_range(4096, r, 8) for r in range(8)]
     assert spans[0] == (0, 512) and spans[-1] == (3584, 4096)
+
+
+def test_bench_traffic_and_flop_models():
+    """bench.py's derived roofline figures: the HBM traffic of a launch scales from the committed per-world fit
+    (profiles/hbm_traffic.json: bytes per launch + bytes per step), the algorithmic FLOP count grows with contacts and
+    solver iterations and stays near 0.14 MFLOP per fly-step for the measured walking averages."""
+    import importlib
+    import json
+
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    args = bench.parse_args([])
+    rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+    t50, issue = bench.traffic_model(4096, 50, args)
+    t20, _ = bench.traffic_model(4096, 20, args)
+    assert t50 == pytest.approx(rec["traffic_bytes_per_launch"], rel=1e-6)          # the profiled point itself
+    assert t50 - t20 == pytest.approx(30 * 4096 * rec["per_world_per_step_bytes"], rel=1e-9)
+    assert 160 <= rec["per_world_per_step_bytes"] <= 200                             # the 168-byte control-table row
+    assert issue["valu_cycles_per_inst"] < 2.0 and issue["valu_insts_per_env_step"] > 5000
+    args_terrain = bench.parse_args(["--terrain", "gapped"])
+    assert bench.traffic_model(4096, 50, args_terrain) == (None, None)              # only the profiled workload is claimed
+    f0 = bench.algorithmic_flops(72, 49, 0.0, 0.0)
+    f1 = bench.algorithmic_flops(72, 49, 5.7, 3.4)
+    assert f0 < f1 and 1.0e5 < f1 < 1.8e5
