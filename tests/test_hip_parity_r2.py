@@ -396,7 +396,7 @@ def test_simulation_on_a_device_other_than_the_current_one_is_guarded(torch_mod,
 def test_chunked_launches_are_bitwise_the_plain_ones(torch_mod, bench_model, monkeypatch):
     """More worlds than resident waves: a launch is cut into (chunk, world) items pulled by persistent workgroups and a
     world's state crosses HBM between chunks (nmf_step_kernel).  Scheduling must never change a result: 4096 worlds x
-    (500 + 7 x 50 + 20 + 9) steps chunked vs the same launches with NMF_NO_CHUNKS=1 — every state array, the clock and the
+    (500 + 47 x 50 + 20 + 9 + 4 x 30) steps chunked vs the same launches with NMF_NO_CHUNKS=1 — every state array, the clock and the
     running sums bit for bit; captured in a hipGraph and replayed, too (the scheduler keeps no host-side state)."""
     torch = torch_mod
     from flygym_amd import HIPSimulation
@@ -413,7 +413,7 @@ def test_chunked_launches_are_bitwise_the_plain_ones(torch_mod, bench_model, mon
         sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
         sim.step(500)
         cur = 0
-        for _ in range(7):
+        for _ in range(47):                                    # 2350 steps of walking in 50-step launches (5 chunks each)
             sim.step_replay(table, ids, cur, 50); cur += 50
         sim.step_replay(table, ids, cur, 20); cur += 20
         sim.step_replay(table, ids, cur, 9); cur += 9
@@ -442,8 +442,8 @@ def test_chunked_launches_are_bitwise_the_plain_ones(torch_mod, bench_model, mon
     for k in plain:
         assert torch.equal(chunked[k], plain[k]), f"chunked launch differs in {k}"
         assert torch.equal(graphed[k], plain[k]), f"graph replay of a chunked launch differs in {k}"
-    assert float(plain["stats_sum"][:, 0].min()) == 500 + 350 + 20 + 9 + 120
-    assert float(plain["time"].min()) == pytest.approx(0.0999, rel=1e-3)
+    assert float(plain["stats_sum"][:, 0].min()) == 500 + 2350 + 20 + 9 + 120
+    assert float(plain["time"].min()) == pytest.approx(0.2999, rel=1e-3)
 
 
 def test_replay_table_resampled_on_the_device(torch_mod, bench_model):
