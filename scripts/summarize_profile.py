@@ -50,7 +50,9 @@ out.append(f"\n## step-kernel launches in dispatch order (ms)\n\n`{[round(d, 3) 
 out.append(f"timed-region mean over the last {n_launch} launches: **{sum(timed)/len(timed):.3f} ms** "
            f"(bench.py HIP-event mean: {b['roofline']['kernel_ms_per_launch']:.3f} ms)\n")
 r0 = rows[-1]
-out.append(f"resources: VGPR {r0.get('VGPR_Count', r0.get('Arch_VGPR_Count','?'))}, accum VGPR {r0.get('Accum_VGPR_Count','?')}, SGPR {r0.get('SGPR_Count','?')}, "
+out.append("resources as rocprofv3 reports them (its VGPR_Count is not the allocation: the code object's .vgpr_count — "
+           "`scripts/kernel_stats.py` — is 256 for this kernel, i.e. two waves per SIMD): "
+           f"VGPR {r0.get('VGPR_Count', r0.get('Arch_VGPR_Count','?'))}, accum VGPR {r0.get('Accum_VGPR_Count','?')}, SGPR {r0.get('SGPR_Count','?')}, "
            f"LDS {r0.get('LDS_Block_Size','?')} B/block, scratch {r0.get('Scratch_Size', r0.get('Private_Segment_Size','?'))} B, grid {r0.get('Grid_Size','?')}, workgroup {r0.get('Workgroup_Size','?')}\n")
 
 
