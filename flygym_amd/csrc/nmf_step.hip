@@ -151,6 +151,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // dof_armature / dof_damping, staged once per launch.  The LDS-bound kernels (hybrid, tree) keep only the armature:
   // damping enters one passive-force pass and the Euler solve of a step, which read it from the model (dof_damp())
   float arm[TP::NV], damp[kHasCm3<TP> ? TP::NV : 1];
+  float dlt[kHasCm3<TP> ? TP::NV : 1];   // armature + timestep * damping: the diagonal term of the Euler step's solve (star kernels)
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
   float xpos_root[3];
   float c_w[kMaxCon][7];     // contact wrenches (6 used; odd stride: lane = contact stores hit 32 different banks)
@@ -186,7 +187,7 @@ template <class TP> __device__ __forceinline__ float dof_damp(const FlyLds<TP>& 
 }
 // diagonal term of an articulated-body solve: armature + hdamp * damping (hdamp = 0 except in the Euler step's solve)
 template <class TP> __device__ __forceinline__ float dof_delta(const FlyLds<TP>& s, const DevModel& m, int j, float hdamp) {
-  if constexpr (kHasCm3<TP>) return s.arm[j] + hdamp * s.damp[j];
+  if constexpr (kHasCm3<TP>) return (hdamp != 0.f ? s.dlt : s.arm)[j];        // hdamp is 0 or the timestep
   else return hdamp != 0.f ? fmaf(hdamp, m.dof_damping[j], s.arm[j]) : s.arm[j];
 }
 template <class TP> __device__ __forceinline__ int tbl_dofbody(const FlyLds<TP>& s, int j) { if constexpr (TP::kNFact > 1) return s.t_dofbody[j]; else return 0; }
@@ -787,6 +788,14 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
   pA += k * u;
   Uout = mask * U; uout = u; invDout = invD;
 }
+// the same for the leg chains of the star sweeps, whose back-substitution needs (u - U.a) / D only: hands back U / D and
+// u / D (one register per dof less to keep, one multiply per dof less in the forward sweep)
+__device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sown, float mask, float delta,
+                                                float tauj, float& UDout, float& uDout) {
+  float U, u, invD;
+  aba_step(IA, pA, sj, sown, mask, delta, tauj, U, u, invD);
+  UDout = U * invD; uDout = u * invD;
+}
 
 template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
@@ -811,7 +820,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
   // forward sweep instead of keeping it: 24 registers fewer to spill
   constexpr bool kKeepS = TP::NDL <= 16;
-  float Ureg[TP::NDL], ureg[TP::NDL], invDreg[TP::NDL], Sreg[kKeepS ? TP::NDL : 1];
+  float Ureg[TP::NDL], ureg[TP::NDL], Sreg[kKeepS ? TP::NDL : 1];        // U / D (this lane's row), u / D, own axis component
   KLane KL;                             // contact stiffness rows: per-row constants from the launch's table
   if (withK) {
     const float* q = s.k_tab[L.rr];
@@ -866,7 +875,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
     const float sown = s.S[j][L.rr];
     if constexpr (kKeepS) Sreg[d] = sown;
-    aba_step(IA, pA, sj, sown, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d], invDreg[d]);
+    aba_step_scaled(IA, pA, sj, sown, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d]);
   });
 #pragma unroll
   for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
@@ -878,7 +887,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // of IA, D and s.pA are single entries (one group broadcast each, and D's is one of the six U broadcasts the rank-1
   // update needs anyway) — 11 instead of 28 vector instructions per dof.  Generalized forces go in as R tau_rot, the
   // rotational accelerations come out as RT alpha.
-  float Ur[6], ur[6], invDr[6];
+  float Ur[6], ur[6];                   // U / D, u / D of the six root directions
   float Rm[3][3];                       // Rm[c][k] = component c of the k-th rotation axis of the free joint
   {
     float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -933,7 +942,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       const float k = U * invD;
       IA[0] -= k * b0; IA[1] -= k * b1; IA[2] -= k * b2; IA[3] -= k * b3; IA[4] -= k * b4; IA[5] -= k * b5;
       pA += k * u;
-      Ur[e] = L.mask * U; ur[e] = u; invDr[e] = invD;
+      Ur[e] = L.mask * k; ur[e] = u * invD;
     });
   }
   // ---- forward sweep: root (linear x, y, z, then angular x, y, z), then down the leg
@@ -943,7 +952,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     static_for<6>([&](auto DD) {
       constexpr int i = decltype(DD)::value;
       constexpr int e = i < 3 ? 3 + i : i - 3;
-      const float xe = (ur[e] - grp8_sum(Ur[e] * a)) * invDr[e];
+      const float xe = ur[e] - grp8_sum(Ur[e] * a);
       xw[e] = xe;
       a = L.rr == e ? a + xe : a;
     });
@@ -957,7 +966,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   static_for<TP::NDL>([&](auto DD) {
     constexpr int d = decltype(DD)::value;
     const int j = j0 + d;
-    const float xj = (ureg[d] - grp8_sum(Ureg[d] * a)) * invDreg[d];
+    const float xj = ureg[d] - grp8_sum(Ureg[d] * a);
     x[j] = xj;
     if constexpr (kKeepS) a += xj * Sreg[d]; else a += xj * s.S[j][L.rr];
     if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
@@ -1645,7 +1654,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
   }
   const int lane = threadIdx.x;
   STAGE_INIT();
-  for (int j = lane; j < s.nv(); j += kWave) { s.arm[j] = m.dof_armature[j]; if constexpr (kHasCm3<TP>) s.damp[j] = m.dof_damping[j]; }
+  for (int j = lane; j < s.nv(); j += kWave) {
+    s.arm[j] = m.dof_armature[j];
+    if constexpr (kHasCm3<TP>) { s.damp[j] = m.dof_damping[j]; s.dlt[j] = m.dof_armature[j] + m.timestep * m.dof_damping[j]; }
+  }
   if (lane < 6) {
     const KLane K = k_lane(lane, make_frame(v3(m.plane[0], m.plane[1], m.plane[2])));
     float* q = s.k_tab[lane];
