@@ -308,10 +308,15 @@ __device__ __forceinline__ void sym6_add_inertia(Sym6& A, const float* I) {
 // Lanes are used as 8 groups of 8; a group owns one leg and its lanes own the 6 rows/components of
 // a spatial quantity (lanes 6,7 of a group carry zeros).  The sum lands in every lane of the group.
 #define NMF_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+// NMF_PIN: the value is final here — keeps the compiler from contracting the producing multiply into the first DPP step
+// (v_mul + v_mov_dpp + v_fmac instead of v_mul + v_add_dpp) or re-associating the last step with what follows.
+#define NMF_PIN(v) asm("" : "+v"(v))
 __device__ __forceinline__ float grp8_sum(float v) {
+  NMF_PIN(v);
   v += NMF_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
   v += NMF_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
   v += NMF_DPP(v, 0x141);   // row_half_mirror: lane i <-> 7-i inside each 8-lane half row
+  NMF_PIN(v);
   return v;
 }
 

@@ -116,6 +116,22 @@ constexpr int conflict_free_width(int rows_per_leg, int nleg) {
 template <class TP> constexpr int row_width_s() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NDL, TP::NLEG) : 6; else return 6; }
 template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6; else return 6; }
 
+// What the non-inlined stages (kinematics, collision) need of the model, staged in LDS once per launch.  Inside a
+// non-inlined function the model is a generic reference: every field would be a flat load (full memory latency, and the
+// LDS counter waits with it) and every array access two dependent round trips (pointer, then value), re-issued after each
+// LDS store the compiler cannot tell apart from it.  From here a pointer costs one LDS read and the arrays are read as
+// global memory.
+struct HotModel {
+  const float *dof_axis, *body_pos, *body_quat, *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *hull_vert, *pair_margin;
+  const int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum;
+  float plane[4], terrain[5], hull_skin;
+  int terrain_type, ng, sem_max_hull_contacts;
+};
+template <class T> using gptr = const __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ gptr<T> G(const T* p) { return (gptr<T>)p; }
+__device__ __forceinline__ V3 ld3(gptr<float> p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ Q4 ldq(gptr<float> p) { return Q4{p[0], p[1], p[2], p[3]}; }
+
 template <class TP>
 struct __align__(16) FlyLds : TreeLds<TP> {
   // sizes: compile-time constants for the chain-star kernels, run-time values of the model for the tree kernel
@@ -161,7 +177,10 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float c_m3[kHasCm3<TP> ? kMaxCon : 1][5];
   // per row index r of a 6x6 (staged once per launch): [0..10] KLane constants of the contact stiffness rows; [11..13]
   // the row's map into a body's 10-float inertia (byte offsets of columns 0-2 / 3-5, 2-bit signs + 1): see InertiaRowMap
-  float k_tab[6][14];
+  float k_tab[6][20];                   // [14..19]: offsets of the row's six entries inside a packed symmetric 6x6 (ints)
+  float frame9[9];                      // contact frame of the ground plane (n, t1, t2), staged once per launch
+  HotModel hot;
+  float axis[kHasIsym<TP> ? TP::NV : 1][3];   // joint axes in their bodies' frames (star kernels with LDS to spare)
   float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
   // first contact of every body (contacts are sorted by body; <= kMaxCon): ints for the star kernels (the ABA fetches a
   // leg's nine in paired reads), bytes where LDS is what limits residency
@@ -211,6 +230,7 @@ struct AbaHandoff {
 
 struct Frame { V3 n, t1, t2; };
 
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s);
 __device__ __forceinline__ Frame make_frame(V3 n) {
   V3 t = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
   float dn = dot(t, n);
@@ -218,6 +238,10 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
   float l = sqrtf(dot(t1, t1));
   t1 = (1.0f / l) * t1;
   return Frame{n, t1, cross(n, t1)};
+}
+
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s) {
+  return Frame{ld3(&s.frame9[0]), ld3(&s.frame9[3]), ld3(&s.frame9[6])};
 }
 
 template <class TP>
@@ -285,11 +309,13 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.T[0][0]) - 1;    // bodies 1..NB-1: (NB-1) x 12 floats in T..W
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.Ib[0][0]);          // NV x 3 floats (Ib is rebuilt afterwards)
   static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
+  const gptr<float> g_axis = G(s.hot.dof_axis), g_quat = G(s.hot.body_quat), g_pos = G(s.hot.body_pos);
+  auto axis_of = [&](int j) { if constexpr (kHasIsym<TP>) return ld3(s.axis[j]); else return ld3(g_axis + 3 * j); };
   for (int j = 6 + lane; j < s.nv(); j += kWave) {
     float sn, cs;
     sincos_bounded(0.5f * s.qpos[j + 1], &sn, &cs);
-    jq[j][0] = cs; jq[j][1] = m.dof_axis[3 * j] * sn; jq[j][2] = m.dof_axis[3 * j + 1] * sn;
-    jq[j][3] = m.dof_axis[3 * j + 2] * sn;
+    const V3 ax = axis_of(j);
+    jq[j][0] = cs; jq[j][1] = ax.x * sn; jq[j][2] = ax.y * sn; jq[j][3] = ax.z * sn;
   }
   if (lane == 0) {
     Q4 q = qnorm(ldq(&s.qpos[3]));
@@ -306,13 +332,15 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
         static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; if (lb == l) { adr += TP::first_dof(l); num = TP::dofs(l); } });
       } else { adr = tbl_dofadr(s, b); num = tbl_dofnum(s, b); }     // hybrid: the rest of the body (tree part)
     } else { adr = tbl_dofadr(s, b); num = tbl_dofnum(s, b); }
+    const Q4 bq = ldq(g_quat + 4 * b);
+    const V3 bp = ld3(g_pos + 3 * b);
     Q4 P = Q4{1.f, 0.f, 0.f, 0.f};
     for (int j = adr + num - 1; j >= adr; --j) {
-      st3(axb[j], qrot_conj(P, ld3(&m.dof_axis[3 * j])));
+      st3(axb[j], qrot_conj(P, axis_of(j)));
       P = qmul(ldq(jq[j]), P);
     }
-    qmat(relm[b], qnorm(qmul(ldq(&m.body_quat[4 * b]), P)));
-    st3(&relm[b][9], ld3(&m.body_pos[3 * b]));
+    qmat(relm[b], qnorm(qmul(bq, P)));
+    st3(&relm[b][9], bp);
   }
   WSYNC();
   if constexpr (!TP::kStar) tree_kinematics_chain(s, m, lane, relm);
@@ -400,13 +428,12 @@ __device__ __forceinline__ float terrain_kind(int kind, float p0, float p1, floa
                    const float par = sum - 2.f * floorf(sum / 2.f); return par != 0.f ? p1 : 0.f; }
   return 0.f;
 }
-__device__ __forceinline__ float terrain_height(const DevModel& m, float x, float y) {
-  const float* p = m.terrain;
-  if (m.terrain_type == 3) {
+__device__ __forceinline__ float terrain_height(int terrain_type, const float* p, float x, float y) {
+  if (terrain_type == 3) {
     const float st = floorf(x / p[3]); const float k = st - 3.f * floorf(st / 3.f);
     return k == 1.f ? terrain_kind(1, 1.0f, p[1], p[2], x, y) : (k == 2.f ? terrain_kind(2, p[0], 0.35f, 0.f, x, y) : 0.f);
   }
-  return terrain_kind(m.terrain_type, p[0], p[1], p[2], x, y);
+  return terrain_kind(terrain_type, p[0], p[1], p[2], x, y);
 }
 
 // Scratch of the collision stage, overlaid on the T..W region (free between steps)
@@ -429,34 +456,46 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   static_assert(kSlotInTW || 3 * (TP::NB - 1) + 2 * kWave <= 7 * kMaxCon, "slot table (128 geoms) does not fit");
   int* geom_slot0 = kSlotInTW ? reinterpret_cast<int*>(&s.T[0][0]) + sizeof(CollisionScratch) / sizeof(int)
                               : reinterpret_cast<int*>(&s.c_w[0][0]) + 3 * (TP::NB - 1);
-  const V3 n = v3(m.plane[0], m.plane[1], m.plane[2]);
-  const float pd = m.plane[3];
+  // the model's side of this stage, staged in LDS at launch (see HotModel): scalars once, arrays as global memory
+  const HotModel& hm = s.hot;
+  const int ng = hm.ng, terrain_type = hm.terrain_type, max_hull_contacts = hm.sem_max_hull_contacts;
+  const float hull_skin = hm.hull_skin, terrain_top = hm.terrain[4];
+  const float tpar[4] = {hm.terrain[0], hm.terrain[1], hm.terrain[2], hm.terrain[3]};
+  const gptr<int> geom_body = G(hm.geom_body), geom_type = G(hm.geom_type), geom_hulladr = G(hm.geom_hulladr),
+                  geom_hullnum = G(hm.geom_hullnum);
+  const gptr<float> pair_margin = G(hm.pair_margin), geom_bsphere = G(hm.geom_bsphere), geom_radius = G(hm.geom_radius),
+                    geom_p0 = G(hm.geom_p0), geom_p1 = G(hm.geom_p1), hull_vert = G(hm.hull_vert);
+  const V3 n = ld3(hm.plane);
+  const float pd = hm.plane[3];
   const V3 o = ld3(s.xpos()[0]);
+  const bool rough = terrain_type != 0;
   // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
   // (more than 64 contact geoms — e.g. every body segment in contact — take further passes of 64)
   int nh = 0, slot_base = 0;
-  for (int g0 = 0; g0 < m.ng; g0 += kWave) {
+  for (int g0 = 0; g0 < ng; g0 += kWave) {
   const int gi = g0 + lane;
   int g_body = 0, g_type = -1, g_hadr = 0, g_hnum = 0, cnt = 0;
   float g_margin = 0.f, cd0 = 0.f, cd1 = 0.f;
   V3 cp0 = v3(0, 0, 0), cp1 = v3(0, 0, 0);
   bool near = false;
-  if (gi < m.ng) {
-    g_body = m.geom_body[gi]; g_type = m.geom_type[gi]; g_margin = m.pair_margin[gi];
-    g_hadr = m.geom_hulladr[gi]; g_hnum = m.geom_hullnum[gi];
+  if (gi < ng) {
+    g_body = geom_body[gi]; g_type = geom_type[gi]; g_margin = pair_margin[gi];
+    g_hadr = geom_hulladr[gi]; g_hnum = geom_hullnum[gi];
+    const V3 bs = ld3(geom_bsphere + 4 * gi);
+    const float bs_r = geom_bsphere[4 * gi + 3], rad = geom_radius[gi];
+    const V3 l0 = ld3(geom_p0 + 3 * gi), l1 = ld3(geom_p1 + 3 * gi);
     const float* R = s.xmat()[g_body];
     const V3 xp = ld3(s.xpos()[g_body]);
-    V3 cw = mat_vec(R, ld3(&m.geom_bsphere[4 * gi]));
+    V3 cw = mat_vec(R, bs);
     float dc = dot(n, cw) + dot(n, xp) - pd;
-    near = dc - m.geom_bsphere[4 * gi + 3] - m.terrain[4] <= g_margin;
-    const float rad = m.geom_radius[gi];
-    const V3 p0 = mat_vec(R, ld3(&m.geom_p0[3 * gi])) + xp, p1 = mat_vec(R, ld3(&m.geom_p1[3 * gi])) + xp;
+    near = dc - bs_r - terrain_top <= g_margin;
+    const V3 p0 = mat_vec(R, l0) + xp, p1 = mat_vec(R, l1) + xp;
     float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
     // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's
     // reach but above its own thickness needs no vertex scan
-    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - m.terrain[4] <= g_margin;
+    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - terrain_top <= g_margin;
     if (near && g_type == GEOM_CAPSULE) {
-      if (m.terrain_type) { d0 -= terrain_height(m, p0.x, p0.y); d1 -= terrain_height(m, p1.x, p1.y); }
+      if (rough) { d0 -= terrain_height(terrain_type, tpar, p0.x, p0.y); d1 -= terrain_height(terrain_type, tpar, p1.x, p1.y); }
       const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
       if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
       if (d1 <= g_margin) { if (cnt) { cd1 = d1; cp1 = q1; } else { cd0 = d1; cp0 = q1; } cnt++; }
@@ -464,23 +503,25 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   }
   // ---- phase 2: near convex hulls one after the other, each scanned by the whole wave; the geom's
   // parameters are broadcast from its lane's registers (no memory round trip)
+  // (measured and dropped: holding a hull's vertices and distances in registers across the four scans, and handing the
+  // few patch candidates over through LDS — same rate on flat ground, where the tarsal capsules make the contacts, and
+  // 3-8 % slower over relief: six slots per lane whatever the hull's size, and 40 more callee-saved registers)
   unsigned long long hmask = __ballot(near && g_type == GEOM_HULL);
   while (hmask) {
     const int g = __ffsll((long long)hmask) - 1;
     hmask &= hmask - 1;
     const int b = __builtin_amdgcn_readlane(g_body, g);
     const float margin = readlane_f(g_margin, g);
-    const float* V = m.hull_vert + 3 * __builtin_amdgcn_readlane(g_hadr, g);
+    const gptr<float> V = hull_vert + 3 * __builtin_amdgcn_readlane(g_hadr, g);
     const int nvv = __builtin_amdgcn_readlane(g_hnum, g);
     const float* R = s.xmat()[b];
     const V3 xp = ld3(s.xpos()[b]);
     const V3 nb = matT_vec(R, n);
     const float c0 = dot(n, xp) - pd;
-    const bool rough = m.terrain_type != 0;
     // distance of a hull vertex to the ground under it (flat ground: the plane distance)
     auto vdist = [&](V3 v) {
       float di = dot(nb, v) + c0;
-      if (rough) { const V3 pw = mat_vec(R, v) + xp; di -= terrain_height(m, pw.x, pw.y); }
+      if (rough) { const V3 pw = mat_vec(R, v) + xp; di -= terrain_height(terrain_type, tpar, pw.x, pw.y); }
       return di;
     };
     float best = INFINITY; int bi = 0x7fffffff;
@@ -491,7 +532,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
     wave_argmin(best, bi);
     const float dmin = best; const int ia = bi;
     if (!(dmin <= margin)) continue;
-    const float thr = fminf(dmin + m.hull_skin, margin);
+    const float thr = fminf(dmin + hull_skin, margin);
     int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
     const V3 va = ld3(V + 3 * ia);
     // b: farthest candidate from a
@@ -533,7 +574,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
         if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
       }
     }
-    nsel = nsel < m.sem_max_hull_contacts ? nsel : m.sem_max_hull_contacts;
+    nsel = nsel < max_hull_contacts ? nsel : max_hull_contacts;
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
@@ -789,21 +830,43 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
   Uout = mask * U; uout = u; invDout = invD;
 }
 // the same for the leg chains of the star sweeps, whose back-substitution needs (u - U.a) / D only: hands back U / D and
-// u / D (one register per dof less to keep, one multiply per dof less in the forward sweep)
-__device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sown, float mask, float delta,
+// u / D (one register per dof less to keep, one multiply per dof less in the forward sweep).  `sr` is the lane's own axis
+// component with the shadow rows already zero.  SHADOW0: the forward sweep keeps its accelerations zero in the shadow
+// rows, so U / D needs no mask either.
+template <bool SHADOW0>
+__device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
                                                 float tauj, float& UDout, float& uDout) {
-  float U, u, invD;
-  aba_step(IA, pA, sj, sown, mask, delta, tauj, U, u, invD);
-  UDout = U * invD; uDout = u * invD;
+  const float U = (IA[0] * sj[0] + IA[1] * sj[1]) + (IA[2] * sj[2] + IA[3] * sj[3]) + (IA[4] * sj[4] + IA[5] * sj[5]);
+  const float D = grp8_sum(sr * U) + delta;
+  const float sp = grp8_sum(sr * pA);
+  const float invD = __builtin_amdgcn_rcpf(D);
+  const float u = tauj - sp;
+  const float k = U * invD;
+  IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
+  IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
+  pA += k * u;
+  UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
+}
+// LDS pointer whose value the optimizer may not look through: the accesses made from it carry their (small, constant)
+// offsets in the instruction — a ds_read2 reaches 255 dwords — instead of one address add per access pair, which is what
+// `big constant array offset + lane-dependent row` turns into
+typedef const __attribute__((address_space(3))) float* lds_cptr;
+template <class T>
+__device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
+  lds_cptr q = (lds_cptr)(const void*)p;
+  asm("" : "+v"(q));
+  return q;
 }
 
 template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
                           const DevModel& m, int lane) {
   if constexpr (!TP::kStar) { tree_aba_solve<TP, WELD>(s, tau_id, x_id, withK, hdamp, m, lane); return; } else {
+  withK = __builtin_amdgcn_readfirstlane((int)withK) != 0;          // wave-uniform: scalar branches, no exec masking
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
-  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  Frame fr{};
+  if (withK) fr = ld_frame(s);
   const LaneRole L = lane_role<TP>(lane);
   const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
@@ -811,16 +874,20 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // offsets of row rr inside a symmetric 6x6's packed storage (lane constants; the hybrid kernels' hand-off slots)
   int so[6];
 #pragma unroll
-  for (int c = 0; c < 6; c++) {
-    const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr;
-    so[c] = i * 6 - i * (i - 1) / 2 + (jx - i);
-  }
+  for (int c = 0; c < 6; c++) so[c] = __float_as_int(s.k_tab[L.rr][14 + c]);
   InertiaRowMap IM{};                                              // this lane's row of a body's 6x6 inertia, read out of Ib
   if constexpr (!kHasIsym<TP>) IM = inertia_map_unpack(s.k_tab[L.rr]);
   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
   // forward sweep instead of keeping it: 24 registers fewer to spill
   constexpr bool kKeepS = TP::NDL <= 16;
   float Ureg[TP::NDL], ureg[TP::NDL], Sreg[kKeepS ? TP::NDL : 1];        // U / D (this lane's row), u / D, own axis component
+  // Shadow rows (r = 6, 7).  Where S and T have a padding column (S's is zeroed at launch) they read their axis
+  // component from it and keep the acceleration sweep's value there: zero contributions to every group sum without a
+  // mask multiply per dof.  Without padding they shadow row 5 and the sums are masked.
+  constexpr bool kShadow0 = row_width_s<TP>() > 6 && row_width_tw<TP>() > 6;
+  const int rS = kShadow0 && L.r >= 6 ? 6 : L.rr;
+  const lds_cptr Sleg = lds_pinned(&s.S[j0][0]), Sown = lds_pinned(&s.S[j0][rS]);
+  constexpr int SW = row_width_s<TP>();
   KLane KL;                             // contact stiffness rows: per-row constants from the launch's table
   if (withK) {
     const float* q = s.k_tab[L.rr];
@@ -872,10 +939,11 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     }
     float sj[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) sj[i] = s.S[j][i];
-    const float sown = s.S[j][L.rr];
-    if constexpr (kKeepS) Sreg[d] = sown;
-    aba_step_scaled(IA, pA, sj, sown, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d]);
+    for (int i = 0; i < 6; i++) sj[i] = Sleg[d * SW + i];
+    const float sown = Sown[d * SW];
+    const float sr = kShadow0 ? sown : L.mask * sown;
+    if constexpr (kKeepS) Sreg[d] = sown;        // shadow rows: zero (kShadow0), else row 5's (same T word, same value)
+    aba_step_scaled<kShadow0>(IA, pA, sj, sr, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d]);
   });
 #pragma unroll
   for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
@@ -942,7 +1010,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       const float k = U * invD;
       IA[0] -= k * b0; IA[1] -= k * b1; IA[2] -= k * b2; IA[3] -= k * b3; IA[4] -= k * b4; IA[5] -= k * b5;
       pA += k * u;
-      Ur[e] = L.mask * k; ur[e] = u * invD;
+      Ur[e] = kShadow0 ? k : L.mask * k; ur[e] = u * invD;
     });
   }
   // ---- forward sweep: root (linear x, y, z, then angular x, y, z), then down the leg
@@ -954,7 +1022,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       constexpr int e = i < 3 ? 3 + i : i - 3;
       const float xe = ur[e] - grp8_sum(Ur[e] * a);
       xw[e] = xe;
-      a = L.rr == e ? a + xe : a;
+      a = (kShadow0 ? L.r : L.rr) == e ? a + xe : a;
     });
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -962,14 +1030,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       x[3 + k] = Rm[0][k] * xw[0] + Rm[1][k] * xw[1] + Rm[2][k] * xw[2];
     }
   }
-  s.T[0][L.rr] = a;
+  s.T[0][rS] = a;
   static_for<TP::NDL>([&](auto DD) {
     constexpr int d = decltype(DD)::value;
     const int j = j0 + d;
     const float xj = ureg[d] - grp8_sum(Ureg[d] * a);
     x[j] = xj;
-    if constexpr (kKeepS) a += xj * Sreg[d]; else a += xj * s.S[j][L.rr];
-    if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
+    if constexpr (kKeepS) a += xj * Sreg[d]; else a += xj * Sown[d * SW];
+    if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][rS] = a;
   });
   WSYNC();
   SUB(19);
@@ -1655,6 +1723,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
   const int lane = threadIdx.x;
   STAGE_INIT();
   for (int j = lane; j < s.nv(); j += kWave) {
+    if constexpr (row_width_s<TP>() > 6) s.S[j][6] = 0.f;      // padding column: the shadow rows' axis component (aba_solve)
     s.arm[j] = m.dof_armature[j];
     if constexpr (kHasCm3<TP>) { s.damp[j] = m.dof_damping[j]; s.dlt[j] = m.dof_armature[j] + m.timestep * m.dof_damping[j]; }
   }
@@ -1667,7 +1736,26 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     int words[3];
     inertia_map_pack(lane, words);
     q[11] = __int_as_float(words[0]); q[12] = __int_as_float(words[1]); q[13] = __int_as_float(words[2]);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const int i = lane < c ? lane : c, jx = lane < c ? c : lane;
+      q[14 + c] = __int_as_float(i * 6 - i * (i - 1) / 2 + (jx - i));
+    }
   }
+  if (lane == 0) {
+    const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+    st3(&s.frame9[0], fr.n); st3(&s.frame9[3], fr.t1); st3(&s.frame9[6], fr.t2);
+    HotModel& h = s.hot;
+    h.dof_axis = m.dof_axis; h.body_pos = m.body_pos; h.body_quat = m.body_quat; h.geom_p0 = m.geom_p0; h.geom_p1 = m.geom_p1;
+    h.geom_radius = m.geom_radius; h.geom_bsphere = m.geom_bsphere; h.hull_vert = m.hull_vert; h.pair_margin = m.pair_margin;
+    h.geom_body = m.geom_body; h.geom_type = m.geom_type; h.geom_hulladr = m.geom_hulladr; h.geom_hullnum = m.geom_hullnum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h.plane[i] = m.plane[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) h.terrain[i] = m.terrain[i];
+    h.hull_skin = m.hull_skin; h.terrain_type = m.terrain_type; h.ng = m.ng; h.sem_max_hull_contacts = m.sem_max_hull_contacts;
+  }
+  if constexpr (kHasIsym<TP>) for (int i = lane; i < 3 * s.nv(); i += kWave) (&s.axis[0][0])[i] = m.dof_axis[i];
   // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps and exits.  Chunked
   // launches (more worlds than resident waves): the launch is cut into n_chunks chunks (long first, short last), the grid is
   // one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket counter until the
