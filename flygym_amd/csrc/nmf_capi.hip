@@ -154,15 +154,16 @@ int upload(nmf_batch* b, const std::vector<T>& host, const T** dev) {
   return 0;
 }
 
-int upload_f(nmf_batch* b, const char* name, const float** dev) {
+// `slot`: address of a DevModel pointer member (the device pass of this file sees those typed as global memory, NMF_G)
+int upload_f(nmf_batch* b, const char* name, void* slot) {
   const HostArray* a = b->model->find(name);
   if (!a || a->is_int) return fail(std::string("model lacks float entry ") + name);
-  return upload(b, a->f, dev);
+  return upload(b, a->f, static_cast<const float**>(slot));
 }
-int upload_i(nmf_batch* b, const char* name, const int** dev) {
+int upload_i(nmf_batch* b, const char* name, void* slot) {
   const HostArray* a = b->model->find(name);
   if (!a || !a->is_int) return fail(std::string("model lacks int entry ") + name);
-  return upload(b, a->i, dev);
+  return upload(b, a->i, static_cast<const int**>(slot));
 }
 
 int alloc_field(nmf_batch* b, int field, int width, float** out) {
@@ -324,8 +325,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     d.sem_max_hull_contacts = so->i[3] >= 1 && so->i[3] <= 4 ? so->i[3] : 4; }
   { const HostArray* tt = model->find("terrain_type"); d.terrain_type = tt && tt->is_int && !tt->i.empty() ? tt->i[0] : 0; }
   int rc = 0;
-#define UF(n) rc |= upload_f(b, #n, &d.n)
-#define UI(n) rc |= upload_i(b, #n, &d.n)
+#define UF(n) rc |= upload_f(b, #n, (void*)&d.n)
+#define UI(n) rc |= upload_i(b, #n, (void*)&d.n)
   UF(body_pos); UF(body_quat); UF(body_mass); UF(body_ipos); UF(body_inertia);
   UI(body_dofadr); UI(body_dofnum); UI(dof_body);
   UF(dof_axis); UF(dof_armature); UF(dof_damping); UF(dof_stiffness); UF(dof_springref);
@@ -339,10 +340,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
 #undef UI
   if (topo >= 2) {
     const HostArray* bp = model->find("body_parent");
-    rc |= upload(b, bp->i, &d.body_parent);
-    rc |= upload(b, tree_body, &d.tree_body);
-    rc |= upload(b, child_start, &d.tree_child_start);
-    rc |= upload(b, child_count, &d.tree_child_count);
+    rc |= upload(b, bp->i, reinterpret_cast<const int**>((void*)&d.body_parent));
+    rc |= upload(b, tree_body, reinterpret_cast<const int**>((void*)&d.tree_body));
+    rc |= upload(b, child_start, reinterpret_cast<const int**>((void*)&d.tree_child_start));
+    rc |= upload(b, child_count, reinterpret_cast<const int**>((void*)&d.tree_child_count));
     d.tree_nlevel = (int)lvl_start.size() - 1;
     for (size_t k = 0; k < 18; ++k) d.tree_lvl_start[k] = k < lvl_start.size() ? lvl_start[k] : (int)tree_body.size();
     d.rest_fast = 0; d.rest_pack = nullptr;
@@ -363,7 +364,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
           pack[(size_t)((lv - 1) * 8 + (k - k0)) * 2 + 1] = child_start[(size_t)bb] | (k << 8);
         }
       }
-      if (fast) { d.rest_fast = 1; const int* pp = nullptr; rc |= upload(b, pack, &pp); d.rest_pack = reinterpret_cast<const unsigned int*>(pp); }
+      if (fast) { d.rest_fast = 1; const int* pp = nullptr; rc |= upload(b, pack, &pp); *reinterpret_cast<const int**>((void*)&d.rest_pack) = pp; }
     }
   } else {
     d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0; d.rest_fast = 0; d.rest_pack = nullptr;

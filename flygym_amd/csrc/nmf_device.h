@@ -79,6 +79,14 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
+// Device-side view of pointers into HBM: typed as global memory, so that loads through them are global_load (own counter,
+// SGPR base) instead of flat_load (LDS-aperture check, waits tied to the LDS counter).  The host sees plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NMF_G __attribute__((address_space(1)))
+#else
+#define NMF_G
+#endif
+
 struct DevModel {
   int nb, nv, nq, nu, ng, nseg, nsite, nsensor, max_iter;
   float timestep, tolerance, hull_skin, meaninertia;
@@ -88,30 +96,30 @@ struct DevModel {
   float weld_pos[3], weld_quat[4], weld_solref[2], weld_solimp[5], weld_invweight[2];
   int terrain_type;         // 0 flat, 1 gapped, 2 blocks, 3 mixed
   float terrain[5];         // parameters + maximum height (see flygym_amd/compose/world.py)
-  const float *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
-  const int *body_dofadr, *body_dofnum, *dof_body;
+  const NMF_G float *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
+  const NMF_G int *body_dofadr, *body_dofnum, *dof_body;
   // general-tree kernel only: bodies in breadth-first order (level by level, children of a body contiguous)
-  const int *body_parent, *tree_body, *tree_child_start, *tree_child_count;   // child ranges index tree_body
+  const NMF_G int *body_parent, *tree_body, *tree_child_start, *tree_child_count;   // child ranges index tree_body
   int tree_nlevel, tree_lvl_start[18];
   // hybrid kernels, fast level passes: every body of the rest has exactly three dofs, at most kRestLevels levels of at
   // most 8 bodies.  rest_pack[level - 1][group][2]: body | parent << 8 | first dof << 16 | children << 24,
   // first child (breadth-first slot) | own breadth-first slot << 8;  0xffffffff = no body for that group
   int rest_fast;
-  const unsigned int* rest_pack;
-  const float *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
-  const int* seg_body;
-  const float *seg_pos, *seg_quat;
-  const int* site_body;
-  const float* site_pos;
-  const int *act_type, *act_trn, *act_limited;
-  const int* act_geom;      // adhesion actuators: contact geom of the adhesion segment (-1: none)
+  const NMF_G unsigned int* rest_pack;
+  const NMF_G float *dof_axis, *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
+  const NMF_G int* seg_body;
+  const NMF_G float *seg_pos, *seg_quat;
+  const NMF_G int* site_body;
+  const NMF_G float* site_pos;
+  const NMF_G int *act_type, *act_trn, *act_limited;
+  const NMF_G int* act_geom;      // adhesion actuators: contact geom of the adhesion segment (-1: none)
   // named engine semantics (blob entry sem_options; flygym_amd.compiler.model.EngineSemantics), shared with the oracle
   int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
-  const float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
-  const float *key_qpos, *key_ctrl;
-  const int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
-  const float *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
-  const float *pair_friction, *pair_solref, *pair_solimp, *pair_margin;
+  const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
+  const NMF_G float *key_qpos, *key_ctrl;
+  const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
+  const NMF_G float *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
+  const NMF_G float *pair_friction, *pair_solref, *pair_solimp, *pair_margin;
 };
 
 struct DevState {
