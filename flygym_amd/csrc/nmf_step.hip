@@ -127,6 +127,7 @@ struct HotModel {
   float plane[4], terrain[5], hull_skin;
   int terrain_type, ng, sem_max_hull_contacts;
 };
+template <class TP> struct FlyLds;
 template <class T> using gptr = const __attribute__((address_space(1))) T*;
 template <class T> __device__ __forceinline__ gptr<T> G(const T* p) { return (gptr<T>)p; }
 __device__ __forceinline__ V3 ld3(gptr<float> p) { return V3{p[0], p[1], p[2]}; }
@@ -177,9 +178,12 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float c_m3[kHasCm3<TP> ? kMaxCon : 1][5];
   // per row index r of a 6x6 (staged once per launch): [0..10] KLane constants of the contact stiffness rows; [11..13]
   // the row's map into a body's 10-float inertia (byte offsets of columns 0-2 / 3-5, 2-bit signs + 1): see InertiaRowMap
-  float k_tab[6][20];                   // [14..19]: offsets of the row's six entries inside a packed symmetric 6x6 (ints)
-  float frame9[9];                      // contact frame of the ground plane (n, t1, t2), staged once per launch
-  HotModel hot;
+  // [14..19]: offsets of the row's six entries inside a packed symmetric 6x6 (ints).  The launch-constant conveniences
+  // from here to `axis` exist in the star kernels with LDS to spare only: the hybrid / tree kernels are LDS-bound (one
+  // more 512-byte granule is one fly per CU less) and derive the same values from the model when they need them.
+  float k_tab[6][kHasIsym<TP> ? 20 : 14];
+  float frame9[kHasIsym<TP> ? 9 : 1];   // contact frame of the ground plane (n, t1, t2), staged once per launch
+  std::conditional_t<kHasIsym<TP>, HotModel, char> hot;
   float axis[kHasIsym<TP> ? TP::NV : 1][3];   // joint axes in their bodies' frames (star kernels with LDS to spare)
   float weldD[6], weld_w[6];            // tether weld: row stiffness 1/R and row wrench (zero without a tether)
   // first contact of every body (contacts are sorted by body; <= kMaxCon): ints for the star kernels (the ABA fetches a
@@ -201,6 +205,24 @@ struct __align__(16) FlyLds : TreeLds<TP> {
     }
   }
 };
+// the staged copy where there is one, else the same fields gathered from the model
+template <class TP> __device__ __forceinline__ HotModel hot_model(const FlyLds<TP>& s, const DevModel& m) {
+  if constexpr (kHasIsym<TP>) return s.hot;
+  else {
+    HotModel h;
+    h.dof_axis = (const float*)m.dof_axis; h.body_pos = (const float*)m.body_pos; h.body_quat = (const float*)m.body_quat;
+    h.geom_p0 = (const float*)m.geom_p0; h.geom_p1 = (const float*)m.geom_p1; h.geom_radius = (const float*)m.geom_radius;
+    h.geom_bsphere = (const float*)m.geom_bsphere; h.hull_vert = (const float*)m.hull_vert; h.pair_margin = (const float*)m.pair_margin;
+    h.geom_body = (const int*)m.geom_body; h.geom_type = (const int*)m.geom_type; h.geom_hulladr = (const int*)m.geom_hulladr;
+    h.geom_hullnum = (const int*)m.geom_hullnum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h.plane[i] = m.plane[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) h.terrain[i] = m.terrain[i];
+    h.hull_skin = m.hull_skin; h.terrain_type = m.terrain_type; h.ng = m.ng; h.sem_max_hull_contacts = m.sem_max_hull_contacts;
+    return h;
+  }
+}
 template <class TP> __device__ __forceinline__ float dof_damp(const FlyLds<TP>& s, const DevModel& m, int j) {
   if constexpr (kHasCm3<TP>) return s.damp[j]; else return m.dof_damping[j];
 }
@@ -230,7 +252,7 @@ struct AbaHandoff {
 
 struct Frame { V3 n, t1, t2; };
 
-template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s);
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const DevModel& m);
 __device__ __forceinline__ Frame make_frame(V3 n) {
   V3 t = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
   float dn = dot(t, n);
@@ -240,8 +262,9 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
   return Frame{n, t1, cross(n, t1)};
 }
 
-template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s) {
-  return Frame{ld3(&s.frame9[0]), ld3(&s.frame9[3]), ld3(&s.frame9[6])};
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const DevModel& m) {
+  if constexpr (sizeof(s.frame9) == 9 * sizeof(float)) return Frame{ld3(&s.frame9[0]), ld3(&s.frame9[3]), ld3(&s.frame9[6])};
+  else return make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
 }
 
 template <class TP>
@@ -309,7 +332,8 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
   float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.T[0][0]) - 1;    // bodies 1..NB-1: (NB-1) x 12 floats in T..W
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.Ib[0][0]);          // NV x 3 floats (Ib is rebuilt afterwards)
   static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
-  const gptr<float> g_axis = G(s.hot.dof_axis), g_quat = G(s.hot.body_quat), g_pos = G(s.hot.body_pos);
+  const HotModel hmk = hot_model(s, m);
+  const gptr<float> g_axis = G(hmk.dof_axis), g_quat = G(hmk.body_quat), g_pos = G(hmk.body_pos);
   auto axis_of = [&](int j) { if constexpr (kHasIsym<TP>) return ld3(s.axis[j]); else return ld3(g_axis + 3 * j); };
   for (int j = 6 + lane; j < s.nv(); j += kWave) {
     float sn, cs;
@@ -457,7 +481,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, i
   int* geom_slot0 = kSlotInTW ? reinterpret_cast<int*>(&s.T[0][0]) + sizeof(CollisionScratch) / sizeof(int)
                               : reinterpret_cast<int*>(&s.c_w[0][0]) + 3 * (TP::NB - 1);
   // the model's side of this stage, staged in LDS at launch (see HotModel): scalars once, arrays as global memory
-  const HotModel& hm = s.hot;
+  const HotModel hm = hot_model(s, m);
   const int ng = hm.ng, terrain_type = hm.terrain_type, max_hull_contacts = hm.sem_max_hull_contacts;
   const float hull_skin = hm.hull_skin, terrain_top = hm.terrain[4];
   const float tpar[4] = {hm.terrain[0], hm.terrain[1], hm.terrain[2], hm.terrain[3]};
@@ -866,7 +890,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   Frame fr{};
-  if (withK) fr = ld_frame(s);
+  if (withK) fr = ld_frame(s, m);
   const LaneRole L = lane_role<TP>(lane);
   const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
@@ -874,7 +898,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   // offsets of row rr inside a symmetric 6x6's packed storage (lane constants; the hybrid kernels' hand-off slots)
   int so[6];
 #pragma unroll
-  for (int c = 0; c < 6; c++) so[c] = __float_as_int(s.k_tab[L.rr][14 + c]);
+  for (int c = 0; c < 6; c++) {
+    if constexpr (kHasIsym<TP>) so[c] = __float_as_int(s.k_tab[L.rr][14 + c]);
+    else { const int i = L.rr < c ? L.rr : c, jx = L.rr < c ? c : L.rr; so[c] = i * 6 - i * (i - 1) / 2 + (jx - i); }
+  }
   InertiaRowMap IM{};                                              // this lane's row of a body's 6x6 inertia, read out of Ib
   if constexpr (!kHasIsym<TP>) IM = inertia_map_unpack(s.k_tab[L.rr]);
   // this lane's row of U_j, S_j; group-uniform u_j, 1/D_j.  Long chains (ALL_POSSIBLE: 24 dofs per leg) re-read S_j in the
@@ -1395,6 +1422,13 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
         WSYNC();
       }
     } }
+    // candidate 2 (the unconstrained acceleration) first: its body twists are what the smooth solve left in T
+    float j0[4] = {0.f, 0.f, 0.f, 0.f}, w0 = 0.f, v0 = 0.f;
+    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), j0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { j0[k] -= c.aref[k]; if (j0[k] < 0.f) v0 += 0.5f * c.D * j0[k] * j0[k]; } }
+    if (wr.on) { w0 = s.T[0][wr.comp] - wr.aref; v0 += 0.5f * wr.D * w0 * w0; }
+    WSYNC();
     // candidate 1: warm start
     float g = 0.f;
     if (red) {
@@ -1417,15 +1451,8 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
     }
     float gauss = wave_sum(g), ccost = 0.f;
     if (!red) ccost = constraint_cost<TP>(c, wr);
-    // candidate 2: unconstrained acceleration
-    sweep_twists(s, s.qacc_smooth, s.T, m, lane);
     {
-      float j0[4] = {0.f, 0.f, 0.f, 0.f}, w0 = 0.f;
-      float v = 0.f;
-      if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), j0);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { j0[k] -= c.aref[k]; if (j0[k] < 0.f) v += 0.5f * c.D * j0[k] * j0[k]; } }
-      if (wr.on) { w0 = s.T[0][wr.comp] - wr.aref; v += 0.5f * wr.D * w0 * w0; }
+      const float v = v0;
       if (red) {
 #pragma unroll
         for (int k = 0; k < 4; k++) c.jar[k] += j0[k];
@@ -1736,13 +1763,15 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     int words[3];
     inertia_map_pack(lane, words);
     q[11] = __int_as_float(words[0]); q[12] = __int_as_float(words[1]); q[13] = __int_as_float(words[2]);
+    if constexpr (kHasIsym<TP>) {
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const int i = lane < c ? lane : c, jx = lane < c ? c : lane;
-      q[14 + c] = __int_as_float(i * 6 - i * (i - 1) / 2 + (jx - i));
+      for (int c = 0; c < 6; c++) {
+        const int i = lane < c ? lane : c, jx = lane < c ? c : lane;
+        q[14 + c] = __int_as_float(i * 6 - i * (i - 1) / 2 + (jx - i));
+      }
     }
   }
-  if (lane == 0) {
+  if constexpr (kHasIsym<TP>) if (lane == 0) {
     const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
     st3(&s.frame9[0], fr.n); st3(&s.frame9[3], fr.t1); st3(&s.frame9[6], fr.t2);
     HotModel& h = s.hot;

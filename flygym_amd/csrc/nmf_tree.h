@@ -448,7 +448,7 @@ template <class TP, bool WELD>
 __device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane) {
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
-  const Frame fr = ld_frame(s);
+  const Frame fr = ld_frame(s, m);
   tree_up(s, lane, [&](int b) { tree_aba_eliminate_body<TP, WELD>(s, b, tau, withK, hdamp, m, fr); });
   if (lane == 0) tree_aba_eliminate_body<TP, WELD>(s, 0, tau, withK, hdamp, m, fr);
   WSYNC();

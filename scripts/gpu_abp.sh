@@ -1,0 +1,13 @@
+#!/bin/bash
+# kernel A/B on the GPU box over prebuilt variants on another skeleton: gpu_abp.sh <joint preset> <variant>...
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+P=$1; shift
+for lib in "$@"; do
+  export NMF_HIP_LIB=$PWD/build/libnmf_$lib.so
+  timeout 300 python bench.py --no-cpu-baseline --joint-preset $P 2>/dev/null | grep '^{"metric"' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print('$lib', '$P', round(d['value'] / 1e6, 2), 'M', 'ms/launch', round(d['roofline']['kernel_ms_per_launch'], 3), 'contacts', round(c['mean_contacts'], 2), 'iters', round(c['mean_newton_iters'], 2), 'valid', d.get('valid'))"
+done > gpurun_out/abp_$P.log 2>&1
+cat gpurun_out/abp_$P.log
