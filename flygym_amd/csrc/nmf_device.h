@@ -122,6 +122,8 @@ struct DevModel {
   const NMF_G float *pair_friction, *pair_solref, *pair_solimp, *pair_margin;
 };
 
+using GModel = NMF_G DevModel;   // the model as the device functions see it (global memory)
+
 struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,

@@ -206,7 +206,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   }
 };
 // the staged copy where there is one, else the same fields gathered from the model
-template <class TP> __device__ __forceinline__ HotModel hot_model(const FlyLds<TP>& s, const DevModel& m) {
+template <class TP> __device__ __forceinline__ HotModel hot_model(const FlyLds<TP>& s, const GModel& m) {
   if constexpr (kHasIsym<TP>) return s.hot;
   else {
     HotModel h;
@@ -223,11 +223,11 @@ template <class TP> __device__ __forceinline__ HotModel hot_model(const FlyLds<T
     return h;
   }
 }
-template <class TP> __device__ __forceinline__ float dof_damp(const FlyLds<TP>& s, const DevModel& m, int j) {
+template <class TP> __device__ __forceinline__ float dof_damp(const FlyLds<TP>& s, const GModel& m, int j) {
   if constexpr (kHasCm3<TP>) return s.damp[j]; else return m.dof_damping[j];
 }
 // diagonal term of an articulated-body solve: armature + hdamp * damping (hdamp = 0 except in the Euler step's solve)
-template <class TP> __device__ __forceinline__ float dof_delta(const FlyLds<TP>& s, const DevModel& m, int j, float hdamp) {
+template <class TP> __device__ __forceinline__ float dof_delta(const FlyLds<TP>& s, const GModel& m, int j, float hdamp) {
   if constexpr (kHasCm3<TP>) return (hdamp != 0.f ? s.dlt : s.arm)[j];        // hdamp is 0 or the timestep
   else return hdamp != 0.f ? fmaf(hdamp, m.dof_damping[j], s.arm[j]) : s.arm[j];
 }
@@ -252,7 +252,7 @@ struct AbaHandoff {
 
 struct Frame { V3 n, t1, t2; };
 
-template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const DevModel& m);
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const GModel& m);
 __device__ __forceinline__ Frame make_frame(V3 n) {
   V3 t = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
   float dn = dot(t, n);
@@ -262,7 +262,7 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
   return Frame{n, t1, cross(n, t1)};
 }
 
-template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const DevModel& m) {
+template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const GModel& m) {
   if constexpr (sizeof(s.frame9) == 9 * sizeof(float)) return Frame{ld3(&s.frame9[0]), ld3(&s.frame9[3]), ld3(&s.frame9[6])};
   else return make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
 }
@@ -294,30 +294,30 @@ __device__ __forceinline__ LaneRole lane_role(int lane) {
 }
 
 // general-tree sweeps (nmf_tree.h, included at the end of this file)
-template <class TP> __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]);
-template <class TP> __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane);
-template <class TP> __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane);
+template <class TP> __device__ void tree_kinematics_chain(FlyLds<TP>& s, const GModel& m, int lane, float (*relm)[12]);
+template <class TP> __device__ void tree_velocity_bias(FlyLds<TP>& s, const GModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const GModel& m, int lane);
 template <class TP, class Extra, class Emit>
-__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra, Emit&& emit);
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const GModel& m, int lane, Extra&& extra, Emit&& emit);
 template <class TP, bool WELD>
-__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane);
-template <class TP> __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane);
-template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane);
+__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const GModel& m, int lane);
+template <class TP> __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const GModel& m, int lane);
+template <class TP> __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const GModel& m, int lane);
 template <class TP, class Extra>
-__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra);
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const GModel& m, int lane, Extra&& extra);
 template <class S, class F> __device__ __forceinline__ void tree_down(const S& s, int lane, F&& f);
 template <class S, class F> __device__ __forceinline__ void tree_up(const S& s, int lane, F&& f);
 struct Frame;
 template <class TP, bool WELD>
 __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
-                                                        const DevModel& m, const Frame& fr);
+                                                        const GModel& m, const Frame& fr);
 template <class TP>
-__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m);
+__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const GModel& m);
 struct RestNode;
 template <class TP, bool FAST, bool UP, class F> __device__ __forceinline__ void rest_levels(FlyLds<TP>& s, int lane, F&& f);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM, const DevModel& m);
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM, const GModel& m);
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
 template <class TP, int NUM, bool HOMOGENEOUS>
@@ -325,7 +325,7 @@ __device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& n
 
 // ------------------------------------------------------------------ kinematics
 template <class TP>
-__device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const GModel& m, int lane) {
   // scratch (dead between steps): joint quaternions in the solver vectors, per-body relative
   // rotation matrices + offsets in the ABA hand-off buffer, body-frame hinge axes in T
   float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.vA[0]);            // NV x 4 floats = vA..vD
@@ -413,7 +413,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const DevModel& m, 
 }
 
 template <class TP>
-__device__ void stage_inertia(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ void stage_inertia(FlyLds<TP>& s, const GModel& m, int lane) {
   for (int b = lane; b < s.nb(); b += kWave) {
     const float* R = s.xmat()[b];
     const float* q = &m.body_inertia[6 * b];
@@ -471,7 +471,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 }
 
 template <class TP>
-__device__ __noinline__ void stage_collision(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int lane) {
   static_assert(sizeof(CollisionScratch) <= sizeof(float) * TP::NB * 12, "collision scratch does not fit T..W");
   CollisionScratch& X = *reinterpret_cast<CollisionScratch*>(&s.T[0][0]);
   // first contact slot of every geom (up to 128 ints): behind the scratch in T..W where that is large enough, else behind
@@ -673,7 +673,7 @@ __device__ __forceinline__ SV rest_inertia_mul(const FlyLds<TP>& s, SV t) {
 }
 
 template <class TP>
-__device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
+__device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const GModel& m, int lane) {
   if constexpr (!TP::kStar) { tree_sweep_twists(s, x, T, m, lane); return; } else {
   const LaneRole L = lane_role<TP>(lane);
   float t = 0.f;
@@ -694,7 +694,7 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width
 // W[b] <- sum of W over the subtree of b (in place), then emit(j, S_j · W[body(j)]) for every dof j
 // (the projection and whatever the caller does with it share one pass: no intermediate vector, no extra sync)
 template <class TP, class Emit>
-__device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Emit&& emit) {
+__device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const GModel& m, int lane, Emit&& emit) {
   if constexpr (!TP::kStar) { tree_sweep_project(s, W, m, lane, [](int, SV w) { return w; }, emit); return; } else {
   const bool red = rest_reduced(s);
   if constexpr (TP::REST_B > 0) { if (!red) tree_gather_levels(s, W, m, lane, [](int, SV w) { return w; }); }
@@ -729,7 +729,7 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_widt
 // y = M x  (composite-free inverse dynamics with zero velocity / gravity); leaves T = twists(x).
 // have_twists: T already holds twists(x) (the ABA leaves them there).
 template <class TP, class Emit>
-__device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const DevModel& m, int lane, bool have_twists, Emit&& emit) {
+__device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const GModel& m, int lane, bool have_twists, Emit&& emit) {
   if (!have_twists) sweep_twists(s, x, s.T, m, lane);
   const bool red = rest_reduced(s);
   for (int b = lane; b < s.nb(); b += kWave) {
@@ -884,7 +884,7 @@ __device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
 
 template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
-                          const DevModel& m, int lane) {
+                          const GModel& m, int lane) {
   if constexpr (!TP::kStar) { tree_aba_solve<TP, WELD>(s, tau_id, x_id, withK, hdamp, m, lane); return; } else {
   withK = __builtin_amdgcn_readfirstlane((int)withK) != 0;          // wave-uniform: scalar branches, no exec masking
   const float* tau = s.vec(tau_id);
@@ -1139,7 +1139,7 @@ __device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
 template <class TP, bool SEEDED, class Emit>
 __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const WeldRow& wr, const Frame& fr,
                                                 const float* rows, float weld_row, float seed_scale,
-                                                const DevModel& m, int lane, Emit&& emit) {
+                                                const GModel& m, int lane, Emit&& emit) {
   if (wr.on) s.weld_w[wr.comp] = weld_row;
   if (c.on) {
     int act = 0;
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
 
 // ------------------------------------------------------------------ the step
 template <class TP, bool WELD>
-__device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
+__device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) { s.rest_fact_valid = 0; s.reduced = 0; } } }   // new configuration: new factors
   stage_kinematics(s, m, lane);
@@ -1641,7 +1641,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const DevModel& m, int lane, cons
 }
 
 template <class TP, bool WELD>
-__device__ void physics_integrate(FlyLds<TP>& s, const DevModel& m, int lane STAGE_ARG) {
+__device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
@@ -1677,7 +1677,7 @@ __device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store
 // the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
 // otherwise reach memory after the final one's.
 template <class TP>
-__device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane, float time, bool final) {
+__device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane, float time, bool final) {
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
@@ -1698,7 +1698,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const DevModel& m, const DevState& 
 // are alive in LDS: right after the collision stage of a launch's last step (as in the reference engine, the poses a
 // step reports belong to the state before its integration), or after the kinematics of a reset.
 template <class TP>
-__device__ void write_poses(FlyLds<TP>& s, const DevModel& m, const DevState& st, int w, int lane) {
+__device__ void write_poses(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane) {
   for (int sg = lane; sg < m.nseg; sg += kWave) {
     int b = m.seg_body[sg];
     V3 p = ld3(s.xpos()[b]) + mat_vec(s.xmat()[b], ld3(&m.seg_pos[3 * sg]));
@@ -1730,7 +1730,7 @@ template <class TP> constexpr int waves_per_simd() {
 template <class TP, bool WELD>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(waves_per_simd<TP>(), waves_per_simd<TP>()))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
   __shared__ FlyLds<TP> s;
-  const DevModel& m = *mp;
+  const GModel& m = *(const GModel*)mp;      // the model lives in HBM: its fields load as global memory in every function
   if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }
   if constexpr (TP::kNFact > 1) {     // kernels with tree sweeps: stage the tree tables
     for (int b = threadIdx.x; b < TP::kTblB && b < m.nb; b += kWave) {

@@ -58,7 +58,7 @@ __device__ __forceinline__ void rest_levels_lane(FlyLds<TP>& s, int lane, F&& f)
 
 // rigid transforms down the tree: R_b = R_parent Rrel_b, p_b = p_parent + R_parent off_b  (relm[b] = Rrel (9), off (3))
 template <class TP>
-__device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane, float (*relm)[12]) {
+__device__ void tree_kinematics_chain(FlyLds<TP>& s, const GModel& m, int lane, float (*relm)[12]) {
   auto body = [&](int b, int p) {
     const float* R = s.xmat()[p];
     const float* M = relm[b];
@@ -79,7 +79,7 @@ __device__ void tree_kinematics_chain(FlyLds<TP>& s, const DevModel& m, int lane
 
 // body velocities -> W, bias accelerations (parent acceleration of the root = -gravity) -> T
 template <class TP>
-__device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ void tree_velocity_bias(FlyLds<TP>& s, const GModel& m, int lane) {
   if (lane == 0) {
     SV vt = SV{v3(0, 0, 0), v3(0, 0, 0)};
     for (int j = 0; j < 3; ++j) vt = vt + s.qvel[j] * ldsv(s.S[j]);
@@ -96,7 +96,7 @@ __device__ void tree_velocity_bias(FlyLds<TP>& s, const DevModel& m, int lane) {
 
 // the levels below the root (W[0], T[0] given)
 template <class TP>
-__device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int lane) {
+__device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const GModel& m, int lane) {
   if constexpr (TP::kStar) {
     if (m.rest_fast) {
       rest_levels_lane<TP, false>(s, lane, [&](const RestNode& nd) {
@@ -125,7 +125,7 @@ __device__ void tree_velocity_bias_levels(FlyLds<TP>& s, const DevModel& m, int 
 
 // T[b] = twist of body b under the generalized vector x
 template <class TP>
-__device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
+__device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const GModel& m, int lane) {
   if (lane == 0) {
     SV t = SV{v3(0, 0, 0), v3(0, 0, 0)};
     for (int j = 0; j < 6; ++j) t = t + x[j] * ldsv(s.S[j]);
@@ -136,7 +136,7 @@ __device__ void tree_sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_
 }
 
 template <class TP>
-__device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const DevModel& m, int lane) {
+__device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*T)[row_width_tw<TP>()], const GModel& m, int lane) {
   tree_down(s, lane, [&](int b) {
     const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
     SV t = ldsv(T[(int)s.t_parent[b]]);
@@ -147,7 +147,7 @@ __device__ void tree_sweep_twists_levels(FlyLds<TP>& s, const float* x, float (*
 
 // W[b] <- extra(b, W[b]) + sum of the children's W, for the bodies below the root, deepest level first
 template <class TP, class Extra>
-__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra) {
+__device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const GModel& m, int lane, Extra&& extra) {
   tree_up(s, lane, [&](int b) {
     SV w = extra(b, ldsv(W[b]));
     const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void tree_gather_levels(FlyLds<TP>& s, float (*W)[row
 
 // W[b] <- sum over the subtree of b (in place; `extra(b)` adds a per-body term first), then emit(j, S_j . W[body(j)])
 template <class TP, class Extra, class Emit>
-__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const DevModel& m, int lane, Extra&& extra, Emit&& emit) {
+__device__ __forceinline__ void tree_sweep_project(FlyLds<TP>& s, float (*W)[row_width_tw<TP>()], const GModel& m, int lane, Extra&& extra, Emit&& emit) {
   tree_gather_levels(s, W, m, lane, extra);
   if (lane == 0) {
     SV w = extra(0, ldsv(W[0]));
@@ -187,7 +187,7 @@ __device__ __forceinline__ void contact_dirs(V3 r, const Frame& fr, float* ln, f
 // them on the rest bodies only.  TP::kFact0 = first dof that has a `fact` slot, TP::kSlot0 = first body with a `slot`.
 template <class TP, bool WELD>
 __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, const float* tau, bool withK, float hdamp,
-                                                        const DevModel& m, const Frame& fr) {
+                                                        const GModel& m, const Frame& fr) {
   Sym6 IA;
   sym6_zero(IA);
   sym6_add_inertia(IA, s.Ib[b]);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
 }
 
 template <class TP>
-__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const DevModel& m) {
+__device__ __forceinline__ void tree_aba_expand_body(FlyLds<TP>& s, int b, SV a, float* x, const GModel& m) {
   const int adr = (int)s.t_dofadr[b], num = (int)s.t_dofnum[b];
   for (int j = adr; j < adr + num; ++j) {
     const float* f = s.fact[j - TP::kFact0];
@@ -319,7 +319,7 @@ __device__ __forceinline__ void rest_dofs(int adr, int num, F&& f) {
 // full elimination of a body: matrix factors and vector part
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
-                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const InertiaRowMap& IM, const DevModel& m) {
+                                                   const Frame& fr, const LaneRole& L, const int (&so)[6], const InertiaRowMap& IM, const GModel& m) {
   const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
   // everything that depends on the node only, first: the body's inertia row and its dofs' axes and scalars
   float row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -445,7 +445,7 @@ __device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& n
 }
 
 template <class TP, bool WELD>
-__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const DevModel& m, int lane) {
+__device__ void tree_aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp, const GModel& m, int lane) {
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   const Frame fr = ld_frame(s, m);
