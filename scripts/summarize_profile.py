@@ -85,7 +85,7 @@ if fetch and write:
                f"WRITE_SIZE {wk:.1f} KiB ({wk*1024/1e6:.2f} MB) -> traffic **{traffic/1e6:.2f} MB** per launch; algorithmic bytes "
                f"({per} B x worlds x steps) = {algo/1e6:.2f} MB; compulsory state+table traffic of a {b['config']['steps_per_launch']}-step persistent launch = "
                f"{(per + 168*b['config']['steps_per_launch']) * b['config']['worlds_per_gpu']/1e6:.2f} MB\n")
-sq = {**counters("pmc_sq"), **counters("pmc_sq2"), **counters("pmc_sq3")}
+sq = {**counters("pmc_sq4"), **counters("pmc_sq"), **counters("pmc_sq2"), **counters("pmc_sq3")}
 if sq:
     out.append("## SQ counters per timed launch (mean)\n\n| counter | value |\n|---|---|")
     for k in sorted(sq):
@@ -95,6 +95,8 @@ if sq:
         for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
             if k in sq:
                 out.append(f"| {k} / SQ_WAVE_CYCLES | {sq[k]/wc:.3f} |")
+    if sq.get("SQC_ICACHE_REQ"):
+        out.append(f"| instruction cache hit rate (SQC_ICACHE_HITS / SQC_ICACHE_REQ) | {sq.get('SQC_ICACHE_HITS', 0.0) / sq['SQC_ICACHE_REQ']:.5f} |")
     if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
         # both in quad-cycle units: thread-cycles / (64 lanes x instruction-cycles) = fraction of lanes a VALU instruction has on
         out.append(f"| active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU) | {sq['SQ_THREAD_CYCLES_VALU'] / (64.0 * sq['SQ_ACTIVE_INST_VALU']):.3f} |")
