@@ -89,7 +89,11 @@ struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodi
 // pyramid-coefficient matrix of every contact (c_m3) and every body's inertia as a symmetric 6x6 (Isym: six reads with
 // lane-constant offsets that the compiler pairs into ds_read2); the hybrid kernels (LDS-bound) rebuild the former from
 // the active-row mask and read inertia rows through InertiaRowMap
+#ifdef NMF_LDS_DIET     // experiment: every kernel on the LDS-bound layout (three waves per SIMD need <= 13.6 KB per fly)
+template <class TP> constexpr bool has_cm3() { return false; }
+#else
 template <class TP> constexpr bool has_cm3() { if constexpr (TP::kStar) return TP::REST_B == 0; else return false; }
+#endif
 template <class TP> inline constexpr bool kHasCm3 = has_cm3<TP>();
 template <class TP> inline constexpr bool kHasIsym = has_cm3<TP>();
 
