@@ -224,6 +224,22 @@ __device__ __forceinline__ Q4 mat_quat(const float* m) {   // rotation matrix ->
   return q;
 }
 
+// Packed float32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fma per instruction).  A wave
+// issues one instruction per >= 4 cycles whatever it is (scripts/valu_issue_microbench: v_pk_fma_f32 4.56 cycles, as
+// v_fma_f32) and this kernel keeps the vector pipe 25 % busy, so pairing halves the issue cost of the row arithmetic.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+// a[0..5] += b[0..5] / a[0..5] += k * b[0..5] as three packed operations
+__device__ __forceinline__ void add6(float (&a)[6], const float* b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) { const f2 r = mk2(a[2 * i], a[2 * i + 1]) + mk2(b[2 * i], b[2 * i + 1]); a[2 * i] = r.x; a[2 * i + 1] = r.y; }
+}
+__device__ __forceinline__ void fma6(float (&a)[6], float k, const float* b) {
+  const f2 kk = mk2(k, k);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { const f2 r = __builtin_elementwise_fma(kk, mk2(b[2 * i], b[2 * i + 1]), mk2(a[2 * i], a[2 * i + 1])); a[2 * i] = r.x; a[2 * i + 1] = r.y; }
+}
+
 // spatial 6-vectors: motion (w; v) and force (n; f), world axes, about the root origin
 struct SV { V3 a, l; };  // angular part, linear part
 __device__ __forceinline__ SV ldsv(const float* p) { return SV{ld3(p), ld3(p + 3)}; }

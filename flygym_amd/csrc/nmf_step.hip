@@ -861,6 +861,7 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
 // u / D (one register per dof less to keep, one multiply per dof less in the forward sweep).  `sr` is the lane's own axis
 // component with the shadow rows already zero.  SHADOW0: the forward sweep keeps its accelerations zero in the shadow
 // rows, so U / D needs no mask either.
+#ifdef NMF_NO_PK
 template <bool SHADOW0>
 __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
                                                 float tauj, float& UDout, float& uDout) {
@@ -875,6 +876,29 @@ __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const
   pA += k * u;
   UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
 }
+#else
+template <bool SHADOW0>
+__device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
+                                                float tauj, float& UDout, float& uDout) {
+  f2 a01 = mk2(IA[0], IA[1]), a23 = mk2(IA[2], IA[3]), a45 = mk2(IA[4], IA[5]);
+  f2 acc = a01 * mk2(sj[0], sj[1]);
+  acc = __builtin_elementwise_fma(a23, mk2(sj[2], sj[3]), acc);
+  acc = __builtin_elementwise_fma(a45, mk2(sj[4], sj[5]), acc);
+  const float U = acc.x + acc.y;
+  const float D = grp8_sum(sr * U) + delta;
+  const float sp = grp8_sum(sr * pA);
+  const float invD = __builtin_amdgcn_rcpf(D);
+  const float u = tauj - sp;
+  const float k = U * invD;
+  const f2 nk = mk2(-k, -k);
+  a01 = __builtin_elementwise_fma(nk, mk2(grp8_bcast<0>(U), grp8_bcast<1>(U)), a01);
+  a23 = __builtin_elementwise_fma(nk, mk2(grp8_bcast<2>(U), grp8_bcast<3>(U)), a23);
+  a45 = __builtin_elementwise_fma(nk, mk2(grp8_bcast<4>(U), grp8_bcast<5>(U)), a45);
+  IA[0] = a01.x; IA[1] = a01.y; IA[2] = a23.x; IA[3] = a23.y; IA[4] = a45.x; IA[5] = a45.y;
+  pA += k * u;
+  UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
+}
+#endif
 // LDS pointer whose value the optimizer may not look through: the accesses made from it carry their (small, constant)
 // offsets in the instruction — a ds_read2 reaches 255 dwords — instead of one address add per access pair, which is what
 // `big constant array offset + lane-dependent row` turns into
@@ -961,8 +985,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
         for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
         for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
-#pragma unroll
-        for (int i = 0; i < 6; i++) IA[i] += row[i];
+        add6(IA, row);
       } else {
         add_inertia_row(IA, s, b, IM);
         for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr);
@@ -1002,8 +1025,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     pA = 0.f;
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) row[i] += H.legIA[k][L.rr][i];
+      add6(row, H.legIA[k][L.rr]);
       pA += H.legpA[k][L.rr];
     }
     if constexpr (TP::REST_B > 0) {
@@ -1039,7 +1061,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       const float invD = __builtin_amdgcn_rcpf(D);
       const float u = tw[e] - sp;
       const float k = U * invD;
-      IA[0] -= k * b0; IA[1] -= k * b1; IA[2] -= k * b2; IA[3] -= k * b3; IA[4] -= k * b4; IA[5] -= k * b5;
+      { const float bb[6] = {b0, b1, b2, b3, b4, b5}; fma6(IA, -k, bb); }
       pA += k * u;
       Ur[e] = kShadow0 ? k : L.mask * k; ur[e] = u * invD;
     });

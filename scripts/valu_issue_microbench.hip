@@ -31,14 +31,16 @@ constexpr int kLoops = 200;     // blocks per measurement
 #define REP8(x) REP4(x) REP4(x)
 
 enum Test { FMA_DEP = 0, FMA_IND8, DPP_DEP, DPP_IND8, SWIZZLE_DEP, SWIZZLE_IND8, LDS_DEP, LDS_IND8, RCP_DEP, READLANE_DEP,
-            MIX_STEP, N_TESTS };
+            MIX_STEP, PK_DEP, PK_IND8, SALU_DEP, SNOP, FMA_SALU_MIX, FMA_LDS_MIX, N_TESTS };
 static const char* kNames[N_TESTS] = {
     "v_fma_f32 dependent chain", "v_fma_f32 8 independent chains", "v_add_f32 dpp quad_perm dependent chain",
     "v_add_f32 dpp 8 independent chains", "ds_swizzle_b32 dependent chain", "ds_swizzle_b32 8 independent",
     "ds_read_b32 dependent chain (pointer chase)", "ds_read_b32 8 independent", "v_rcp_f32 dependent chain",
-    "v_readlane_b32 -> v_mov dependent chain", "ABA-like mix: 6 fma + 3 (s_nop + dpp add) + rcp + mul + 6 swizzle + 6 fma, dependent (23 counted)"};
+    "v_readlane_b32 -> v_mov dependent chain", "ABA-like mix: 6 fma + 3 (s_nop + dpp add) + rcp + mul + 6 swizzle + 6 fma, dependent (23 counted)",
+    "v_pk_fma_f32 dependent chain (2 fma per lane each)", "v_pk_fma_f32 8 independent chains", "s_add_u32 dependent chain",
+    "s_nop 0", "v_fma_f32 + s_add_u32 alternating, independent (per pair)", "v_fma_f32 + ds_read_b32 alternating, independent (per pair)"};
 // instructions counted per asm block for each test
-static const int kPerBlock[N_TESTS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64 * 2, 4 * 23};
+static const int kPerBlock[N_TESTS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64 * 2, 4 * 23, 64, 64, 64, 64, 64, 64};
 
 template <int TEST>
 __global__ void __launch_bounds__(1024) bench(unsigned long long* cycles, unsigned long long* real, float* sink) {
@@ -50,6 +52,8 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* cycles, unsign
   const float b = 0.999f, c = 1e-3f;
   int p0 = (tid & 1023) * 4, p1 = p0 ^ 64, p2 = p0 ^ 128, p3 = p0 ^ 192, p4 = p0 ^ 256, p5 = p0 ^ 320, p6 = p0 ^ 384, p7 = p0 ^ 448;
   int si = 0;
+  double d0 = tid * 1e-3, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;   // 64-bit pairs = two floats each
+  const double db = 0.999, dc = 1e-3;
   __syncthreads();
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -91,6 +95,25 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* cycles, unsign
       asm volatile(REP64("v_rcp_f32 %0, %0\n") : "+v"(a0));
     } else if constexpr (TEST == READLANE_DEP) {
       asm volatile(REP64("v_readlane_b32 %1, %0, 63\n v_mov_b32 %0, %1\n") : "+v"(a0), "+s"(si));
+    } else if constexpr (TEST == PK_DEP) {
+      asm volatile(REP64("v_pk_fma_f32 %0, %0, %1, %2\n") : "+v"(d0) : "v"(db), "v"(dc));
+    } else if constexpr (TEST == PK_IND8) {
+      asm volatile(REP8("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                        "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n")
+                   : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db), "v"(dc));
+    } else if constexpr (TEST == SALU_DEP) {
+      asm volatile(REP64("s_add_u32 %0, %0, 3\n") : "+s"(si) :: "scc");
+    } else if constexpr (TEST == SNOP) {
+      asm volatile(REP64("s_nop 0\n"));
+    } else if constexpr (TEST == FMA_SALU_MIX) {
+      asm volatile(REP64("v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 3\n") : "+v"(a0), "+s"(si) : "v"(b), "v"(c) : "scc");
+    } else if constexpr (TEST == FMA_LDS_MIX) {
+      asm volatile(REP8("v_fma_f32 %0, %0, %16, %17\n ds_read_b32 %8, %8\n v_fma_f32 %1, %1, %16, %17\n ds_read_b32 %9, %9\n"
+                        "v_fma_f32 %2, %2, %16, %17\n ds_read_b32 %10, %10\n v_fma_f32 %3, %3, %16, %17\n ds_read_b32 %11, %11\n"
+                        "v_fma_f32 %4, %4, %16, %17\n ds_read_b32 %12, %12\n v_fma_f32 %5, %5, %16, %17\n ds_read_b32 %13, %13\n"
+                        "v_fma_f32 %6, %6, %16, %17\n ds_read_b32 %14, %14\n v_fma_f32 %7, %7, %16, %17\n ds_read_b32 %15, %15\n s_waitcnt lgkmcnt(0)\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                     "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(b), "v"(c));
     } else if constexpr (TEST == MIX_STEP) {
       // one articulated-body elimination step as the kernel issues it: U = IA.s (6 dependent fma), group sum (3 dpp
       // adds), 1/D, k = U/D, six group broadcasts, six downdates — every instruction depends on the one before
@@ -114,7 +137,7 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* cycles, unsign
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   const int wave = (blockIdx.x * blockDim.x + tid) >> 6;
   if ((tid & 63) == 0) { cycles[wave] = t1 - t0; real[wave] = r1 - r0; }
-  sink[blockIdx.x * blockDim.x + tid] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7) + (float)si;
+  sink[blockIdx.x * blockDim.x + tid] = (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7) + (float)si;
 }
 
 template <int TEST>
@@ -159,7 +182,8 @@ int main(int argc, char** argv) {
       switch (t) {
 #define CASE(T) case T: run<T>(W, n_cu, d_cyc, d_real, d_sink, &cyc, &ghz); break;
         CASE(FMA_DEP) CASE(FMA_IND8) CASE(DPP_DEP) CASE(DPP_IND8) CASE(SWIZZLE_DEP) CASE(SWIZZLE_IND8) CASE(LDS_DEP)
-        CASE(LDS_IND8) CASE(RCP_DEP) CASE(READLANE_DEP) CASE(MIX_STEP)
+        CASE(LDS_IND8) CASE(RCP_DEP) CASE(READLANE_DEP) CASE(MIX_STEP) CASE(PK_DEP) CASE(PK_IND8) CASE(SALU_DEP) CASE(SNOP)
+        CASE(FMA_SALU_MIX) CASE(FMA_LDS_MIX)
 #undef CASE
       }
       const double per = cyc / ((double)kLoops * kPerBlock[t]);
