@@ -28,7 +28,7 @@ constexpr float kNoiseFactor = 8.f;
 // Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
 // -DNMF_STAGE_PROFILE into a separate diagnostic library; the product build has no trace of it.
 #ifdef NMF_STAGE_PROFILE
-#define NMF_NSTAGE 24
+#define NMF_NSTAGE 28
 __device__ unsigned long long g_stage_cycles[NMF_NSTAGE];
 struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_INIT() __shared__ unsigned long long stage_acc_[NMF_NSTAGE]; StageClock sc_; sc_.acc = stage_acc_; \
@@ -37,12 +37,14 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_ARG , StageClock& sc_
 #define STAGE_PASS , sc_
 #define STAGE(k) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sc_.acc[k] += t_ - sc_.last; sc_.last = clock64(); } } while (0)
-// sub-stages inside a non-inlined function (block 0 only, straight to the global accumulators 18..23)
+// sub-stages inside a non-inlined function (block 0 only, straight to the global accumulators 18..27)
 #define SUB_T0() unsigned long long sub_t_ = clock64()
 #define SUB(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sub_t_; sub_t_ = clock64(); } } while (0)
+#define SUB_COUNT(k, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stage_cycles[k] += (unsigned long long)(n); } while (0)
 #else
 #define SUB_T0()
 #define SUB(k)
+#define SUB_COUNT(k, n)
 #define STAGE_INIT()
 #define STAGE_ARG
 #define STAGE_PASS
@@ -497,6 +499,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   const float pd = hm.plane[3];
   const V3 o = ld3(s.xpos()[0]);
   const bool rough = terrain_type != 0;
+  SUB_T0();
   // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
   // (more than 64 contact geoms — e.g. every body segment in contact — take further passes of 64)
   int nh = 0, slot_base = 0;
@@ -529,12 +532,14 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       if (d1 <= g_margin) { if (cnt) { cd1 = d1; cp1 = q1; } else { cd0 = d1; cp0 = q1; } cnt++; }
     }
   }
+  SUB(21);
   // ---- phase 2: near convex hulls one after the other, each scanned by the whole wave; the geom's
   // parameters are broadcast from its lane's registers (no memory round trip)
   // (measured and dropped: holding a hull's vertices and distances in registers across the four scans, and handing the
   // few patch candidates over through LDS — same rate on flat ground, where the tarsal capsules make the contacts, and
   // 3-8 % slower over relief: six slots per lane whatever the hull's size, and 40 more callee-saved registers)
   unsigned long long hmask = __ballot(near && g_type == GEOM_HULL);
+  SUB_COUNT(24, __popcll(hmask));
   while (hmask) {
     const int g = __ffsll((long long)hmask) - 1;
     hmask &= hmask - 1;
@@ -552,10 +557,22 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       if (rough) { const V3 pw = mat_vec(R, v) + xp; di -= terrain_height(terrain_type, tpar, pw.x, pw.y); }
       return di;
     };
+    // scan 1 — the deepest vertex — is all most near hulls ever get (a tarsal segment next to the one in contact: its
+    // bounding cylinder reaches the margin, its vertices do not), and a plain loop pays one memory round trip per 64
+    // vertices: the loads of four passes are issued together (indices clamped, results of the overhang ignored)
     float best = INFINITY; int bi = 0x7fffffff;
-    for (int i = lane; i < nvv; i += kWave) {
-      float di = vdist(ld3(V + 3 * i));
-      if (di < best) { best = di; bi = i; }
+    for (int base = lane; base < nvv + lane; base += 4 * kWave) {
+      V3 hv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int i = base + k * kWave; hv[k] = ld3(V + 3 * (i < nvv ? i : nvv - 1)); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = base + k * kWave;
+        if (i < nvv) {
+          const float di = vdist(hv[k]);
+          if (di < best) { best = di; bi = i; }
+        }
+      }
     }
     wave_argmin(best, bi);
     const float dmin = best; const int ia = bi;
@@ -615,6 +632,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     if (lane == g) cnt = nsel;
     nh += nsel;
   }
+  SUB(22);
   // ---- phase 3: contact slots in geom order.  cnt <= 4, so an exclusive prefix over lanes is three ballots.
   const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -643,6 +661,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     s.body_cstart[b] = (typename FlyLds<TP>::cstart_t)c_before;
   }
   WSYNC();
+  SUB(23);
 }
 
 // ------------------------------------------------------------------ chain sweeps

@@ -25,15 +25,16 @@ table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_wor
 ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
 sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 sim.step(500); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 24)()
-L.nmf_debug_stage_cycles(buf, 24, 1)
+buf = (ctypes.c_ulonglong * 28)()
+L.nmf_debug_stage_cycles(buf, 28, 1)
 steps = 500
 sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
-L.nmf_debug_stage_cycles(buf, 24, 1)
+L.nmf_debug_stage_cycles(buf, 28, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
          "ABA smooth", "solver init + first grad", "newton: test/exit", "newton: ABA(H)", "newton: jv, g1, g2", "newton: linesearch",
          "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors",
-         "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down"]
+         "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down",
+         "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
 tot = cyc[:18].sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
