@@ -73,7 +73,7 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  int max_chunks = 8, min_chunk_steps = 2;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
+  int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
   double chunk_div = 2.0;
 };
 
@@ -185,7 +185,8 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
   // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds:
   // whole-launch items 32.0 / 31.9 M env-steps/s (20- / 50-step launches), 7 equal chunks 36.3 / 38.3 M, halving chunks
   // (chunk_div 2: 10 + 5 + 3 + 2 steps) 36.9 / 38.8 M; more, shorter chunks lose to the per-item cost of taking a
-  // ticket and moving the state through HBM (~10 us).
+  // ticket and moving the state through HBM (~10 us) — except at the very end: a last chunk of one step (min_chunk_steps
+  // 1: 50 = 25 + 13 + 6 + 3 + 2 + 1) is worth +1.2 % on 50-step launches (43.0 -> 43.5 M), nothing on 20-step ones.
   int n_chunks = 1;
   b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
   if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {
