@@ -1717,6 +1717,8 @@ __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane STAGE
 // with every wave of the chip fencing) — only "stores done before the flag", i.e. s_waitcnt vmcnt(0).
 __device__ __forceinline__ float ld_state(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// *p += v at agent scope, result not needed (global_atomic_add_f32 without return: no round trip to wait for)
+__device__ __forceinline__ void add_state(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // `final`: this item ends the launch.  Pure outputs (plain stores: qacc, stats — like the pose / sensor / force outputs of
 // the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
@@ -1844,6 +1846,9 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
   for (;;) {
     int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
     if (chunked) {
+      // (taking the next item's ticket while the current one runs hides the counter's round trip but was measured 7 %
+      // slower: items must go to whoever is free, or the launch's tail grows back; taking it while the finished item's
+      // state drains to HBM changes nothing)
       unsigned int t = 0;
       if (lane == 0) t = atomicAdd(&st.csched->ticket, 1u);
       t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
@@ -1881,6 +1886,12 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       stage_kinematics(s, m, lane);
       write_poses(s, m, st, w, lane);
     } else {
+      // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
+      // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path; the item's first
+      // row travels with the state
+      const float* tab = rp.table ? rp.table + (size_t)w * rp.table_steps * rp.n_act : nullptr;
+      const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[lane] : -1;
+      float next_ctrl = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;
       for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
       for (int i = lane; i < s.nv(); i += kWave) {
         s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
@@ -1889,11 +1900,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
       time = ld_state(&st.time[w]);
       WSYNC();
-      // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
-      // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path
-      const float* tab = rp.table ? rp.table + (size_t)w * rp.table_steps * rp.n_act : nullptr;
-      const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[lane] : -1;
-      float next_ctrl = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;
       for (int step = step0; step < step1; ++step) {
         if (tab) {
           if (my_ctrl >= 0) s.ctrl[my_ctrl] = next_ctrl;
@@ -1914,15 +1920,14 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     if (lane == 0) {
       float* q = &st.stats_sum[4 * (size_t)w];
       if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
-      else {
-        st_state(q, ld_state(q) + (float)(step1 - step0)); st_state(q + 1, ld_state(q + 1) + sum_con);
-        st_state(q + 2, ld_state(q + 2) + sum_it); st_state(q + 3, ld_state(q + 3) + sum_of);
+      else {     // accumulators: adds the item does not wait for (small integers in float: exact in any grouping)
+        add_state(q, (float)(step1 - step0)); add_state(q + 1, sum_con); add_state(q + 2, sum_it); add_state(q + 3, sum_of);
       }
     }
     if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
     if (mode == 0 && lane == 0) {
       const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
-      st_state(&st.cost[w], chunk > 0 ? ld_state(&st.cost[w]) + cyc : cyc);     // the world's cycles over the whole launch
+      if (chunk > 0) add_state(&st.cost[w], cyc); else st_state(&st.cost[w], cyc);     // the world's cycles over the whole launch
       if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     if (!chunked) break;
