@@ -802,8 +802,14 @@ __device__ __forceinline__ InertiaRowMap inertia_map_unpack(const float* q) {
 template <class TP>
 __device__ __forceinline__ void add_inertia_row(float* IA, const FlyLds<TP>& s, int b, const InertiaRowMap& M) {
   const char* base = reinterpret_cast<const char*>(&s.Ib[b][0]);
+  float v[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) IA[c] = fmaf(M.sg[c], *reinterpret_cast<const float*>(base + M.off[c]), IA[c]);
+  for (int c = 0; c < 6; ++c) v[c] = *reinterpret_cast<const float*>(base + M.off[c]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {       // packed: sign pair x value pair + row pair
+    const f2 r = __builtin_elementwise_fma(mk2(M.sg[2 * i], M.sg[2 * i + 1]), mk2(v[2 * i], v[2 * i + 1]), mk2(IA[2 * i], IA[2 * i + 1]));
+    IA[2 * i] = r.x; IA[2 * i + 1] = r.y;
+  }
 }
 
 // row `r` of the contact stiffness  K_c = D * sum_{active rows k} l_k l_kT,  l_k = l_n +/- mu l_t,  l_m = (rc x d_m ; d_m)
@@ -864,15 +870,19 @@ __device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& 
 // bias component pA, own component `sown`, diagonal term delta and generalized force tauj
 __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float* sj, float sown, float mask, float delta,
                                          float tauj, float& Uout, float& uout, float& invDout) {
-  const float U = (IA[0] * sj[0] + IA[1] * sj[1]) + (IA[2] * sj[2] + IA[3] * sj[3]) + (IA[4] * sj[4] + IA[5] * sj[5]);
+  // row arithmetic in packed float32, as in aba_step_scaled below
+  f2 acc = mk2(IA[0], IA[1]) * mk2(sj[0], sj[1]);
+  acc = __builtin_elementwise_fma(mk2(IA[2], IA[3]), mk2(sj[2], sj[3]), acc);
+  acc = __builtin_elementwise_fma(mk2(IA[4], IA[5]), mk2(sj[4], sj[5]), acc);
+  const float U = acc.x + acc.y;
   const float sr = mask * sown;
   const float D = grp8_sum(sr * U) + delta;
   const float sp = grp8_sum(sr * pA);
   const float invD = __builtin_amdgcn_rcpf(D);
   const float u = tauj - sp;
   const float k = U * invD;
-  IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
-  IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
+  { const float bb[6] = {grp8_bcast<0>(U), grp8_bcast<1>(U), grp8_bcast<2>(U), grp8_bcast<3>(U), grp8_bcast<4>(U), grp8_bcast<5>(U)};
+    fma6(IA, -k, bb); }
   pA += k * u;
   Uout = mask * U; uout = u; invDout = invD;
 }
@@ -1054,8 +1064,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       } else
       for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
         const float* sl = s.slot[k - 1];               // hybrid: slots in breadth-first order
+        { float v[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) row[i] += sl[so[i]];
+          for (int i = 0; i < 6; i++) v[i] = sl[so[i]];
+          add6(row, v); }
         pA += sl[21 + L.rr];
       }
     }

@@ -337,8 +337,10 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
   float pA = 0.f;
   for (int k = nd.cstart - 1; k < nd.cstart - 1 + nd.ccount; ++k) {
     const float* sl = s.slot[k];
+    { float v[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) row[c] += sl[so[c]];
+      for (int c = 0; c < 6; ++c) v[c] = sl[so[c]];
+      add6(row, v); }
     pA += sl[21 + L.rr];
   }
   if (withK) {
