@@ -890,22 +890,6 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
 // u / D (one register per dof less to keep, one multiply per dof less in the forward sweep).  `sr` is the lane's own axis
 // component with the shadow rows already zero.  SHADOW0: the forward sweep keeps its accelerations zero in the shadow
 // rows, so U / D needs no mask either.
-#ifdef NMF_NO_PK
-template <bool SHADOW0>
-__device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
-                                                float tauj, float& UDout, float& uDout) {
-  const float U = (IA[0] * sj[0] + IA[1] * sj[1]) + (IA[2] * sj[2] + IA[3] * sj[3]) + (IA[4] * sj[4] + IA[5] * sj[5]);
-  const float D = grp8_sum(sr * U) + delta;
-  const float sp = grp8_sum(sr * pA);
-  const float invD = __builtin_amdgcn_rcpf(D);
-  const float u = tauj - sp;
-  const float k = U * invD;
-  IA[0] -= k * grp8_bcast<0>(U); IA[1] -= k * grp8_bcast<1>(U); IA[2] -= k * grp8_bcast<2>(U);
-  IA[3] -= k * grp8_bcast<3>(U); IA[4] -= k * grp8_bcast<4>(U); IA[5] -= k * grp8_bcast<5>(U);
-  pA += k * u;
-  UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
-}
-#else
 template <bool SHADOW0>
 __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
                                                 float tauj, float& UDout, float& uDout) {
@@ -927,7 +911,6 @@ __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const
   pA += k * u;
   UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
 }
-#endif
 // LDS pointer whose value the optimizer may not look through: the accesses made from it carry their (small, constant)
 // offsets in the instruction — a ds_read2 reaches 255 dwords — instead of one address add per access pair, which is what
 // `big constant array offset + lane-dependent row` turns into
