@@ -1546,27 +1546,35 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         stsv(s.W[b], wb);
         g2 += dot(tb, wb);
       }
+      // the rows' part of the line search's first evaluation (alpha = 0) rides the same reduction round as g1, g2: the
+      // four wave sums interleave, and the search starts one dependent round later than it would otherwise
+      float q1 = 0.f, q2 = 0.f;
       if (c.on) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) g1 -= c.D * c.jar[k] * c.jv[k];
+        for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) { q1 += c.D * c.jar[k] * c.jv[k]; q2 += c.D * c.jv[k] * c.jv[k]; }
       }
-      if (wr.on) g1 -= wr.D * wr.jar * wr.jv;
+      if (wr.on) { q1 += wr.D * wr.jar * wr.jv; q2 += wr.D * wr.jv * wr.jv; }
+      g1 -= q1;
       g1 = wave_sum(g1); g2 = wave_sum(g2);
+      const float s1 = wave_sum(q1), s2 = wave_sum(q2);
       STAGE(11);
       // exact line search
       float alpha = 0.f, lo = 0.f, hi = -1.f;
       for (int ls = 0; ls < 30; ++ls) {
-        float d1 = 0.f, d2 = 0.f;
-        if (c.on) {
+        float d1 = s1 + g1, d2 = s2 + g2;
+        if (ls > 0) {
+          d1 = 0.f; d2 = 0.f;
+          if (c.on) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float x = c.jar[k] + alpha * c.jv[k];
-            if (x < 0.f) { d1 += c.D * x * c.jv[k]; d2 += c.D * c.jv[k] * c.jv[k]; }
+            for (int k = 0; k < 4; k++) {
+              float x = c.jar[k] + alpha * c.jv[k];
+              if (x < 0.f) { d1 += c.D * x * c.jv[k]; d2 += c.D * c.jv[k] * c.jv[k]; }
+            }
           }
+          if (wr.on) { const float x = wr.jar + alpha * wr.jv; d1 += wr.D * x * wr.jv; d2 += wr.D * wr.jv * wr.jv; }
+          d1 = wave_sum(d1) + g1 + alpha * g2;
+          d2 = wave_sum(d2) + g2;
         }
-        if (wr.on) { const float x = wr.jar + alpha * wr.jv; d1 += wr.D * x * wr.jv; d2 += wr.D * wr.jv * wr.jv; }
-        d1 = wave_sum(d1) + g1 + alpha * g2;
-        d2 = wave_sum(d2) + g2;
         if (d2 <= 0.f || d1 == 0.f) break;
         if (d1 < 0.f) lo = alpha; else hi = alpha;
         float next = alpha - d1 / d2;
