@@ -1146,7 +1146,8 @@ template <class TP>
 __device__ __forceinline__ void contact_reload(ContactRegs& c, const FlyLds<TP>& s, int lane) {
   if (c.on) {
     c.r = ld3(s.c_r[lane]); c.D = s.c_D[lane]; c.mu = s.c_mu[lane];
-    c.info = s.c_info[lane] & 0xfffff; c.body = info_body(c.info);
+    // (the packed info word — hence the body — stays in its register across the call: the body twist the rows need next
+    // is requested together with these reads instead of one LDS round trip later)
   }
 }
 
