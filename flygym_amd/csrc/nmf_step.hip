@@ -1162,6 +1162,15 @@ __device__ __forceinline__ void rows_of_twist(const ContactRegs& c, const Frame&
 // (w; v) of the root twist, so J x is a component of T[0] and JT f a component of the root wrench.
 struct WeldRow { bool on; int comp; float D, aref, jar, jv; };
 
+// this lane's share of the constraint cost (callers that have other wave sums to take put them in one reduction round)
+__device__ __forceinline__ float constraint_cost_lane(const ContactRegs& c, const WeldRow& wr) {
+  float v = wr.on ? 0.5f * wr.D * wr.jar * wr.jar : 0.f;
+  if (c.on) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (c.jar[k] < 0.f) v += 0.5f * c.D * c.jar[k] * c.jar[k];
+  }
+  return v;
+}
 template <class TP>
 __device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
   float v = wr.on ? 0.5f * wr.D * wr.jar * wr.jar : 0.f;
@@ -1490,17 +1499,15 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
       if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
     }
-    float gauss = wave_sum(g), ccost = 0.f;
-    if (!red) ccost = constraint_cost<TP>(c, wr);
-    {
-      const float v = v0;
-      if (red) {
+    if (red) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) c.jar[k] += j0[k];
-        wr.jar += w0;
-        ccost = constraint_cost<TP>(c, wr);
-      }
-      const float cost_sm = wave_sum(v);
+      for (int k = 0; k < 4; k++) c.jar[k] += j0[k];
+      wr.jar += w0;
+    }
+    const float cost_ws_lane = constraint_cost_lane(c, wr);
+    float gauss = wave_sum(g), ccost = wave_sum(cost_ws_lane);   // with the cost at the unconstrained acceleration: one round
+    {
+      const float cost_sm = wave_sum(v0);
       if (cost_sm < gauss + ccost) {
         gauss = 0.f; ccost = cost_sm;
         wr.jar = w0;
@@ -1607,6 +1614,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       float dfw = 0.f;
       if (wr.on) { dfw = wr.D * alpha * wr.jv; wr.jar += alpha * wr.jv; }
       gn = 0.f; gm = 0.f;
+      const float cost_lane = constraint_cost_lane(c, wr);     // of the moved residuals; summed with gn, gm below
       contact_project<TP, true>(s, c, wr, fr, df, dfw, alpha, m, lane, [&](int j, float x) {
         const float sj = search[j];
         x += alpha * s.arm[j] * sj;
@@ -1616,9 +1624,9 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         gn += r * r; gm += mag * mag;
       });
       gn = wave_sum(gn); gm = wave_sum(gm);
+      const float newccost = wave_sum(cost_lane);              // one reduction round for the three
       // the Gauss term is quadratic along the search direction: its change is exact from g1, g2
       const float dgauss = alpha * (g1 + 0.5f * alpha * g2);
-      const float newccost = constraint_cost<TP>(c, wr);
       iters = iter + 1;
       STAGE(13);
       const float improvement = (ccost - newccost) - dgauss;
