@@ -334,10 +334,14 @@ template <class TP>
 __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const GModel& m, int lane) {
   // scratch (dead between steps): joint quaternions in the solver vectors, per-body relative
   // rotation matrices + offsets in the ABA hand-off buffer, body-frame hinge axes in T
-  float(*jq)[4] = reinterpret_cast<float(*)[4]>(&s.vA[0]);            // NV x 4 floats = vA..vD
-  float(*relm)[12] = reinterpret_cast<float(*)[12]>(&s.T[0][0]) - 1;    // bodies 1..NB-1: (NB-1) x 12 floats in T..W
+  // Odd strides: lane = dof / lane = body loops and the leg groups of the chain pass (8 bodies apart) would otherwise
+  // hit a bank every 8 lanes / all four groups of a half-wave the same bank (stride 4: 4-way, stride 12: 4-way).
+  constexpr int kJq = 5;                                                 // NV x 5 floats in qacc_smooth .. vD (6 NV floats)
+  constexpr int kRel = row_width_tw<TP>() > 6 ? 13 : 12;     // 13 needs the wide T / W rows (star kernels without rest bodies)
+  float(*jq)[kJq] = reinterpret_cast<float(*)[kJq]>(&s.qacc_smooth[0]);
+  float(*relm)[kRel] = reinterpret_cast<float(*)[kRel]>(&s.T[0][0]) - 1;  // bodies 1..NB-1: (NB-1) x kRel floats in T..W
   float(*axb)[3] = reinterpret_cast<float(*)[3]>(&s.Ib[0][0]);          // NV x 3 floats (Ib is rebuilt afterwards)
-  static_assert((TP::NB - 1) * 12 <= TP::NB * 12 && TP::NV * 3 <= TP::NB * 10, "kinematics scratch does not fit");
+  static_assert((TP::NB - 1) * kRel <= TP::NB * 2 * row_width_tw<TP>() && TP::NV * 3 <= TP::NB * 10 && kJq <= 6, "kinematics scratch does not fit");
   const HotModel hmk = hot_model(s, m);
   const gptr<float> g_axis = G(hmk.dof_axis), g_quat = G(hmk.body_quat), g_pos = G(hmk.body_pos);
   auto axis_of = [&](int j) { if constexpr (kHasIsym<TP>) return ld3(s.axis[j]); else return ld3(g_axis + 3 * j); };
