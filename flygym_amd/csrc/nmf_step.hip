@@ -580,7 +580,8 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     }
     wave_argmin(best, bi);
     const float dmin = best; const int ia = bi;
-    if (!(dmin <= margin)) continue;
+    if (!(dmin <= margin)) { SUB_COUNT(25, 1); SUB_COUNT(26, (unsigned long long)(fminf(dmin, 1.f) * 1e6f)); continue; }
+    SUB_COUNT(27, 1);
     const float thr = fminf(dmin + hull_skin, margin);
     int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
     const V3 va = ld3(V + 3 * ia);

@@ -34,9 +34,9 @@ names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "v
          "ABA smooth", "solver init + first grad", "newton: test/exit", "newton: ABA(H)", "newton: jv, g1, g2", "newton: linesearch",
          "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors",
          "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down",
-         "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step"]
+         "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step", "(collision) scans without a contact per step", "(collision) their summed dmin [nm]", "(collision) scans with contacts per step"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
 tot = cyc[:18].sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
 for nm, c in zip(names, cyc):
-    print(f"  {nm:24s} {c:9.0f}  {100*c/tot:5.1f}%")
+    print(f"  {nm:24s} {c:9.2f}  {100*c/tot:5.1f}%")
