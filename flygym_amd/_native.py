@@ -37,24 +37,46 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
     if os.environ.get("NMF_HIP_LIB"):
         return LIB_PATH                       # an externally built variant: nothing to compile here
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    def fresh():
+        return LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs)
+
+    if not force and fresh():
         return LIB_PATH
+    # one builder at a time: the ranks of a multi-GPU launch import this together, and a library that is being written must
+    # never be the one another rank maps (build into a temporary file, rename when done)
+    import fcntl
+
+    lock = open(LIB_PATH.with_suffix(".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and fresh():
+            return LIB_PATH                   # another process built it while this one waited
+        return _compile(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _compile(verbose: bool) -> Path:
     # -fno-slp-vectorize: the SLP vectoriser packs the 6-vector arithmetic into v_pk_* pairs and pays for it in v_mov
     # shuffles and register pressure (12 spilled VGPRs); scalar code is 9 % faster on the step kernel.  The iterative
     # ILP scheduler interleaves the independent chains of the unrolled sweeps better than the default (+5 %).
     # Arithmetic: divisions and square roots to 1-2.5 ulp (v_rcp / v_sqrt without the correctly-rounded fix-up sequences),
     # reassociation and no signed zeros (+3.7 % together); NaN / Inf semantics are kept (no -ffinite-math-only), and the
     # only transcendental of the step, the joint-angle sincos, is the kernel's own polynomial (nmf_device.h).
+    tmp = LIB_PATH.with_name(LIB_PATH.name + f".{os.getpid()}.tmp")
     cmd = [
         "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
         *MATH_FLAGS, "-fPIC", "-shared",
-        f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(LIB_PATH),
+        f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(tmp),
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise NativeError("hipcc failed:\n" + res.stderr[-4000:])
     if verbose:
         print(res.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
