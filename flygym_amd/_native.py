@@ -24,6 +24,8 @@ FIELDS = dict(
     actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12, stats_sum=13, contact_geom=14,
 )
 
+INT_FIELDS = frozenset({"stats_sum"})   # fields whose 32-bit words are unsigned integer counters, not floats
+
 _lib = None
 
 

@@ -30,6 +30,24 @@ int fail(const std::string& msg) { g_err = msg; return -1; }
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
+// Makes the batch's device current for the calls below and puts the caller's back on every return path: torch (and any
+// other HIP user of the thread) reads its current device through hipGetDevice, so a library call must not change it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) { err = hipSetDevice(device); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_GUARD(b)                                                                       \
+  DeviceGuard guard_((b)->device);                                                            \
+  if (guard_.err != hipSuccess) return fail(std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
+
 struct BlobEntry {
   char name[32];
   uint32_t dtype, ndim;
@@ -73,6 +91,11 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned int* chunk_done_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
+  // schedule of launches with more worlds than resident waves (nmf_step_kernel): NMF_SCHED = auto (default) | paired |
+  // chunks | plain.  auto = paired (static, cost-balanced; no hand-over) for launches of at most paired_max_steps steps whose
+  // worlds fill the rounds evenly, chunks otherwise.
+  int sched_policy = 0;          // 0 auto, 1 paired, 2 chunks, 3 plain
+  int paired_max_steps = 64;     // NMF_PAIRED_MAX_STEPS
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
   double chunk_div = 2.0;
 };
@@ -178,18 +201,58 @@ int alloc_field(nmf_batch* b, int field, int width, float** out) {
   return 0;
 }
 
-int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipStream_t stream) {
-  HIP_OK(hipSetDevice(b->device));      // the caller's current device need not be the batch's
-  // More worlds than resident waves and a launch long enough to cut: chunks whose lengths shrink towards the end of the
-  // launch ("guided" sizes: each takes 1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks)
-  // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds:
-  // whole-launch items 32.0 / 31.9 M env-steps/s (20- / 50-step launches), 7 equal chunks 36.3 / 38.3 M, halving chunks
-  // (chunk_div 2: 10 + 5 + 3 + 2 steps) 36.9 / 38.8 M; more, shorter chunks lose to the per-item cost of taking a
-  // ticket and moving the state through HBM (~10 us) — except at the very end: a last chunk of one step (min_chunk_steps
-  // 1: 50 = 25 + 13 + 6 + 3 + 2 + 1) is worth +1.2 % on 50-step launches (43.0 -> 43.5 M), nothing on 20-step ones.
+int launch_reset(nmf_batch* b, const uint8_t* mask_dev, hipStream_t stream) {
+  DEVICE_GUARD(b);
+  dim3 grid((unsigned)b->n_worlds), block(nmf::kWave);
+#define NMF_RESET_TOPO(K, TOPO) if (b->topo == K) hipLaunchKernelGGL((nmf::nmf_reset_kernel<TOPO>), grid, block, 0, stream, b->dm_dev, b->st, mask_dev);
+#if NMF_HAS_TOPO(0)
+  NMF_RESET_TOPO(0, nmf::FlyTopo)
+#endif
+#if NMF_HAS_TOPO(1)
+  NMF_RESET_TOPO(1, nmf::FlyTopoActive)
+#endif
+#if NMF_HAS_TOPO(2)
+  NMF_RESET_TOPO(2, nmf::TreeTopoSmall)
+#endif
+#if NMF_HAS_TOPO(3)
+  NMF_RESET_TOPO(3, nmf::TreeTopo)
+#endif
+#if NMF_HAS_TOPO(4)
+  NMF_RESET_TOPO(4, nmf::FlyTopoBio)
+#endif
+#if NMF_HAS_TOPO(5)
+  NMF_RESET_TOPO(5, nmf::FlyTopoAll)
+#endif
+#undef NMF_RESET_TOPO
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t stream) {
+  DEVICE_GUARD(b);      // the caller's current device need not be the batch's, and stays what it was
+  // More worlds than resident waves: a launch runs in rounds, and a world's cost (contacts, Newton iterations) spreads 2x
+  // over a gait cycle, so one workgroup per world in arbitrary order leaves the chip half empty while the costliest
+  // worlds finish.  Two remedies (nmf_step_kernel):
+  //  * paired — short launches: persistent workgroups, each steps a static, cost-balanced set of worlds (costliest with
+  //    cheapest, by the cycles of the previous launch) through the whole launch.  No hand-over at all.  Needs the worlds
+  //    to fill the rounds evenly (n_worlds / resident_waves close to an integer) and a cost that predicts the next launch.
+  //  * chunked — long launches: chunks whose lengths shrink towards the end of the launch ("guided" sizes: each takes
+  //    1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks), (chunk, world) items taken
+  //    from a ticket counter.  Measured on 4096 worlds, round 2: whole-launch items 32.0 / 31.9 M env-steps/s (20- /
+  //    50-step launches), halving chunks 42.4 / 44.4 M; each hand-over costs ~10 us (ticket, flag, 2 KB of state each way).
+  const bool oversub = b->n_worlds > b->resident_waves;
+  const int rounds = (b->n_worlds + b->resident_waves - 1) / std::max(1, b->resident_waves);
+  const double fill = (double)b->n_worlds / ((double)rounds * std::max(1, b->resident_waves));   // 1.0: every round full
+  int mode = 0;
+  if (oversub && b->order_buf && b->csched_buf) {
+    if (b->sched_policy == 1) mode = 2;
+    else if (b->sched_policy == 2) mode = 1;
+    else if (b->sched_policy == 0) mode = (n_steps <= b->paired_max_steps && fill >= 0.9) ? 2 : 1;
+  }
+  if (mode == 1 && !(b->chunking && n_steps >= 2 * b->min_chunk_steps)) mode = 0;
   int n_chunks = 1;
   b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
-  if (mode == 0 && b->chunking && b->csched_buf && b->n_worlds > b->resident_waves && n_steps >= 2 * b->min_chunk_steps) {
+  if (mode == 1) {
     int start = 0, c = 0;
     while (start < n_steps && c < b->max_chunks) {
       int len = (int)std::ceil((n_steps - start) / b->chunk_div);
@@ -201,23 +264,44 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, int mode, hipSt
     b->st.chunk_start[c] = n_steps;
     n_chunks = c;
     b->st.n_chunks = c;
+    if (c < 2) mode = 0;
   }
-  // chunked: one persistent workgroup per resident wave pulls (chunk, world) items; plain: one workgroup per world
-  dim3 grid(n_chunks > 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks) : (unsigned)b->n_worlds), block(nmf::kWave);
-  // more worlds than resident waves: the launch runs in rounds; start the costliest worlds first
+  b->st.sched_mode = mode;
+  // chunked / paired: one persistent workgroup per resident wave; plain: one workgroup per world
+  const unsigned n_groups = mode == 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks)
+                          : mode == 2 ? (unsigned)std::min(b->resident_waves, b->n_worlds) : (unsigned)b->n_worlds;
+  dim3 grid(n_groups), block(nmf::kWave);
+  // world order of the launch: paired — costliest first, always (the partition is built on it); otherwise the measured
+  // policy (in order / costliest first) of nmf_order_kernel
   b->st.order = nullptr; b->st.sched = nullptr;
-  if (mode == 0 && b->order_buf && b->sched_buf && b->n_worlds > b->resident_waves) {
-    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps);
-    b->st.order = b->order_buf; b->st.sched = b->sched_buf;
+  if (oversub && b->order_buf && b->sched_buf) {
+    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps,
+                       mode == 2 ? 1 : -1);
+    b->st.order = b->order_buf;
+    if (mode != 2) b->st.sched = b->sched_buf;
   }
   const bool weld = b->dm.weld_active != 0;
-#define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps, mode)
-  if (b->topo == 0) { if (weld) NMF_LAUNCH(nmf::FlyTopo, true); else NMF_LAUNCH(nmf::FlyTopo, false); }
-  else if (b->topo == 1) { if (weld) NMF_LAUNCH(nmf::FlyTopoActive, true); else NMF_LAUNCH(nmf::FlyTopoActive, false); }
-  else if (b->topo == 2) { if (weld) NMF_LAUNCH(nmf::TreeTopoSmall, true); else NMF_LAUNCH(nmf::TreeTopoSmall, false); }
-  else if (b->topo == 3) { if (weld) NMF_LAUNCH(nmf::TreeTopo, true); else NMF_LAUNCH(nmf::TreeTopo, false); }
-  else if (b->topo == 4) { if (weld) NMF_LAUNCH(nmf::FlyTopoBio, true); else NMF_LAUNCH(nmf::FlyTopoBio, false); }
-  else { if (weld) NMF_LAUNCH(nmf::FlyTopoAll, true); else NMF_LAUNCH(nmf::FlyTopoAll, false); }
+#define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
+#define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else NMF_LAUNCH(TOPO, false); }
+#if NMF_HAS_TOPO(0)
+  NMF_LAUNCH_TOPO(0, nmf::FlyTopo)
+#endif
+#if NMF_HAS_TOPO(1)
+  NMF_LAUNCH_TOPO(1, nmf::FlyTopoActive)
+#endif
+#if NMF_HAS_TOPO(2)
+  NMF_LAUNCH_TOPO(2, nmf::TreeTopoSmall)
+#endif
+#if NMF_HAS_TOPO(3)
+  NMF_LAUNCH_TOPO(3, nmf::TreeTopo)
+#endif
+#if NMF_HAS_TOPO(4)
+  NMF_LAUNCH_TOPO(4, nmf::FlyTopoBio)
+#endif
+#if NMF_HAS_TOPO(5)
+  NMF_LAUNCH_TOPO(5, nmf::FlyTopoAll)
+#endif
+#undef NMF_LAUNCH_TOPO
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -302,7 +386,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   }
   if (model->ng > 2 * nmf::kWave) { fail("nmf_batch_create: more than 128 contact geoms"); return nullptr; }
   if (model->nu > (topo >= 2 ? nmf::TreeTopo::kCtrl : nmf::kMaxCtrl)) { fail("nmf_batch_create: too many actuators (48 for the leg skeletons, 224 otherwise)"); return nullptr; }
-  if (hipSetDevice(device) != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
+  DeviceGuard guard(device);            // allocations and the first reset run on `device`; the caller's device comes back on return
+  if (guard.err != hipSuccess) { fail("nmf_batch_create: hipSetDevice failed (no MI355X visible?)"); return nullptr; }
   auto* b = new nmf_batch();
   b->model = model; b->n_worlds = n_worlds; b->device = device; b->topo = topo;
   nmf::DevModel& d = b->dm;
@@ -391,7 +476,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   rc |= alloc_field(b, NMF_STATS, 4, &st.stats);
   rc |= alloc_field(b, NMF_QACC, model->nv, &st.qacc);
   rc |= alloc_field(b, NMF_COST, 1, &st.cost);
-  rc |= alloc_field(b, NMF_STATS_SUM, 4, &st.stats_sum);
+  { float* p = nullptr; rc |= alloc_field(b, NMF_STATS_SUM, 4, &p); st.stats_sum = reinterpret_cast<unsigned int*>(p); }   // uint32 counters
   rc |= alloc_field(b, NMF_CONTACT_GEOM, nmf::kMaxCon, &st.contact_geom);
   {
     void* p = nullptr;
@@ -408,6 +493,12 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
+    if (const char* e = getenv("NMF_SCHED")) {
+      const std::string v(e);
+      b->sched_policy = v == "paired" ? 1 : v == "chunks" ? 2 : v == "plain" ? 3 : 0;
+    }
+    if (!b->chunking && b->sched_policy == 0) b->sched_policy = 3;
+    if (const char* e = getenv("NMF_PAIRED_MAX_STEPS")) b->paired_max_steps = std::max(0, atoi(e));
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
@@ -425,10 +516,26 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     {
       const bool weld = b->dm.weld_active != 0;
       const void* fn = nullptr;
-#define NMF_FN(TOPO) (weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>))
-      switch (topo) { case 0: fn = NMF_FN(nmf::FlyTopo); break; case 1: fn = NMF_FN(nmf::FlyTopoActive); break;
-                      case 2: fn = NMF_FN(nmf::TreeTopoSmall); break; case 3: fn = NMF_FN(nmf::TreeTopo); break;
-                      case 4: fn = NMF_FN(nmf::FlyTopoBio); break; default: fn = NMF_FN(nmf::FlyTopoAll); break; }
+#define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
+#if NMF_HAS_TOPO(0)
+      NMF_FN(0, nmf::FlyTopo)
+#endif
+#if NMF_HAS_TOPO(1)
+      NMF_FN(1, nmf::FlyTopoActive)
+#endif
+#if NMF_HAS_TOPO(2)
+      NMF_FN(2, nmf::TreeTopoSmall)
+#endif
+#if NMF_HAS_TOPO(3)
+      NMF_FN(3, nmf::TreeTopo)
+#endif
+#if NMF_HAS_TOPO(4)
+      NMF_FN(4, nmf::FlyTopoBio)
+#endif
+#if NMF_HAS_TOPO(5)
+      NMF_FN(5, nmf::FlyTopoAll)
+#endif
+      if (!fn) { nmf_batch_destroy(b); fail("nmf_batch_create: this build of the library has no kernel for the model's skeleton (NMF_TOPO_MASK)"); return nullptr; }
 #undef NMF_FN
       int nblk = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, nmf::kWave, 0) == hipSuccess && nblk > 0) per_cu = nblk;
@@ -446,7 +553,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
 
 extern "C" void nmf_batch_destroy(nmf_batch* b) {
   if (!b) return;
-  (void)hipSetDevice(b->device);
+  DeviceGuard guard(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
   delete b;
 }
@@ -455,24 +562,22 @@ extern "C" int nmf_batch_n_worlds(const nmf_batch* b) { return b ? b->n_worlds :
 
 extern "C" int nmf_reset(nmf_batch* b, void* stream) {
   if (!b) return fail("nmf_reset: null batch");
-  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, nullptr};
   b->steps = 0;
-  return launch(b, rp, 0, 1, (hipStream_t)stream);
+  return launch_reset(b, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nmf_reset_worlds(nmf_batch* b, const uint8_t* mask_dev, void* stream) {
   if (!b) return fail("nmf_reset_worlds: null batch");
   if (!mask_dev) return fail("nmf_reset_worlds: null mask");
-  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, mask_dev};
-  return launch(b, rp, 0, 1, (hipStream_t)stream);
+  return launch_reset(b, mask_dev, (hipStream_t)stream);
 }
 
 extern "C" int nmf_step(nmf_batch* b, int n_steps, void* stream) {
   if (!b) return fail("nmf_step: null batch");
   if (n_steps <= 0) return fail("nmf_step: n_steps must be positive");
-  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0, nullptr};
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
   b->steps += n_steps;
-  return launch(b, rp, n_steps, 0, (hipStream_t)stream);
+  return launch(b, rp, n_steps, (hipStream_t)stream);
 }
 
 extern "C" int nmf_step_replay(nmf_batch* b, const float* table_dev, int table_steps, int n_act,
@@ -481,9 +586,9 @@ extern "C" int nmf_step_replay(nmf_batch* b, const float* table_dev, int table_s
   if (n_steps <= 0) return fail("nmf_step_replay: n_steps must be positive");
   if (!table_dev || !act_ids_dev || table_steps <= 0 || n_act <= 0 || n_act > b->model->nu)
     return fail("nmf_step_replay: bad replay table arguments");
-  nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps, nullptr};
+  nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps};
   b->steps += n_steps;
-  return launch(b, rp, n_steps, 0, (hipStream_t)stream);
+  return launch(b, rp, n_steps, (hipStream_t)stream);
 }
 
 extern "C" float* nmf_field_ptr(nmf_batch* b, int field, int32_t* width) {
@@ -496,7 +601,7 @@ extern "C" int nmf_gather(nmf_batch* b, int field, const int32_t* ids_dev, int n
   if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_gather: bad field");
   if (n_ids <= 0) return 0;
   if (group < 1 || !ids_dev || !dst_dev) return fail("nmf_gather: bad arguments");
-  HIP_OK(hipSetDevice(b->device));
+  DEVICE_GUARD(b);
   size_t total = (size_t)b->n_worlds * n_ids * group;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(nmf::nmf_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
@@ -509,7 +614,7 @@ extern "C" int nmf_scatter(nmf_batch* b, int field, const int32_t* ids_dev, int 
   if (!b || field < 0 || field >= NMF_FIELD_COUNT) return fail("nmf_scatter: bad field");
   if (n_ids <= 0) return 0;
   if (!ids_dev || !src_dev) return fail("nmf_scatter: bad arguments");
-  HIP_OK(hipSetDevice(b->device));
+  DEVICE_GUARD(b);
   size_t total = (size_t)b->n_worlds * n_ids;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(nmf::nmf_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->fields[field],
@@ -598,7 +703,7 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
     return fail("nmf_eye_render: bad body-capsule list (at most 64)");
   if (!(p->checker_size > 0.f) || !(p->fov_deg > 0.f) || p->fov_deg > 360.f) return fail("nmf_eye_render: bad checker size / field of view");
   const nmf_model* m = b->model;
-  HIP_OK(hipSetDevice(b->device));
+  DEVICE_GUARD(b);
   if (b->dm.plane[0] != 0.f || b->dm.plane[1] != 0.f || b->dm.plane[2] != 1.f) return fail("nmf_eye_render: the ground plane must be z-up");
   if ((reinterpret_cast<uintptr_t>(plan_dev) | reinterpret_cast<uintptr_t>(frames_out_dev)) & 15u)
     return fail("nmf_eye_render: plan / frames must be 16-byte aligned");
@@ -644,7 +749,7 @@ extern "C" int nmf_odor_intensity(nmf_batch* b, const int32_t* sensor_seg_dev, c
   if (n_sensors <= 0 || n_sources < 0 || n_dims <= 0 || !sensor_seg_dev || !sensor_rel_dev || !out_dev)
     return fail("nmf_odor_intensity: bad arguments");
   int total = b->n_worlds * n_sensors;
-  HIP_OK(hipSetDevice(b->device));
+  DEVICE_GUARD(b);
   hipLaunchKernelGGL(nmf::nmf_odor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      b->st.seg_xpos, b->st.seg_xquat, b->model->nseg, sensor_seg_dev, sensor_rel_dev, n_sensors,
                      source_pos_dev, source_peak_dev, n_sources, n_dims, out_dev, b->n_worlds);

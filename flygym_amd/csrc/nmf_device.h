@@ -69,6 +69,12 @@ struct TreeTopoT {
 using TreeTopo = TreeTopoT<72, 216>;
 using TreeTopoSmall = TreeTopoT<72, 144>;
 
+// The same value, but not one the optimizer can see through: address arithmetic built on it stays where it is written.
+// Used for the once-per-item / once-per-launch paths of the stepping kernel (state hand-over, pure outputs): hoisted out
+// of the persistent item loop, their per-lane 64-bit addresses sat in ~40 vector registers across every step and 31 of
+// them were spilled to scratch (round 2's shipped kernel).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -128,7 +134,7 @@ struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
       *sensordata, *time, *stats, *qacc;
-  float* stats_sum;        // [n_worlds][4] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps
+  unsigned int* stats_sum; // [n_worlds][4] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps
   float* contact_geom;     // [n_worlds][kMaxCon] geom index of contact c at the launch's last step (-1 beyond ncon)
   float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
   const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
@@ -137,7 +143,8 @@ struct DevState {
   // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
   struct ChunkSched* csched;
   unsigned int* chunk_done;   // [n_worlds] epoch * 32 + chunks of this launch the world has finished
-  int n_chunks;               // 1: one workgroup steps a world through the whole launch
+  int n_chunks;               // chunked schedule: number of chunks
+  int sched_mode;             // 0 plain (one workgroup per world), 1 chunked (tickets), 2 paired (static, cost-balanced): nmf_step_kernel
   int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 
@@ -156,7 +163,6 @@ struct ReplayArgs {
   const float* table;   // [n_worlds][table_steps][n_act] or nullptr
   const int* act_ids;   // [n_act]
   int table_steps, n_act, start;
-  const unsigned char* reset_mask;   // mode 1 only: reset world w iff reset_mask[w] != 0 (nullptr = all worlds)
 };
 
 // ---------------------------------------------------------------- small math

@@ -23,6 +23,13 @@
 namespace nmf {
 
 #define WSYNC() __syncthreads()
+// NMF_TOPO_MASK (development builds only: `scripts/build_variant.sh x -DNMF_TOPO_MASK=1` compiles the LEGS_ONLY kernels alone,
+// in a sixth of the time): bit k keeps the kernels of topology k (0 LEGS_ONLY, 1 LEGS_ACTIVE_ONLY, 2 / 3 general tree,
+// 4 ALL_BIOLOGICAL, 5 ALL_POSSIBLE).  The shipped library has all of them.
+#ifndef NMF_TOPO_MASK
+#define NMF_TOPO_MASK 0x3f
+#endif
+#define NMF_HAS_TOPO(k) ((NMF_TOPO_MASK >> (k)) & 1)
 constexpr float kNoiseFactor = 8.f;
 
 // Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
@@ -1430,7 +1437,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       if (m.act_limited[2 * u]) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
       s.vA[j] += f;
     }
-    if (last) st.actuator_force[(size_t)w * m.nu + u] = f;     // pure output: only the launch's last step stores it
+    if (last) st.actuator_force[(size_t)w * m.nu + opaque(u)] = f;     // pure output: only the launch's last step stores it
   }
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) {
@@ -1667,9 +1674,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // ---- contact sensors (oracle contact_sensors): a pure output, evaluated on the launch's last step only and
   // written straight to HBM.  c_w holds the world-frame contact wrenches about the root origin.
   if (last) {
-    if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = c.on ? (float)info_geom(c.info) : -1.f;
+    const int ol = opaque(lane);
+    if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + ol] = c.on ? (float)info_geom(c.info) : -1.f;
     float* out = &st.sensordata[(size_t)w * 96];
-    for (int i = lane; i < 96; i += kWave) out[i] = 0.f;
+    for (int i = ol; i < 96; i += kWave) out[i] = 0.f;
     WSYNC();
     if (m.nsensor && lane < 6 && ncon > 0) {
       float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
@@ -1688,7 +1696,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
           F = F + f;
           Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
         }
-        float* o16 = out + 16 * lane;
+        float* o16 = out + 16 * ol;
         V3 o = ld3(s.xpos()[0]);
         if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
           F = v3(dot(fr.n, F), dot(fr.t1, F), dot(fr.t2, F));
@@ -1736,12 +1744,14 @@ __device__ __forceinline__ float ld_state(const float* p) { return __hip_atomic_
 __device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // *p += v at agent scope, result not needed (global_atomic_add_f32 without return: no round trip to wait for)
 __device__ __forceinline__ void add_state(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void add_count(unsigned int* p, unsigned int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // `final`: this item ends the launch.  Pure outputs (plain stores: qacc, stats — like the pose / sensor / force outputs of
 // the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
 // otherwise reach memory after the final one's.
 template <class TP>
 __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane, float time, bool final) {
+  lane = opaque(lane);     // once per item: keep its address arithmetic out of the registers the steps live in
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
@@ -1751,7 +1761,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
   for (int i = lane; i < m.nu; i += kWave) {
     st_state(&st.ctrl[(size_t)w * m.nu + i], s.ctrl[i]);
   }
-  if (lane == 0) st_state(&st.time[w], time);
+  if (lane == 0) st_state(&st.time[opaque(w)], time);      // (opaque: the address is not kept in a register pair from the item's start)
   if (lane == 0 && final) {
     st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
     st.stats[4 * w + 3] = (float)(4 * s.ncon);
@@ -1763,6 +1773,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
 // step reports belong to the state before its integration), or after the kinematics of a reset.
 template <class TP>
 __device__ void write_poses(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane) {
+  lane = opaque(lane);     // once per launch (see write_outputs)
   for (int sg = lane; sg < m.nseg; sg += kWave) {
     int b = m.seg_body[sg];
     V3 p = ld3(s.xpos()[b]) + mat_vec(s.xmat()[b], ld3(&m.seg_pos[3 * sg]));
@@ -1790,11 +1801,11 @@ template <class TP> constexpr int waves_per_simd() {
 #endif
 }
 
-// mode 0: step n_steps times; mode 1: reset to the keyframe and refresh poses (no stepping)
-template <class TP, bool WELD>
-__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(waves_per_simd<TP>(), waves_per_simd<TP>()))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps, int mode) {
-  __shared__ FlyLds<TP> s;
-  const GModel& m = *(const GModel*)mp;      // the model lives in HBM: its fields load as global memory in every function
+// What every kernel of a batch stages in LDS once per launch: the tree tables (kernels with tree sweeps), the per-dof
+// diagonal terms, the per-row constants of the contact stiffness rows / inertia rows, and — star kernels with LDS to spare —
+// the part of the model the non-inlined stages read (HotModel), the contact frame and the joint axes.
+template <class TP>
+__device__ __forceinline__ void stage_launch_constants(FlyLds<TP>& s, const GModel& m) {
   if constexpr (!TP::kStar) { if (threadIdx.x == 0) { s.rt_nb = m.nb; s.rt_nv = m.nv; } __syncthreads(); }
   if constexpr (TP::kNFact > 1) {     // kernels with tree sweeps: stage the tree tables
     for (int b = threadIdx.x; b < TP::kTblB && b < m.nb; b += kWave) {
@@ -1812,7 +1823,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     __syncthreads();
   }
   const int lane = threadIdx.x;
-  STAGE_INIT();
   for (int j = lane; j < s.nv(); j += kWave) {
     if constexpr (row_width_s<TP>() > 6) s.S[j][6] = 0.f;      // padding column: the shadow rows' axis component (aba_solve)
     s.arm[j] = m.dof_armature[j];
@@ -1849,18 +1859,59 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     h.hull_skin = m.hull_skin; h.terrain_type = m.terrain_type; h.ng = m.ng; h.sem_max_hull_contacts = m.sem_max_hull_contacts;
   }
   if constexpr (kHasIsym<TP>) for (int i = lane; i < 3 * s.nv(); i += kWave) (&s.axis[0][0])[i] = m.dof_axis[i];
-  // Which world, which steps.  Plain launches: workgroup b steps world order[b] through all n_steps and exits.  Chunked
-  // launches (more worlds than resident waves): the launch is cut into n_chunks chunks (long first, short last), the grid is
-  // one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket counter until the
-  // counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost varies 2x with its gait
-  // phase, so whole-launch items leave the machine half empty while the costliest worlds finish; with chunks the tail is
-  // one chunk long.  An item waits for its world's previous chunk (an older ticket, hence taken by a workgroup that is
-  // running or done: no deadlock whatever the dispatch order) and takes the state over through HBM (ld_state / st_state).
-  // The model constants staged above stay in LDS from item to item.
-  const bool chunked = mode == 0 && st.n_chunks > 1;
+}
+
+// Reset to the keyframe and refresh the pose outputs (no stepping): one workgroup per world; reset_mask (may be null)
+// selects the worlds.  Its own kernel: inside the stepping kernel the reset path's addresses and constants were hoisted out
+// of the persistent item loop and held (or spilled) across every step.
+template <class TP>
+__global__ void __launch_bounds__(kWave) nmf_reset_kernel(const DevModel* __restrict__ mp, DevState st, const unsigned char* __restrict__ reset_mask) {
+  __shared__ FlyLds<TP> s;
+  const GModel& m = *(const GModel*)mp;
+  const int lane = threadIdx.x, w = (int)blockIdx.x;
+  if (w >= st.n_worlds || (reset_mask && !reset_mask[w])) return;
+  stage_launch_constants(s, m);
+  for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
+  for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
+  for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
+  for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
+  if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
+  WSYNC();
+  stage_kinematics(s, m, lane);
+  write_poses(s, m, st, w, lane);
+  write_outputs(s, m, st, w, lane, 0.f, true);
+  if (lane < 4) st.stats_sum[4 * (size_t)w + lane] = 0u;
+  if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
+}
+
+// Step n_steps times.  Which world, which steps — three schedules (DevState::sched_mode):
+//   plain   (0): workgroup b steps world order[b] through all n_steps and exits (every world resident at once).
+//   chunked (1): more worlds than resident waves, long launches.  The launch is cut into n_chunks chunks (long first, short
+//     last), the grid is one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket
+//     counter until the counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost
+//     varies 2x with its gait phase, so whole-launch items in arbitrary order leave the machine half empty while the
+//     costliest worlds finish; with chunks the tail is one chunk long.  An item waits for its world's previous chunk (an
+//     older ticket, hence taken by a workgroup that is running or done: no deadlock whatever the dispatch order) and
+//     takes the state over through HBM (ld_state / st_state).
+//   paired  (2): more worlds than resident waves, short launches (a control tick of 20 steps).  Every hand-over of the
+//     chunked schedule costs ~10 us (ticket, flag, 2 KB of state each way) — 8 % of a 20-step launch.  Here the grid is
+//     again one persistent workgroup per resident wave, but workgroup b steps the worlds of ranks b, 2R-1-b, 2R+b, 4R-1-b,
+//     ... (R = grid size) of `order`, which nmf_order_kernel sorted costliest first by the cycles each world took in the
+//     previous launch: the costliest world shares a workgroup with the cheapest, the second costliest with the second
+//     cheapest, ...  A world's cost changes by a few per cent from one short launch to the next (the gait advances 2.4 % of
+//     a cycle in 20 steps), so the static partition is balanced without tickets, flags or a state hand-over.
+// The model constants staged above stay in LDS from item to item.  Worlds are independent: the schedule never changes a result.
+template <class TP, bool WELD>
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(waves_per_simd<TP>(), waves_per_simd<TP>()))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps) {
+  __shared__ FlyLds<TP> s;
+  const GModel& m = *(const GModel*)mp;      // the model lives in HBM: its fields load as global memory in every function
+  stage_launch_constants(s, m);
+  const int lane = threadIdx.x;
+  STAGE_INIT();
+  const bool chunked = st.sched_mode == 1, paired = st.sched_mode == 2;
   const int n_chunks = chunked ? st.n_chunks : 1;
-  const unsigned int epoch = chunked ? st.csched->epoch : 0u;
-  for (;;) {
+  const unsigned int epoch = chunked ? (unsigned int)__builtin_amdgcn_readfirstlane((int)st.csched->epoch) : 0u;
+  for (int round = 0;; ++round) {
     int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
     if (chunked) {
       // (taking the next item's ticket while the current one runs hides the counter's round trip but was measured 7 %
@@ -1879,49 +1930,43 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       }
       chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
       step0 = st.chunk_start[chunk]; step1 = st.chunk_start[chunk + 1];
+    } else if (paired) {
+      const int R = (int)gridDim.x;
+      slot = (round & 1) ? (round + 1) * R - 1 - (int)blockIdx.x : round * R + (int)blockIdx.x;   // boustrophedon over the cost ranks
+      if (slot >= st.n_worlds) break;       // ranks grow with the round: nothing further for this workgroup
     } else if (slot >= st.n_worlds) return;
-    const int w = st.order ? st.order[slot] : slot;
-    if (mode == 1 && rp.reset_mask && !rp.reset_mask[w]) return;
+    const int w = __builtin_amdgcn_readfirstlane(st.order ? st.order[slot] : slot);     // wave-uniform: lives in a scalar register
     if (chunked && chunk > 0) {
-      const unsigned int want = epoch * 32u + (unsigned int)chunk;
+      const unsigned int want = (unsigned int)__builtin_amdgcn_readfirstlane((int)(epoch * 32u + (unsigned int)chunk));
       if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
       __syncthreads();
     }
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    if (mode == 0 && st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     float time;
-    float sum_con = 0.f, sum_it = 0.f, sum_of = 0.f;     // lane 0: running sums over the steps of this item
-    if (mode == 1) {
-      for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
-      for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
-      for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
-      for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
-      if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
-      time = 0.f;
-      WSYNC();
-      stage_kinematics(s, m, lane);
-      write_poses(s, m, st, w, lane);
-    } else {
+    unsigned int sum_con = 0u, sum_it = 0u, sum_of = 0u;     // lane 0: running sums over the steps of this item
+    {
       // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
       // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path; the item's first
       // row travels with the state
       const float* tab = rp.table ? rp.table + (size_t)w * rp.table_steps * rp.n_act : nullptr;
-      const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[lane] : -1;
+      const int ln = opaque(lane);      // once per item (see write_outputs)
+      const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[ln] : -1;
       float next_ctrl = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;
-      for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
-      for (int i = lane; i < s.nv(); i += kWave) {
+      for (int i = ln; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
+      for (int i = ln; i < s.nv(); i += kWave) {
         s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
         s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
       }
-      for (int i = lane; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
+      for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
       time = ld_state(&st.time[w]);
       WSYNC();
       for (int step = step0; step < step1; ++step) {
         if (tab) {
           if (my_ctrl >= 0) s.ctrl[my_ctrl] = next_ctrl;
           const float* src = tab + (size_t)((rp.start + step) % rp.table_steps) * rp.n_act;
-          for (int a = lane + kWave; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];
+          for (int a = opaque(lane) + kWave; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];     // (more than 64 controls: hybrid / tree kernels)
           if (my_ctrl >= 0 && step + 1 < step1) next_ctrl = tab[(size_t)((rp.start + step + 1) % rp.table_steps) * rp.n_act + lane];
           WSYNC();
         }
@@ -1930,27 +1975,25 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
         physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
         STAGE(15);
         time += m.timestep;
-        if (lane == 0) { sum_con += (float)s.ncon; sum_it += (float)s.iters; sum_of += (float)s.overflow; }
+        if (lane == 0) { sum_con += (unsigned int)s.ncon; sum_it += (unsigned int)s.iters; sum_of += (unsigned int)s.overflow; }
       }
     }
     write_outputs(s, m, st, w, lane, time, step1 == n_steps);
     if (lane == 0) {
-      float* q = &st.stats_sum[4 * (size_t)w];
-      if (mode == 1) { q[0] = 0.f; q[1] = 0.f; q[2] = 0.f; q[3] = 0.f; }
-      else {     // accumulators: adds the item does not wait for (small integers in float: exact in any grouping)
-        add_state(q, (float)(step1 - step0)); add_state(q + 1, sum_con); add_state(q + 2, sum_it); add_state(q + 3, sum_of);
-      }
-    }
-    if (mode == 1 && lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
-    if (mode == 0 && lane == 0) {
+      // accumulators: integer adds the item does not wait for (uint32: exact up to 4.29e9 — at ~6 contacts per step that is
+      // 7e8 steps of one world between two resets)
+      unsigned int* q = &st.stats_sum[4 * (size_t)w];
+      add_count(q, (unsigned int)(step1 - step0)); add_count(q + 1, sum_con); add_count(q + 2, sum_it); add_count(q + 3, sum_of);
       const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
       if (chunk > 0) add_state(&st.cost[w], cyc); else st_state(&st.cost[w], cyc);     // the world's cycles over the whole launch
       if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
-    if (!chunked) break;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this item wrote (agent-scope stores) is out
-    __syncthreads();                                                  // ... for every lane, before the hand-off flag
-    if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 32u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!chunked && !paired) break;
+    if (chunked) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this item wrote (agent-scope stores) is out
+      __syncthreads();                                                  // ... for every lane, before the hand-off flag
+      if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 32u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else __syncthreads();      // paired: the next world's state load overwrites LDS the stores above still read
   }
   STAGE(16);
   STAGE_FLUSH();
@@ -1986,11 +2029,13 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
 // a smoothed duration per step is kept for both orders (restarted when the launch length changes), the better one is
 // used and the other re-tried every 32nd launch.  Costliest-first = one workgroup: min / max, 256-bin histogram of the quantised cost, exclusive prefix from
 // the top bin, scatter.  Worlds are independent: the order changes the schedule only, never a result.
+// force_policy >= 0 (the paired schedule needs costliest-first) bypasses the measured choice and its bookkeeping.
 __global__ void __launch_bounds__(1024) nmf_order_kernel(const float* __restrict__ cost, int n, int* __restrict__ order,
-                                                         SchedState* __restrict__ sched, int n_steps) {
+                                                         SchedState* __restrict__ sched, int n_steps, int force_policy) {
   __shared__ unsigned int lo, hi, hist[256], base[256];   // lo / hi: bit patterns of non-negative floats order like the floats
   __shared__ int policy;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && force_policy >= 0) { lo = 0xffffffffu; hi = 0u; policy = force_policy; }
+  if (threadIdx.x == 0 && force_policy < 0) {
     lo = 0xffffffffu; hi = 0u;
     SchedState s = *sched;
     if (s.launches > 0 && s.t_last > s.t_first && s.last_steps > 0) {
@@ -2038,17 +2083,29 @@ using FlyTopoBio = HybridTopo<20, 60, 6, 3, 2, 1, 1, 1, 1, 1, 1>;        // ALL_
 using FlyTopoAll = HybridTopo<20, 60, 6, 3, 3, 3, 3, 3, 3, 3, 3>;        // ALL_POSSIBLE:   69 bodies, 210 dofs
 using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton: 25 bodies, 48 dofs
 
-template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoBio, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoBio, true>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoAll, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<FlyTopoAll, true>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<TreeTopoSmall, false>(const DevModel*, DevState, ReplayArgs, int, int);
-template __global__ void nmf_step_kernel<TreeTopoSmall, true>(const DevModel*, DevState, ReplayArgs, int, int);
+#if NMF_HAS_TOPO(0)
+template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
+#if NMF_HAS_TOPO(1)
+template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
+#if NMF_HAS_TOPO(2)
+template __global__ void nmf_step_kernel<TreeTopoSmall, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<TreeTopoSmall, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
+#if NMF_HAS_TOPO(3)
+template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
+#if NMF_HAS_TOPO(4)
+template __global__ void nmf_step_kernel<FlyTopoBio, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<FlyTopoBio, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
+#if NMF_HAS_TOPO(5)
+template __global__ void nmf_step_kernel<FlyTopoAll, false>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<FlyTopoAll, true>(const DevModel*, DevState, ReplayArgs, int);
+#endif
 
 }  // namespace nmf

@@ -140,7 +140,10 @@ class HIPSimulation:
             ptr = self._lib.nmf_field_ptr(self._batch_h, _native.FIELDS[name], ctypes.byref(width))
             if not ptr:
                 raise _native.NativeError(self._lib.nmf_last_error().decode())
-            self._views[name] = _tensor_from_ptr(self._torch, ptr, (self.n_worlds, max(width.value, 0)), self.device)
+            view = _tensor_from_ptr(self._torch, ptr, (self.n_worlds, max(width.value, 0)), self.device)
+            if name in _native.INT_FIELDS:       # integer counters behind the float-typed field pointer (include/nmf.h)
+                view = view.view(self._torch.int32)
+            self._views[name] = view
         return self._views[name]
 
     def _gather(self, field: str, ids, group: int = 1):

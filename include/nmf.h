@@ -41,7 +41,10 @@ enum nmf_field {
   NMF_QACC = 11,        /* [nv]                                                                */
   NMF_COST = 12,        /* [1]       shader cycles the world took in the last stepping launch (load metric) */
   NMF_STATS_SUM = 13,   /* [4]       since the last reset: physics steps, sum of ncon, sum of solver iterations, steps with
-                                    contact overflow (means over any window = differences of two reads)              */
+                                    contact overflow (means over any window = differences of two reads).  The four
+                                    words are uint32_t COUNTERS (read them through a uint32_t / int32_t view of the
+                                    pointer nmf_field_ptr returns): exact up to 4.29e9, i.e. ~7e8 steps of one world at
+                                    6 contacts per step between two resets                                           */
   NMF_CONTACT_GEOM = 14, /* [48]     contact list of the launch's last step: index (into the world's contact-geom list,
                                     reference compose/world.py:300-309 pair order sorted by body) of the geom of contact
                                     c, as a float; -1 beyond ncon                                                    */

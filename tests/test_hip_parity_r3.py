@@ -1,0 +1,232 @@
+"""Round-3 parity tests on MI355X: every kernel instantiation and every BASELINE config at its real size.
+
+* the three launch schedules of ``nmf_step_kernel`` (plain, chunked with state hand-over, paired / cost-balanced) are
+  bit-identical on 4096 worlds — for the LEGS_ONLY, LEGS_ACTIVE_ONLY (star kernels) and ALL_BIOLOGICAL (hybrid kernel)
+  skeletons and a tethered world (``WELD = true`` instantiation), plain launches and hipGraph replays;
+* worlds drawn from a 4096-world ALL_BIOLOGICAL batch walking on the tripod CPG follow the float64 / float32 oracle
+  (the hybrid kernel's reduced Newton problem at the size ``bench.py --joint-preset all_biological`` runs);
+* BASELINE config 3 at full size: 4096 flies walking with both eyes rendered and resampled every 20 steps — finite,
+  deterministic, and 16 sampled eye views against the numpy specification (``oracle/sensors_oracle.py``) evaluated at
+  the poses the engine reports.
+
+Tolerances as in tests/test_hip_parity.py (float32 engine vs float64 oracle).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 4096
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+def _model(kind):
+    """(fly, world) of the kernel instantiation under test."""
+    import flygym_amd.compose as C
+    from flygym_amd import anatomy as A, make_model
+    from flygym_amd.utils.math import Rotation3D
+
+    if kind in ("legs_only", "legs_active_only", "all_biological"):
+        fly, world, _ = make_model(joints_preset=kind)
+        return fly, world
+    assert kind == "tethered"
+    fly = C.Fly(name="t")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    fly.add_actuators(sk.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    world = C.TetheredWorld()
+    world.add_fly(fly, (0, 0, 1.5), Rotation3D("quat", (1, 0, 0, 0)))
+    return fly, world
+
+
+@pytest.mark.parametrize("kind", ["legs_only", "legs_active_only", "all_biological", "tethered"])
+def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
+    """More worlds than resident waves: a launch is either cut into (chunk, world) items pulled by persistent workgroups,
+    a world's state crossing HBM between chunks, or stepped by persistent workgroups over a static cost-balanced partition
+    of the worlds (nmf_step_kernel: chunked / paired).  Scheduling must never change a result: 4096 worlds through a
+    settle, CPG walking in 50-, 20- and 9-step launches and four 30-step launches (eager, and captured in a hipGraph and
+    replayed — the schedulers keep no host-side state) give every state array, the clock and the running sums bit for
+    bit under NMF_SCHED = chunks / paired / plain and under the default policy."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world = _model(kind)
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    table = cpg.targets(N, 1250, device="cuda:0")
+    n50 = 47 if kind == "legs_only" else 12
+
+    def run(sched, graphed=False):
+        if sched is None:
+            monkeypatch.delenv("NMF_SCHED", raising=False)
+        else:
+            monkeypatch.setenv("NMF_SCHED", sched)        # read when the batch is created
+        sim = HIPSimulation(world, n_worlds=N, device=0)
+        ids = sim.replay_ids(fly.name)
+        sim.set_leg_adhesion_states(fly.name, np.ones((N, 6), dtype=np.float32))
+        sim.step(500)
+        cur = 0
+        for _ in range(n50):
+            sim.step_replay(table, ids, cur, 50); cur += 50
+        sim.step_replay(table, ids, cur, 20); cur += 20
+        sim.step_replay(table, ids, cur, 9); cur += 9
+        if graphed:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                sim.step(30)                                   # warm the capture stream (part of the compared sequence)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sim.step(30)
+            for _ in range(3):
+                g.replay()
+        else:
+            for _ in range(4):
+                sim.step(30)
+        torch.cuda.synchronize()
+        return {k: sim.field(k).clone() for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "time", "stats_sum", "stats",
+                                                 "sensordata", "seg_xpos", "contact_geom", "actuator_force")}
+
+    plain = run("plain")
+    for name, got in (("chunks", run("chunks")), ("paired", run("paired")), ("default policy", run(None)),
+                      ("default policy, hipGraph", run(None, graphed=True)), ("chunks, hipGraph", run("chunks", graphed=True))):
+        for k in plain:
+            assert torch.equal(got[k], plain[k]), f"{kind}: schedule '{name}' differs from plain launches in {k}"
+    assert int(plain["stats_sum"][:, 0].min()) == int(plain["stats_sum"][:, 0].max()) == 500 + 50 * n50 + 20 + 9 + 120
+    assert bool(torch.isfinite(plain["qpos"]).all())
+    if kind == "tethered":
+        assert int(plain["stats_sum"][:, 1].max()) == 0                       # no ground, no contacts: the weld rows alone
+        assert float((plain["qpos"][:, :3] - torch.tensor([0.0, 0.0, 1.5], device="cuda:0")).abs().max()) < 1e-3
+    else:
+        assert float(plain["stats_sum"][:, 1].float().mean()) > 1000          # contact-rich walking
+        assert len(torch.unique(plain["qpos"][:, 0])) > 1000                  # the worlds really differ (phase offsets)
+
+
+def test_all_biological_batch_follows_the_oracle(torch_mod, oracle_lib):
+    """4096 ALL_BIOLOGICAL flies (69 bodies, 132 dofs: hybrid kernel, 1792 resident -> chunked launches) settle and walk
+    on the tripod CPG; 12 worlds drawn from the batch against the float64 and float32 oracles stepping the same rows."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world = _model("all_biological")
+    sim = HIPSimulation(world, n_worlds=N, device=0)
+    assert sim.model.nv == 132 and sim.model.nb == 69
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    tdev = cpg.targets(N, 1250, device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    sim.set_leg_adhesion_states(fly.name, np.ones((N, 6), dtype=np.float32))
+    sim.step(300)
+    for k in range(3):
+        sim.step_replay(tdev, ids, 50 * k, 50)
+    torch.cuda.synchronize()
+    qpos = sim.field("qpos").cpu().numpy()
+    stats = sim.field("stats").cpu().numpy()
+    geom = sim.field("contact_geom").cpu().numpy()
+    assert np.isfinite(qpos).all() and int(sim.field("stats_sum")[:, 3].max()) == 0
+    picks = np.random.default_rng(5).choice(N, size=12, replace=False)
+    rows = tdev[torch.as_tensor(picks, device=sim.device)].cpu().numpy()
+    blob = sim.model.to_blob()
+    nu = sim.model.nu
+    bases = {}
+    for prec in ("f64", "f32"):
+        bases[prec] = oracle_lib.Oracle(blob, prec)
+        bases[prec].ctrl[nu - 6:] = 1.0
+        bases[prec].step(300)
+    ids_np = ids.cpu().numpy()
+    errs, errs64, same_contacts = [], [], []
+    for row, w in zip(rows, picks):
+        ref = {}
+        for prec in ("f64", "f32"):
+            ref[prec] = bases[prec].clone_data()
+            ref[prec].step_replay(row, ids_np, 0, 150)
+        e64, e32 = np.abs(qpos[w] - ref["f64"].qpos).max(), np.abs(qpos[w] - ref["f32"].qpos).max()
+        errs64.append(e64); errs.append(min(e64, e32))
+        nc = int(stats[w, 0])
+        same_contacts.append(any(nc == r.ints()["ncon"] and geom[w, :nc].astype(int).tolist() == r.ints()["con_geom"]
+                                 for r in ref.values()))
+    errs, errs64 = np.array(errs), np.array(errs64)
+    # same bars as the LEGS_ONLY batch test (tests/test_hip_parity_r2.py): the bulk to rounding against whichever oracle
+    # the engine's float32 rounding follows, every world bounded, contact lists equal to an oracle's
+    assert (errs < 5e-5).mean() >= 0.8, np.sort(errs)[-6:]
+    assert np.median(errs64) < 1e-5 and errs64.max() < 5e-3, np.sort(errs64)[-6:]
+    assert np.mean(same_contacts) >= 0.8
+    assert stats[:, 0].mean() > 3
+
+
+def test_config3_vision_at_full_size(torch_mod, bench_model):
+    """BASELINE config 3: 4096 flies with vision on.  Settle, then 200 steps of CPG walking with both compound eyes of
+    every fly rendered and resampled to 2 x 721 ommatidia every 20 steps (one fused launch per tick: nmf_eye_render).
+    Finite, in range, deterministic; and 16 eye views sampled from the last tick against the numpy specification
+    evaluated at the poses the engine reports — a frame through ``render_frames`` (pixel-exact up to float32 rounding at
+    material edges) and the fused readings (bit-identical to the resample of that frame)."""
+    torch = torch_mod
+    import sensors_oracle as so
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.vision import EyeRenderer, Scene
+    from test_sensors import _world_capsules
+
+    fly, world, _ = bench_model
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    table = cpg.targets(N, 1250, device="cuda:0")
+    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0)], sphere_rgb=[(0.9, 0.2, 0.1)])
+
+    def run():
+        sim = HIPSimulation(world, n_worlds=N, device=0)
+        eyes = EyeRenderer(sim, fly.name, scene)
+        ids = sim.replay_ids(fly.name)
+        sim.set_leg_adhesion_states(fly.name, np.ones((N, 6), dtype=np.float32))
+        sim.step(500)
+        ticks = []
+        for k in range(10):
+            sim.step_replay(table, ids, 20 * k, 20)
+            ticks.append(eyes.render())
+        torch.cuda.synchronize()
+        return sim, eyes, ticks
+
+    sim, eyes, ticks = run()
+    _, _, ticks2 = run()
+    for a, b in zip(ticks, ticks2):
+        assert a.shape == (N, 2, 721, 2) and a.dtype == torch.float32
+        assert torch.equal(a, b)                                              # deterministic, physics and rendering
+        assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert not torch.equal(ticks[0], ticks[-1])                               # the flies moved
+    assert len(torch.unique(ticks[-1].sum(dim=(1, 2, 3)))) > 1000             # the worlds see different things
+    assert torch.equal(eyes.render(), ticks[-1])                              # same poses, same readings
+    names = [s.name for s in fly.get_bodysegs_order()]
+    picks = np.random.default_rng(9).choice(N, size=16, replace=False)
+    xpos = sim.field("seg_xpos").cpu().numpy().reshape(N, 69, 3).astype(np.float64)
+    xquat = sim.field("seg_xquat").cpu().numpy().reshape(N, 69, 4).astype(np.float64)
+    frames, omm = eyes.render_frames(with_readings=True)                      # 4096 x 2 x 691 KB = 5.7 GB of raw frames
+    assert torch.equal(omm, ticks[-1])
+    body_seen = 0
+    for i, w in enumerate(picks):
+        e = i % 2
+        seg, pos, quat = eyes.cameras[e]
+        caps = _world_capsules(eyes, xpos[w], xquat[w])
+        Rs = so.quat_to_mat(xquat[w, names.index(seg)])
+        cam = xpos[w, names.index(seg)] + Rs @ pos
+        want = so.render_eye_frames(cam, Rs @ so.quat_to_mat(quat), 512, 450, 157.0, 4.0, 0.0, scene.sky_rgb, scene.ground_rgb,
+                                    scene.spheres, scene.sphere_rgb, capsules=caps, body_rgb=scene.body_rgb)
+        got = frames[int(w), e].cpu().numpy()
+        diff = (got != want).any(axis=-1).mean()
+        assert diff < 5e-3, f"world {w} eye {e}: {diff:.2e} of the pixels differ"
+        ref = so.retina_resample(want, eyes.retina.id_map, eyes.retina.pale_mask, eyes.retina.inv_norm)
+        assert np.abs(ticks[-1][int(w), e].cpu().numpy() - ref).max() < 1e-2
+        exact = so.retina_resample(got, eyes.retina.id_map, eyes.retina.pale_mask, eyes.retina.inv_norm)
+        assert np.array_equal(ticks[-1][int(w), e].cpu().numpy(), exact.astype(np.float32))
+        body_seen += int((want == np.array(scene.body_rgb, dtype=np.uint8)).all(axis=-1).sum())
+    assert body_seen > 8000
