@@ -77,6 +77,12 @@ def parse_args(argv=None):
     ap.add_argument("--joint-preset", choices=["legs_only", "legs_active_only", "all_biological"], default="legs_only",
                     help="skeleton: the benchmark's LEGS_ONLY (default) or the full-body ALL_BIOLOGICAL (hybrid kernel)")
     ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
+    ap.add_argument("--vision", choices=["off", "resample", "render"], default="off",
+                    help="BASELINE config 3: per vision tick (every --vision-every physics steps = one launch) both 512 x 450 eye "
+                         "frames of every fly become 2 x 721 ommatidia readings.  resample: synthetic raw frames resident in HBM "
+                         "(seeded noise over a checker floor) through the retina kernel — the HBM-bound kernel of the path; "
+                         "render: the eye views are ray-cast on the GPU, fused with the resample (no raw frames in HBM)")
+    ap.add_argument("--vision-every", type=int, default=20, help="physics steps per vision tick (20 = 500 Hz)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=200000)
@@ -244,6 +250,8 @@ def main():
     n_local = last_world - first_world
     if n_local <= 0:
         raise SystemExit("more ranks than worlds")
+    if args.vision != "off":
+        args.steps_per_launch = args.vision_every      # one launch per vision tick
     spl = max(1, min(args.steps_per_launch, args.steps))
     if args.steps % spl:
         spl = next(d for d in range(spl, 0, -1) if args.steps % d == 0)
@@ -265,6 +273,22 @@ def main():
         rng = np.random.default_rng(0)     # S = 3 sources, D = 2 dims, seeded within +-20 mm
         src = rng.uniform(-20, 20, (3, 3)); src[:, 2] = rng.uniform(0.5, 3.0, 3)
         odor = OdorSensors(sim, fly.name, src, rng.uniform(0.1, 1.0, (3, 2)))
+    see, frames, vision_out = None, None, None
+    if args.vision == "resample":
+        from flygym_amd.sensors import RAW_IMG_HEIGHT as H, RAW_IMG_WIDTH as W, Retina
+
+        retina = Retina()
+        g = torch.Generator(device=sim.device); g.manual_seed(first_world)
+        frames = torch.randint(0, 256, (n_local, 2, H, W, 3), dtype=torch.uint8, device=sim.device, generator=g)
+        yy, xx = torch.meshgrid(torch.arange(H, device=sim.device), torch.arange(W, device=sim.device), indexing="ij")
+        frames[:, :, ((yy // 32 + xx // 32) % 2 == 0) & (yy > H // 2)] //= 4          # darker checker floor
+        del yy, xx
+        see = lambda: retina.raw_image_to_hex_pxls(frames)
+    elif args.vision == "render":
+        from flygym_amd.vision import EyeRenderer, Scene
+
+        eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(8.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]))
+        see = lambda: eyes.render()
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
     if args.workload == "replay":
         table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
@@ -306,12 +330,17 @@ def main():
     n_events = repeats * n_launches
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)]
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)] if see is not None else None
 
     def control_tick(start, k=n_events):
         # the kernel is launched on torch's current stream, so these events bracket exactly it
         ev0[k].record()
         sim.step_replay(table, act_ids, start, spl)
         ev1[k].record()
+        if see is not None:                # the vision tick: ev1 .. ev2 bracket exactly the retina / eye kernel
+            nonlocal vision_out
+            vision_out = see()
+            ev2[k].record()
         if odor is not None:
             odor.get_odor_intensities()
         if gather is not None:
@@ -326,6 +355,7 @@ def main():
     # untimed: one tick to settle allocator / RCCL channels
     control_tick(cursor); cursor += spl
     fence()
+    sim.shader_clock_hz(reset=True)              # the clock probe counts the timed region's launches only
     sums0 = sim.field("stats_sum").clone()
     # ONE bracket (barrier + synchronize on both sides) around `repeats` back-to-back K-step regions: the mean region time
     # is (t1 - t0) / repeats.  The observation gather of a tick overlaps the next tick's stepping kernel across region
@@ -341,6 +371,7 @@ def main():
     fence()
     total_elapsed = time.perf_counter() - t0
     sums1 = sim.field("stats_sum").clone()
+    shader_clock_hz = sim.shader_clock_hz()
     elapsed_t = torch.tensor([total_elapsed], dtype=torch.float64, device=sim.device)
     if use_dist:
         dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)      # the slowest rank
@@ -384,13 +415,15 @@ def main():
             "frac_of_f32_vector_peak": flops * kernel_rate / 1e12 / VALU_PEAK_TFLOPS,
             "peak_tflops": VALU_PEAK_TFLOPS,
         }
-        if issue and issue.get("valu_insts_per_env_step") and issue.get("valu_cycles_per_inst"):
-            # vector-pipe occupancy from the measured issue cost of a wave64 VALU instruction (scripts/valu_issue_microbench.hip)
-            # and this run's kernel rate: instructions/s x cycles each / (SIMDs x clock)
-            clock = issue.get("shader_clock_hz", 2.4e9)
-            compute["valu_pipe_busy"] = issue["valu_insts_per_env_step"] * kernel_rate * issue["valu_cycles_per_inst"] / (1024 * clock)
+        compute["shader_clock_hz"] = shader_clock_hz       # measured inside the timed region's launches (nmf_shader_clock)
+        if issue and issue.get("valu_insts_per_env_step") and issue.get("valu_cycles_per_inst") and shader_clock_hz > 0:
+            # vector-pipe occupancy: instructions/s (the committed profile's count per env-step x this run's kernel rate) x
+            # the pipe cycles a wave64 VALU instruction takes (scripts/valu_issue_microbench.hip) / (1024 SIMDs x the clock
+            # THIS kernel ran at — not the throttled clock of the microbenchmark)
+            compute["valu_pipe_busy"] = issue["valu_insts_per_env_step"] * kernel_rate * issue["valu_cycles_per_inst"] / (1024 * shader_clock_hz)
         out = {
-            "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain",
+            "metric": "env-steps/sec (whole node), 4096 flies per GPU, flat terrain" + (
+                f", vision on (2 x 721-ommatidia retina per {args.vision_every} steps)" if args.vision != "off" else ""),
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "valid": valid,
@@ -400,7 +433,11 @@ def main():
                             + (", position-actuated tripod CPG gait (12 Hz, per-world phase offsets; BASELINE config 2)"
                                if args.workload == "cpg" else
                                ", position-actuated kinematic replay of the Spotlight tripod-walking clip "
-                               "(reference benchmark protocol)") + ", adhesion on",
+                               "(reference benchmark protocol)") + ", adhesion on"
+                            + ({"off": "", "resample": f"; vision on (BASELINE config 3): every {args.vision_every} steps both 512 x 450 raw eye "
+                                "frames of every fly (synthetic: seeded noise over a checker floor, resident in HBM) -> 2 x 721 x 2 ommatidia readings",
+                                "render": f"; vision on (BASELINE config 3): every {args.vision_every} steps both eye views of every fly are ray-cast "
+                                "(checker ground, sky, one sphere, the fly's own body) and resampled to 2 x 721 x 2 ommatidia readings in one kernel"}[args.vision]),
                 "control": args.workload,
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
                 "settle_steps": {"neutral": settle_neutral, "gait": settle_gait, "warmup": args.warmup},
@@ -416,6 +453,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # traffic / issue are NOT measured by this run: they are the rocprofv3 --pmc passes of the same command,
+                # committed under profiles/ and scaled to this launch length
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, fitted per world and per step)" if traffic is not None else None,
+                "issue_source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_* passes of this command)" if issue else None,
                 "kernel": {"legs_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>",
                            "legs_active_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1>, false>",
                            "all_biological": "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>",
@@ -429,6 +470,36 @@ def main():
                         "per launch); see DESIGN.md for the instruction-side analysis",
             },
         }
+        if see is not None:
+            # BASELINE config 3: the retina kernel is the HBM-bound kernel of the path, so IT carries the `roofline` block
+            # (2 x 512 x 450 x 3 B of raw frames in + 2 x 721 x 2 x 4 B of readings out per fly and tick);
+            # the stepping kernel's block stays beside it as `roofline_physics`.
+            vis_ms = float(np.mean([ev1[k].elapsed_time(ev2[k]) for k in range(n_events)]))
+            out["roofline_physics"] = out["roofline"]
+            frame_bytes = (int(frames[0, 0].numel()) if frames is not None else 0)
+            out_bytes = int(vision_out[0, 0].numel()) * 4
+            per_launch = 2 * n_local * (frame_bytes + out_bytes)
+            vt = None
+            vfile = ROOT / "profiles" / "vision_traffic.json"
+            if vfile.exists() and args.vision == "resample":
+                rec = json.loads(vfile.read_text())
+                vt = rec.get("traffic_bytes_per_eye_frame", 0) * 2 * n_local or None
+            ach = per_launch / (vis_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm" if args.vision == "resample" else "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": vt,
+                "traffic_source": "profiles/vision_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if vt else None,
+                "kernel": "nmf_retina_stream_kernel" if args.vision == "resample" else "nmf_eye_kernel",
+                "kernel_ms_per_launch": vis_ms, "eye_frames_per_launch": 2 * n_local,
+                "algorithmic_bytes_per_eye_frame": {"in": frame_bytes, "out": out_bytes},
+                "algorithmic_bytes_per_launch": per_launch,
+                "note": ("streams every raw frame once: HBM-bound by construction" if args.vision == "resample" else
+                         "ray-casts the views instead of reading frames: compute-bound, the HBM figure is the readings written only"),
+            }
+            if args.vision == "render":
+                out["roofline"]["rays_per_s"] = 2 * n_local * 512 * 450 / (vis_ms * 1e-3)
+            out["config"]["vision"] = {"mode": args.vision, "every_steps": args.vision_every, "kernel_ms_per_tick": vis_ms,
+                                       "physics_kernel_ms_per_tick": ms}
         if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
             n_rows = min(n_local, host_cores())
             rows = np.ascontiguousarray(table[:n_rows, :, :42].cpu().numpy())

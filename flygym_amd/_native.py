@@ -108,6 +108,7 @@ def lib():
             "nmf_gather": (ci, [vp, ci, vp, ci, ci, vp, vp]),
             "nmf_scatter": (ci, [vp, ci, vp, ci, vp, vp]),
             "nmf_step_count": (ctypes.c_int64, [vp]),
+            "nmf_shader_clock": (ci, [vp, ctypes.POINTER(ctypes.c_double), ci]),
             "nmf_time_launches": (ctypes.c_double, [vp, vp, ci, ci, vp, ci, ci, vp]),
             "nmf_retina_plan_bytes": (ctypes.c_size_t, [ci]),
             "nmf_retina_plan": (ci, [vp, ci, vp, vp]),

@@ -89,13 +89,15 @@ struct nmf_batch {
   nmf::SchedState* sched_buf = nullptr;
   int resident_waves = 0;        // step-kernel waves the device holds at once
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
-  unsigned int* chunk_done_buf = nullptr;
+  unsigned long long* handoff_buf = nullptr;   // chunk hand-off granules (nmf_step_kernel); allocated with the batch
+  int handoff_stride = 0;
+  unsigned long long* clock_probe_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  // schedule of launches with more worlds than resident waves (nmf_step_kernel): NMF_SCHED = auto (default) | paired |
-  // chunks | plain.  auto = paired (static, cost-balanced; no hand-over) for launches of at most paired_max_steps steps whose
-  // worlds fill the rounds evenly, chunks otherwise.
-  int sched_policy = 0;          // 0 auto, 1 paired, 2 chunks, 3 plain
-  int paired_max_steps = 64;     // NMF_PAIRED_MAX_STEPS
+  // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = costliest (default) | inorder | none
+  // (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
+  // faster, the other re-tried every 32nd launch — with chunked launches costliest-first wins everywhere: 20-step CPG
+  // launches 43.1 vs 42.5 M env-steps/s, replay 45.9 vs 45.0 M)
+  int order_policy = 1;          // 1 costliest first (default), 0 in order, 2 none, -1 the measured policy of rounds 1-2
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
   double chunk_div = 2.0;
 };
@@ -230,29 +232,16 @@ int launch_reset(nmf_batch* b, const uint8_t* mask_dev, hipStream_t stream) {
 
 int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t stream) {
   DEVICE_GUARD(b);      // the caller's current device need not be the batch's, and stays what it was
-  // More worlds than resident waves: a launch runs in rounds, and a world's cost (contacts, Newton iterations) spreads 2x
-  // over a gait cycle, so one workgroup per world in arbitrary order leaves the chip half empty while the costliest
-  // worlds finish.  Two remedies (nmf_step_kernel):
-  //  * paired — short launches: persistent workgroups, each steps a static, cost-balanced set of worlds (costliest with
-  //    cheapest, by the cycles of the previous launch) through the whole launch.  No hand-over at all.  Needs the worlds
-  //    to fill the rounds evenly (n_worlds / resident_waves close to an integer) and a cost that predicts the next launch.
-  //  * chunked — long launches: chunks whose lengths shrink towards the end of the launch ("guided" sizes: each takes
-  //    1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks), (chunk, world) items taken
-  //    from a ticket counter.  Measured on 4096 worlds, round 2: whole-launch items 32.0 / 31.9 M env-steps/s (20- /
-  //    50-step launches), halving chunks 42.4 / 44.4 M; each hand-over costs ~10 us (ticket, flag, 2 KB of state each way).
+  // More worlds than resident waves and a launch long enough to cut: chunks whose lengths shrink towards the end of the
+  // launch ("guided" sizes: each takes 1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks)
+  // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds,
+  // round 2: whole-launch items 32.0 / 31.9 M env-steps/s (20- / 50-step launches), 7 equal chunks 36.3 / 38.3 M, halving
+  // chunks (chunk_div 2: 10 + 5 + 3 + 1 + 1 steps) 42.4 / 44.4 M; a last chunk of one step (min_chunk_steps 1) is worth
+  // +1.2 % on 50-step launches.
   const bool oversub = b->n_worlds > b->resident_waves;
-  const int rounds = (b->n_worlds + b->resident_waves - 1) / std::max(1, b->resident_waves);
-  const double fill = (double)b->n_worlds / ((double)rounds * std::max(1, b->resident_waves));   // 1.0: every round full
-  int mode = 0;
-  if (oversub && b->order_buf && b->csched_buf) {
-    if (b->sched_policy == 1) mode = 2;
-    else if (b->sched_policy == 2) mode = 1;
-    else if (b->sched_policy == 0) mode = (n_steps <= b->paired_max_steps && fill >= 0.9) ? 2 : 1;
-  }
-  if (mode == 1 && !(b->chunking && n_steps >= 2 * b->min_chunk_steps)) mode = 0;
   int n_chunks = 1;
-  b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.chunk_done = b->chunk_done_buf;
-  if (mode == 1) {
+  b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.handoff = b->handoff_buf; b->st.handoff_stride = b->handoff_stride;
+  if (oversub && b->chunking && b->csched_buf && b->handoff_buf && n_steps >= 2 * b->min_chunk_steps) {
     int start = 0, c = 0;
     while (start < n_steps && c < b->max_chunks) {
       int len = (int)std::ceil((n_steps - start) / b->chunk_div);
@@ -264,21 +253,17 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
     b->st.chunk_start[c] = n_steps;
     n_chunks = c;
     b->st.n_chunks = c;
-    if (c < 2) mode = 0;
   }
-  b->st.sched_mode = mode;
-  // chunked / paired: one persistent workgroup per resident wave; plain: one workgroup per world
-  const unsigned n_groups = mode == 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks)
-                          : mode == 2 ? (unsigned)std::min(b->resident_waves, b->n_worlds) : (unsigned)b->n_worlds;
-  dim3 grid(n_groups), block(nmf::kWave);
-  // world order of the launch: paired — costliest first, always (the partition is built on it); otherwise the measured
-  // policy (in order / costliest first) of nmf_order_kernel
+  b->st.sched_mode = n_chunks > 1 ? 1 : 0;
+  // chunked: one persistent workgroup per resident wave pulls (chunk, world) items; plain: one workgroup per world
+  dim3 grid(n_chunks > 1 ? (unsigned)std::min(b->resident_waves, b->n_worlds * n_chunks) : (unsigned)b->n_worlds), block(nmf::kWave);
+  // more worlds than resident waves: the launch runs in rounds; the measured policy picks the world order (nmf_order_kernel)
   b->st.order = nullptr; b->st.sched = nullptr;
-  if (oversub && b->order_buf && b->sched_buf) {
+  if (oversub && b->order_buf && b->sched_buf && b->order_policy != 2) {
     hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps,
-                       mode == 2 ? 1 : -1);
+                       b->order_policy);
     b->st.order = b->order_buf;
-    if (mode != 2) b->st.sched = b->sched_buf;
+    if (b->order_policy < 0) b->st.sched = b->sched_buf;
   }
   const bool weld = b->dm.weld_active != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
@@ -488,17 +473,23 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->csched_buf = (nmf::ChunkSched*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     p = nullptr;
-    if (hipMalloc(&p, sizeof(unsigned int) * (size_t)n_worlds) == hipSuccess) {
-      (void)hipMemset(p, 0, sizeof(unsigned int) * (size_t)n_worlds);
-      b->allocs.push_back(p); b->chunk_done_buf = (unsigned int*)p;
+    b->handoff_stride = (model->nq + 2 * model->nv + model->nu + 6 + 63) / 64 * 64;      // state, controls, clock + 5 running sums
+    if (hipMalloc(&p, sizeof(unsigned long long) * (size_t)n_worlds * (size_t)b->handoff_stride) == hipSuccess) {
+      (void)hipMemset(p, 0, sizeof(unsigned long long) * (size_t)n_worlds * (size_t)b->handoff_stride);   // tag 0 = no launch's
+      b->allocs.push_back(p); b->handoff_buf = (unsigned long long*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
+    p = nullptr;
+    if (hipMalloc(&p, 2 * sizeof(unsigned long long)) == hipSuccess) {
+      (void)hipMemset(p, 0, 2 * sizeof(unsigned long long));
+      b->allocs.push_back(p); b->clock_probe_buf = (unsigned long long*)p;
+    } else rc |= fail("nmf_batch_create: out of device memory");
+    st.clock_probe = b->clock_probe_buf;
     b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
-    if (const char* e = getenv("NMF_SCHED")) {
+    if (const char* e = getenv("NMF_SCHED")) { if (std::string(e) == "plain") b->chunking = false; }
+    if (const char* e = getenv("NMF_ORDER")) {
       const std::string v(e);
-      b->sched_policy = v == "paired" ? 1 : v == "chunks" ? 2 : v == "plain" ? 3 : 0;
+      b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 1;
     }
-    if (!b->chunking && b->sched_policy == 0) b->sched_policy = 3;
-    if (const char* e = getenv("NMF_PAIRED_MAX_STEPS")) b->paired_max_steps = std::max(0, atoi(e));
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
@@ -624,6 +615,17 @@ extern "C" int nmf_scatter(nmf_batch* b, int field, const int32_t* ids_dev, int 
 }
 
 extern "C" int64_t nmf_step_count(const nmf_batch* b) { return b ? b->steps : 0; }
+
+extern "C" int nmf_shader_clock(nmf_batch* b, double* hz_out, int reset) {
+  if (!b || !hz_out) return fail("nmf_shader_clock: null argument");
+  DEVICE_GUARD(b);
+  unsigned long long v[2] = {0, 0};
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(v, b->clock_probe_buf, sizeof(v), hipMemcpyDeviceToHost));
+  *hz_out = v[1] ? 1e8 * (double)v[0] / (double)v[1] : 0.0;
+  if (reset) HIP_OK(hipMemset(b->clock_probe_buf, 0, sizeof(v)));
+  return 0;
+}
 
 extern "C" double nmf_time_launches(nmf_batch* b, const float* table_dev, int table_steps, int n_act,
                                     const int32_t* act_ids_dev, int n_steps, int reps, void* stream) {
@@ -768,6 +770,15 @@ extern "C" int nmf_replay_resample(const float* clip_dev, int n_frames, int n_co
   HIP_OK(hipGetLastError());
   return 0;
 }
+
+#ifdef NMF_SCHED_TRACE
+// diagnostic build only: per-workgroup schedule trace of the last stepping launch (see nmf_step.hip)
+extern "C" int nmf_debug_sched_trace(unsigned long long* out, int n_groups) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nmf::g_sched_trace), sizeof(unsigned long long) * 8 * (size_t)std::min(n_groups, 4096)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 #ifdef NMF_STAGE_PROFILE
 // diagnostic build only: cumulative s_memtime cycles per pipeline stage of wave 0

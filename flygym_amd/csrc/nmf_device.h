@@ -142,9 +142,13 @@ struct DevState {
   // chunked launches (nmf_step_kernel): a launch of n_steps is cut into chunks (chunk_start); workgroups take
   // (world, chunk) items from a ticket counter, a world's chunks hand its state over through HBM
   struct ChunkSched* csched;
-  unsigned int* chunk_done;   // [n_worlds] epoch * 32 + chunks of this launch the world has finished
+  // hand-off of a world's state between two chunks of one launch: [n_worlds][handoff_stride] 8-byte granules
+  // {float bits, tag}, tag = epoch * 32 + chunks of this launch the world has finished (see nmf_step_kernel)
+  unsigned long long* handoff;
+  int handoff_stride;
   int n_chunks;               // chunked schedule: number of chunks
-  int sched_mode;             // 0 plain (one workgroup per world), 1 chunked (tickets), 2 paired (static, cost-balanced): nmf_step_kernel
+  unsigned long long* clock_probe;   // [2] shader cycles / 100 MHz ticks workgroup 0 spent in stepping launches (nmf_shader_clock)
+  int sched_mode;             // 0 plain (one workgroup per world), 1 chunked (persistent workgroups, tickets): nmf_step_kernel
   int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 

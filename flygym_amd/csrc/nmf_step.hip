@@ -59,6 +59,26 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_FLUSH()
 #endif
 
+// Optional schedule trace (-DNMF_SCHED_TRACE, diagnostic library only): per workgroup of the last stepping launch — start and
+// exit time (s_memrealtime, 100 MHz), items taken, shader cycles spent stepping / between items (ticket, state in, state out)
+#ifdef NMF_SCHED_TRACE
+__device__ unsigned long long g_sched_trace[4096][8];
+#define TRACE_DECL() unsigned long long tr_busy_ = 0, tr_gap_ = 0, tr_items_ = 0, tr_mark_ = __builtin_amdgcn_s_memtime(), tr_sub_[3] = {0, 0, 0}, tr_sm_ = tr_mark_; const unsigned long long tr_t0_ = __builtin_amdgcn_s_memrealtime()
+// sub-marks inside the gap between two items: 0 = state out issued, 1 = ticket known, 2 = world known (order looked up); the rest is the state load
+#define TRACE_SUB(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_sub_[k] += t_ - tr_sm_; tr_sm_ = t_; } while (0)
+#define TRACE_SUB_RESET() do { tr_sm_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define TRACE_GAP_END() do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_gap_ += t_ - tr_mark_; tr_mark_ = t_; } while (0)
+#define TRACE_BUSY_END() do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_busy_ += t_ - tr_mark_; tr_mark_ = t_; tr_items_++; } while (0)
+#define TRACE_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { unsigned long long* q_ = g_sched_trace[blockIdx.x]; TRACE_GAP_END(); q_[0] = tr_t0_; q_[1] = __builtin_amdgcn_s_memrealtime(); q_[2] = tr_items_; q_[3] = tr_busy_; q_[4] = tr_gap_; q_[5] = tr_sub_[0]; q_[6] = tr_sub_[1]; q_[7] = tr_sub_[2]; } } while (0)
+#else
+#define TRACE_SUB(k)
+#define TRACE_SUB_RESET()
+#define TRACE_DECL()
+#define TRACE_GAP_END()
+#define TRACE_BUSY_END()
+#define TRACE_FLUSH()
+#endif
+
 // tree tables staged in LDS once per launch (bodies in breadth-first order; see nmf_capi.hip): body of BFS slot k, parent /
 // first dof / dof count / child range of body b, body of dof j, level starts
 // (sized for the bodies / dofs the tree sweeps touch: everything for the tree kernels, root + rest for the hybrid ones —
@@ -1274,9 +1294,20 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
   for (int k = 0; k < 4; k++) f[k] = c.jar[k] < 0.f ? -sign * c.D * c.jar[k] : 0.f;
 }
 
+// The control-table row of the NEXT step, requested from inside the current one.  Every non-inlined stage function begins
+// with `s_waitcnt vmcnt(0)` (the calling convention: a callee cannot know what is in flight), so a load issued right before
+// a call — round 2 requested the row at the top of the step, just ahead of the kinematics call — is waited for at once, HBM
+// latency and all, every step.  physics_forward issues it right after the collision stage returns: ~8 k cycles of inlined
+// work (contact parameters, velocities, bias forces, actuation) follow before the next call.
+struct CtrlPrefetch {
+  const float* next_row;    // table row of the next step (nullptr: none)
+  bool mine;                // this lane carries a column
+  float value;              // the lane's entry of that row, once loaded
+};
+
 // ------------------------------------------------------------------ the step
 template <class TP, bool WELD>
-__device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last STAGE_ARG) {
+__device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, CtrlPrefetch& pf STAGE_ARG) {
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) { s.rest_fact_valid = 0; s.reduced = 0; } } }   // new configuration: new factors
   stage_kinematics(s, m, lane);
@@ -1284,6 +1315,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   stage_inertia(s, m, lane);
   STAGE(2);
   stage_collision(s, m, lane);
+  if (pf.next_row && pf.mine) pf.value = G(pf.next_row)[lane];      // consumed at the top of the next step
   if (last) write_poses(s, m, st, w, lane);       // the body poses die here (their LDS is the solver's from now on)
   STAGE(3);
   const int ncon = s.ncon;
@@ -1746,12 +1778,41 @@ __device__ __forceinline__ void st_state(float* p, float v) { __hip_atomic_store
 __device__ __forceinline__ void add_state(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void add_count(unsigned int* p, unsigned int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Hand-off between two chunks of a launch: DATA-TAGGED GRANULES.  Every float of the state travels as one 8-byte word
+// {float bits, tag} written and read with ONE 64-bit relaxed agent-scope atomic (global_store / global_load_dwordx2 sc1:
+// single-copy atomic by the memory model, never torn, never served from a non-coherent cache).  The tag names the
+// launch and the number of chunks the world has finished, so a granule is valid exactly when its tag is the one the
+// reader expects — each granule on its own.  No flag, hence no "all stores done before the flag" drain on the writer
+// (it goes straight on to its next item) and no flag round trip before the state loads on the reader: one batch of loads,
+// re-issued only if a tag is still old.  (Round 2 handed over through the state arrays + a per-world flag: writer
+// s_waitcnt vmcnt(0) -> flag store; reader flag poll -> state loads — ~12 us per item against ~5 us now.)
+__device__ __forceinline__ void st_tagged(unsigned long long* p, float v, unsigned int tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_tagged(const unsigned long long* p, unsigned int want, bool& ok) {
+  const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ok = ok && (unsigned int)(g >> 32) == want;
+  return __uint_as_float((unsigned int)g);
+}
+
 // `final`: this item ends the launch.  Pure outputs (plain stores: qacc, stats — like the pose / sensor / force outputs of
 // the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
 // otherwise reach memory after the final one's.
 template <class TP>
-__device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane, float time, bool final) {
+__device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane, float time, bool final,
+                              unsigned int tag = 0u, float carry = 0.f) {
   lane = opaque(lane);     // once per item: keep its address arithmetic out of the registers the steps live in
+  if (!final) {            // an inner chunk of a chunked launch: the state goes to the world's next item as tagged granules
+    unsigned long long* hb = st.handoff + (size_t)w * st.handoff_stride;
+    const int nq = s.nq(), nv = s.nv();
+    for (int i = lane; i < nq; i += kWave) st_tagged(&hb[i], s.qpos[i], tag);
+    for (int i = lane; i < nv; i += kWave) { st_tagged(&hb[nq + i], s.qvel[i], tag); st_tagged(&hb[nq + nv + i], s.qacc[i], tag); }
+    for (int i = lane; i < m.nu; i += kWave) st_tagged(&hb[nq + 2 * nv + i], s.ctrl[i], tag);
+    // lanes 0..5: the clock and what the world's items have accumulated so far (steps, contacts, iterations, overflow steps —
+    // as integer bit patterns — and cycles): one store; the launch's final item adds them to the world's counters
+    if (lane < 6) st_tagged(&hb[nq + 2 * nv + m.nu + lane], lane == 0 ? time : carry, tag);
+    return;
+  }
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
@@ -1884,42 +1945,40 @@ __global__ void __launch_bounds__(kWave) nmf_reset_kernel(const DevModel* __rest
   if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
 }
 
-// Step n_steps times.  Which world, which steps — three schedules (DevState::sched_mode):
+// Step n_steps times.  Which world, which steps — two schedules (DevState::sched_mode):
 //   plain   (0): workgroup b steps world order[b] through all n_steps and exits (every world resident at once).
-//   chunked (1): more worlds than resident waves, long launches.  The launch is cut into n_chunks chunks (long first, short
-//     last), the grid is one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket
-//     counter until the counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost
-//     varies 2x with its gait phase, so whole-launch items in arbitrary order leave the machine half empty while the
-//     costliest worlds finish; with chunks the tail is one chunk long.  An item waits for its world's previous chunk (an
-//     older ticket, hence taken by a workgroup that is running or done: no deadlock whatever the dispatch order) and
-//     takes the state over through HBM (ld_state / st_state).
-//   paired  (2): more worlds than resident waves, short launches (a control tick of 20 steps).  Every hand-over of the
-//     chunked schedule costs ~10 us (ticket, flag, 2 KB of state each way) — 8 % of a 20-step launch.  Here the grid is
-//     again one persistent workgroup per resident wave, but workgroup b steps the worlds of ranks b, 2R-1-b, 2R+b, 4R-1-b,
-//     ... (R = grid size) of `order`, which nmf_order_kernel sorted costliest first by the cycles each world took in the
-//     previous launch: the costliest world shares a workgroup with the cheapest, the second costliest with the second
-//     cheapest, ...  A world's cost changes by a few per cent from one short launch to the next (the gait advances 2.4 % of
-//     a cycle in 20 steps), so the static partition is balanced without tickets, flags or a state hand-over.
+//   chunked (1): more worlds than resident waves.  The launch is cut into n_chunks chunks (long first, short last), the
+//     grid is one PERSISTENT workgroup per resident wave, and each takes (chunk, world) items from a ticket counter until
+//     the counter runs out: ticket t = (chunk t / n_worlds, world order[t % n_worlds]).  A world's cost varies 2x with its
+//     gait phase (and by +-30 % from one 20-step launch to the next: contact events), so whole-launch items leave the
+//     machine half empty while the costliest worlds finish; with chunks the tail is one chunk long.  An item's state
+//     comes from the world's previous chunk — an older ticket, hence taken by a workgroup that is running or done: no
+//     deadlock whatever the dispatch order — as data-tagged granules (st_tagged / ld_tagged).
+//   (Measured and dropped, round 3: a static cost-balanced partition — persistent workgroups stepping the worlds of ranks
+//    b, 2R-1-b, ... of the cost order through the whole launch, no hand-over at all.  A world's cost predicts its next
+//    launch's only to r = 0.88, and the costliest world takes 1.6x the mean: the costliest-with-cheapest pair sums spread
+//    to 1.30x their mean, 35.9 M env-steps/s against 42.4 M chunked on 20-step launches.)
 // The model constants staged above stay in LDS from item to item.  Worlds are independent: the schedule never changes a result.
 template <class TP, bool WELD>
 __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(waves_per_simd<TP>(), waves_per_simd<TP>()))) nmf_step_kernel(const DevModel* __restrict__ mp, DevState st, ReplayArgs rp, int n_steps) {
   __shared__ FlyLds<TP> s;
   const GModel& m = *(const GModel*)mp;      // the model lives in HBM: its fields load as global memory in every function
-  stage_launch_constants(s, m);
+  const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+  TRACE_DECL();
   const int lane = threadIdx.x;
+  const bool chunked = st.sched_mode == 1;
+  // the first ticket is requested before the launch constants are staged: its round trip hides behind them
+  unsigned int t_next = 0;
+  if (chunked && lane == 0) t_next = atomicAdd(&st.csched->ticket, 1u);
+  stage_launch_constants(s, m);
   STAGE_INIT();
-  const bool chunked = st.sched_mode == 1, paired = st.sched_mode == 2;
   const int n_chunks = chunked ? st.n_chunks : 1;
   const unsigned int epoch = chunked ? (unsigned int)__builtin_amdgcn_readfirstlane((int)st.csched->epoch) : 0u;
-  for (int round = 0;; ++round) {
+  for (;;) {
     int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
     if (chunked) {
-      // (taking the next item's ticket while the current one runs hides the counter's round trip but was measured 7 %
-      // slower: items must go to whoever is free, or the launch's tail grows back; taking it while the finished item's
-      // state drains to HBM changes nothing)
-      unsigned int t = 0;
-      if (lane == 0) t = atomicAdd(&st.csched->ticket, 1u);
-      t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+      const unsigned int t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t_next);
+      TRACE_SUB(1);
       if (t >= (unsigned int)st.n_worlds * (unsigned int)n_chunks) {
         // out of items.  The last workgroup to get here rewinds the counters for the next launch (no host-side state,
         // so hipGraph replays stay valid); every workgroup has taken its final ticket by then.
@@ -1930,22 +1989,14 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       }
       chunk = (int)(t / (unsigned int)st.n_worlds); slot = (int)(t % (unsigned int)st.n_worlds);
       step0 = st.chunk_start[chunk]; step1 = st.chunk_start[chunk + 1];
-    } else if (paired) {
-      const int R = (int)gridDim.x;
-      slot = (round & 1) ? (round + 1) * R - 1 - (int)blockIdx.x : round * R + (int)blockIdx.x;   // boustrophedon over the cost ranks
-      if (slot >= st.n_worlds) break;       // ranks grow with the round: nothing further for this workgroup
     } else if (slot >= st.n_worlds) return;
     const int w = __builtin_amdgcn_readfirstlane(st.order ? st.order[slot] : slot);     // wave-uniform: lives in a scalar register
-    if (chunked && chunk > 0) {
-      const unsigned int want = (unsigned int)__builtin_amdgcn_readfirstlane((int)(epoch * 32u + (unsigned int)chunk));
-      if (lane == 0) while (__hip_atomic_load(&st.chunk_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(16);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the flag first, then the state (agent-scope loads below)
-      __syncthreads();
-    }
+    TRACE_SUB(2);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     float time;
-    unsigned int sum_con = 0u, sum_it = 0u, sum_of = 0u;     // lane 0: running sums over the steps of this item
+    float carry = 0.f;       // lanes 1..5: what the world's earlier items of this launch accumulated (steps, contacts, iterations, overflow steps, cycles)
+    unsigned int sum_con = 0u, sum_it = 0u, sum_of = 0u;     // running sums over the steps of this item (wave-uniform)
     {
       // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
       // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path; the item's first
@@ -1953,47 +2004,87 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       const float* tab = rp.table ? rp.table + (size_t)w * rp.table_steps * rp.n_act : nullptr;
       const int ln = opaque(lane);      // once per item (see write_outputs)
       const int my_ctrl = tab && lane < rp.n_act ? rp.act_ids[ln] : -1;
-      float next_ctrl = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;
-      for (int i = ln; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
-      for (int i = ln; i < s.nv(); i += kWave) {
-        s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
-        s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
+      CtrlPrefetch pf;
+      pf.mine = my_ctrl >= 0; pf.next_row = nullptr;
+      pf.value = my_ctrl >= 0 ? tab[(size_t)((rp.start + step0) % rp.table_steps) * rp.n_act + lane] : 0.f;     // the item's first row travels with the state
+      if (chunk > 0) {
+        // the world's previous chunk (an older ticket: its item is running or done) leaves the state as tagged granules
+        const unsigned int want = (unsigned int)__builtin_amdgcn_readfirstlane((int)(epoch * 32u + (unsigned int)chunk));
+        const unsigned long long* hb = st.handoff + (size_t)w * st.handoff_stride;
+        const int nq = s.nq(), nv = s.nv();
+        for (;;) {
+          bool ok = true;
+          for (int i = ln; i < nq; i += kWave) s.qpos[i] = ld_tagged(&hb[i], want, ok);
+          for (int i = ln; i < nv; i += kWave) { s.qvel[i] = ld_tagged(&hb[nq + i], want, ok); s.qacc[i] = ld_tagged(&hb[nq + nv + i], want, ok); }
+          for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_tagged(&hb[nq + 2 * nv + i], want, ok);
+          carry = lane < 6 ? ld_tagged(&hb[nq + 2 * nv + m.nu + ln], want, ok) : 0.f;     // lane 0: the clock; 1..5: running sums
+          if (!__any(!ok)) break;            // wave-uniform: every granule carried the expected tag
+          __builtin_amdgcn_s_sleep(8);
+        }
+        time = readlane_f(carry, 0);
+      } else {
+        for (int i = ln; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
+        for (int i = ln; i < s.nv(); i += kWave) {
+          s.qvel[i] = ld_state(&st.qvel[(size_t)w * s.nv() + i]);
+          s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
+        }
+        for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
+        time = ld_state(&st.time[w]);
       }
-      for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
-      time = ld_state(&st.time[w]);
       WSYNC();
+      TRACE_GAP_END();
       for (int step = step0; step < step1; ++step) {
         if (tab) {
-          if (my_ctrl >= 0) s.ctrl[my_ctrl] = next_ctrl;
+          if (my_ctrl >= 0) s.ctrl[my_ctrl] = pf.value;
           const float* src = tab + (size_t)((rp.start + step) % rp.table_steps) * rp.n_act;
           for (int a = opaque(lane) + kWave; a < rp.n_act; a += kWave) s.ctrl[rp.act_ids[a]] = src[a];     // (more than 64 controls: hybrid / tree kernels)
-          if (my_ctrl >= 0 && step + 1 < step1) next_ctrl = tab[(size_t)((rp.start + step + 1) % rp.table_steps) * rp.n_act + lane];
+          pf.next_row = step + 1 < step1 ? tab + (size_t)((rp.start + step + 1) % rp.table_steps) * rp.n_act : nullptr;
           WSYNC();
         }
+#ifdef NMF_TICKET_EARLY
+        // (experiment) the next item's ticket one step before this item ends: its round trip is off the item boundary
+        if (chunked && lane == 0 && step == step1 - 1) t_next = atomicAdd(&st.csched->ticket, 1u);
+#endif
         STAGE(0);
-        physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1 STAGE_PASS);     // pure outputs: the launch's last step only
+        physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, pf STAGE_PASS);     // pure outputs: the launch's last step only
         physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
         STAGE(15);
         time += m.timestep;
-        if (lane == 0) { sum_con += (unsigned int)s.ncon; sum_it += (unsigned int)s.iters; sum_of += (unsigned int)s.overflow; }
+        sum_con += (unsigned int)s.ncon; sum_it += (unsigned int)s.iters; sum_of += (unsigned int)s.overflow;
       }
     }
-    write_outputs(s, m, st, w, lane, time, step1 == n_steps);
-    if (lane == 0) {
-      // accumulators: integer adds the item does not wait for (uint32: exact up to 4.29e9 — at ~6 contacts per step that is
-      // 7e8 steps of one world between two resets)
-      unsigned int* q = &st.stats_sum[4 * (size_t)w];
-      add_count(q, (unsigned int)(step1 - step0)); add_count(q + 1, sum_con); add_count(q + 2, sum_it); add_count(q + 3, sum_of);
+    TRACE_BUSY_END();
+    TRACE_SUB_RESET();
+#ifndef NMF_TICKET_EARLY
+    // the next item's ticket BEFORE this item's state goes out: a wave's memory operations complete in order, so a ticket
+    // requested behind the ~1300 write-through stores of the hand-off would come back only after all of them
+    if (chunked && lane == 0) t_next = atomicAdd(&st.csched->ticket, 1u);
+#endif
+    {
+      // the world's running sums of this launch: lane 1 steps, 2 contacts, 3 solver iterations, 4 overflow steps (integers as
+      // bit patterns), 5 shader cycles (float).  Inner items pass them on with the state; the final item adds them to the
+      // world's counters — integer adds it does not wait for (uint32: exact up to 4.29e9 — at ~6 contacts per step that
+      // is 7e8 steps of one world between two resets)
+      const unsigned int own = lane == 1 ? (unsigned int)(step1 - step0) : lane == 2 ? sum_con : lane == 3 ? sum_it : sum_of;
       const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
-      if (chunk > 0) add_state(&st.cost[w], cyc); else st_state(&st.cost[w], cyc);     // the world's cycles over the whole launch
-      if (st.sched) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      if (lane >= 1 && lane <= 4) carry = __uint_as_float(__float_as_uint(carry) + own);
+      if (lane == 5) carry += cyc;
+      const bool final = step1 == n_steps;
+      write_outputs(s, m, st, w, lane, time, final, epoch * 32u + (unsigned int)(chunk + 1), carry);
+      if (final) {
+        if (lane >= 1 && lane <= 4) add_count(&st.stats_sum[4 * (size_t)w + opaque(lane) - 1], __float_as_uint(carry));
+        if (lane == 5) st_state(&st.cost[w], carry);     // the world's cycles over the whole launch
+      }
+      if (st.sched && lane == 0) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
-    if (!chunked && !paired) break;
-    if (chunked) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the state this item wrote (agent-scope stores) is out
-      __syncthreads();                                                  // ... for every lane, before the hand-off flag
-      if (lane == 0) __hip_atomic_store(&st.chunk_done[w], epoch * 32u + (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else __syncthreads();      // paired: the next world's state load overwrites LDS the stores above still read
+    if (!chunked) break;
+    TRACE_SUB(0);
+    __syncthreads();      // the next item's state loads overwrite the LDS the stores above read
+  }
+  TRACE_FLUSH();
+  if (blockIdx.x == 0 && lane == 0 && st.clock_probe) {      // the clock this launch ran at (nmf_shader_clock)
+    atomicAdd(&st.clock_probe[0], __builtin_amdgcn_s_memtime() - probe_c0);
+    atomicAdd(&st.clock_probe[1], __builtin_amdgcn_s_memrealtime() - probe_r0);
   }
   STAGE(16);
   STAGE_FLUSH();
@@ -2029,7 +2120,7 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
 // a smoothed duration per step is kept for both orders (restarted when the launch length changes), the better one is
 // used and the other re-tried every 32nd launch.  Costliest-first = one workgroup: min / max, 256-bin histogram of the quantised cost, exclusive prefix from
 // the top bin, scatter.  Worlds are independent: the order changes the schedule only, never a result.
-// force_policy >= 0 (the paired schedule needs costliest-first) bypasses the measured choice and its bookkeeping.
+// force_policy >= 0 (NMF_ORDER = inorder / costliest, diagnostics) bypasses the measured choice and its bookkeeping.
 __global__ void __launch_bounds__(1024) nmf_order_kernel(const float* __restrict__ cost, int n, int* __restrict__ order,
                                                          SchedState* __restrict__ sched, int n_steps, int force_policy) {
   __shared__ unsigned int lo, hi, hist[256], base[256];   // lo / hi: bit patterns of non-negative floats order like the floats

@@ -249,6 +249,13 @@ class HIPSimulation:
         self._profile_events.clear()
         self._physics_time_folded_ns = int(value)
 
+    def shader_clock_hz(self, reset: bool = False) -> float:
+        """Shader clock (Hz) the stepping launches since the last ``reset=True`` call ran at (``nmf_shader_clock``;
+        synchronises).  0.0 if there were none."""
+        hz = ctypes.c_double(0.0)
+        _native.check(self._lib.nmf_shader_clock(self._batch_h, ctypes.byref(hz), int(reset)))
+        return float(hz.value)
+
     def warmup(self, duration_s: float = 0.05) -> None:
         n = int(duration_s / self.timestep)
         if n > 0:

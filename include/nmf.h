@@ -109,6 +109,13 @@ int64_t nmf_step_count(const nmf_batch* batch);
 double nmf_time_launches(nmf_batch* batch, const float* table_dev, int table_steps, int n_act,
                          const int32_t* act_ids_dev, int n_steps, int reps, void* stream);
 
+/* Measurement helper: the shader clock the stepping kernel actually ran at.  Workgroup 0 of every stepping launch reads
+ * the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts and when it
+ * ends; the library accumulates both differences.  *hz_out = 1e8 * (shader cycles) / (100 MHz ticks) over the launches
+ * since the last call with reset != 0 (0 if there were none).  Synchronises with the device.  No reference
+ * counterpart: bench.py prices the kernel's instruction issue against the clock of the run it measures. */
+int nmf_shader_clock(nmf_batch* batch, double* hz_out, int reset);
+
 /* ---- sensors the north star names; the reference snapshot holds only their constants
  * (src/flygym/assets/model/legacy/flygym1_config.yaml:141-192), so semantics are build-defined. ---- */
 

@@ -1,7 +1,7 @@
 """Round-3 parity tests on MI355X: every kernel instantiation and every BASELINE config at its real size.
 
-* the three launch schedules of ``nmf_step_kernel`` (plain, chunked with state hand-over, paired / cost-balanced) are
-  bit-identical on 4096 worlds — for the LEGS_ONLY, LEGS_ACTIVE_ONLY (star kernels) and ALL_BIOLOGICAL (hybrid kernel)
+* the launch schedules of ``nmf_step_kernel`` (whole-launch items; chunked with the state handed over as data-tagged
+  granules, under every world-order policy) are bit-identical on 4096 worlds — for the LEGS_ONLY, LEGS_ACTIVE_ONLY (star kernels) and ALL_BIOLOGICAL (hybrid kernel)
   skeletons and a tethered world (``WELD = true`` instantiation), plain launches and hipGraph replays;
 * worlds drawn from a 4096-world ALL_BIOLOGICAL batch walking on the tripod CPG follow the float64 / float32 oracle
   (the hybrid kernel's reduced Newton problem at the size ``bench.py --joint-preset all_biological`` runs);
@@ -52,12 +52,12 @@ def _model(kind):
 
 @pytest.mark.parametrize("kind", ["legs_only", "legs_active_only", "all_biological", "tethered"])
 def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
-    """More worlds than resident waves: a launch is either cut into (chunk, world) items pulled by persistent workgroups,
-    a world's state crossing HBM between chunks, or stepped by persistent workgroups over a static cost-balanced partition
-    of the worlds (nmf_step_kernel: chunked / paired).  Scheduling must never change a result: 4096 worlds through a
-    settle, CPG walking in 50-, 20- and 9-step launches and four 30-step launches (eager, and captured in a hipGraph and
-    replayed — the schedulers keep no host-side state) give every state array, the clock and the running sums bit for
-    bit under NMF_SCHED = chunks / paired / plain and under the default policy."""
+    """More worlds than resident waves: a launch is cut into (chunk, world) items pulled by persistent workgroups, and a
+    world's state travels from one chunk's workgroup to the next's as data-tagged 8-byte granules (nmf_step_kernel).
+    Scheduling must never change a result: 4096 worlds through a settle, CPG walking in 50-, 20- and 9-step launches and
+    four 30-step launches (eager, and captured in a hipGraph and replayed — the scheduler keeps no host-side state) give
+    every state array, the clock and the running sums bit for bit with whole-launch items (NMF_SCHED=plain), with the
+    default chunked schedule, and under every world-order policy (NMF_ORDER)."""
     torch = torch_mod
     from flygym_amd import HIPSimulation
     from flygym_amd.controllers import TripodCPG
@@ -67,11 +67,11 @@ def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
     table = cpg.targets(N, 1250, device="cuda:0")
     n50 = 47 if kind == "legs_only" else 12
 
-    def run(sched, graphed=False):
-        if sched is None:
-            monkeypatch.delenv("NMF_SCHED", raising=False)
-        else:
-            monkeypatch.setenv("NMF_SCHED", sched)        # read when the batch is created
+    def run(env, graphed=False):
+        for k in ("NMF_SCHED", "NMF_ORDER", "NMF_MAX_CHUNKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                      # read when the batch is created
         sim = HIPSimulation(world, n_worlds=N, device=0)
         ids = sim.replay_ids(fly.name)
         sim.set_leg_adhesion_states(fly.name, np.ones((N, 6), dtype=np.float32))
@@ -99,11 +99,13 @@ def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
         return {k: sim.field(k).clone() for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "time", "stats_sum", "stats",
                                                  "sensordata", "seg_xpos", "contact_geom", "actuator_force")}
 
-    plain = run("plain")
-    for name, got in (("chunks", run("chunks")), ("paired", run("paired")), ("default policy", run(None)),
-                      ("default policy, hipGraph", run(None, graphed=True)), ("chunks, hipGraph", run("chunks", graphed=True))):
+    plain = run({"NMF_SCHED": "plain"})
+    for name, got in (("chunked (default)", run({})), ("chunked, hipGraph", run({}, graphed=True)),
+                      ("chunked, worlds in index order", run({"NMF_ORDER": "none"})),
+                      ("chunked, measured order policy", run({"NMF_ORDER": "policy"})),
+                      ("chunked, 16 chunks", run({"NMF_MAX_CHUNKS": "16"}, graphed=True))):
         for k in plain:
-            assert torch.equal(got[k], plain[k]), f"{kind}: schedule '{name}' differs from plain launches in {k}"
+            assert torch.equal(got[k], plain[k]), f"{kind}: schedule '{name}' differs from whole-launch items in {k}"
     assert int(plain["stats_sum"][:, 0].min()) == int(plain["stats_sum"][:, 0].max()) == 500 + 50 * n50 + 20 + 9 + 120
     assert bool(torch.isfinite(plain["qpos"]).all())
     if kind == "tethered":
