@@ -66,10 +66,12 @@ def _compile(verbose: bool) -> Path:
     # Arithmetic: divisions and square roots to 1-2.5 ulp (v_rcp / v_sqrt without the correctly-rounded fix-up sequences),
     # reassociation and no signed zeros (+3.7 % together); NaN / Inf semantics are kept (no -ffinite-math-only), and the
     # only transcendental of the step, the joint-angle sincos, is the kernel's own polynomial (nmf_device.h).
+    # No atomic optimizer: the kernels' atomics are one-lane ticket / counter operations; the optimizer rewrites a returning
+    # one into a wave-wide form that waits for the value at once (the chunk scheduler requests its ticket ahead of use).
     tmp = LIB_PATH.with_name(LIB_PATH.name + f".{os.getpid()}.tmp")
     cmd = [
         "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-        *MATH_FLAGS, "-fPIC", "-shared",
+        *MATH_FLAGS, "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC", "-shared",
         f"-I{INCLUDE}", f"-I{CSRC}", str(CSRC / "nmf_capi.hip"), "-o", str(tmp),
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)

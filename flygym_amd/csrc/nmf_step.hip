@@ -1308,6 +1308,10 @@ struct CtrlPrefetch {
 // ------------------------------------------------------------------ the step
 template <class TP, bool WELD>
 __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, CtrlPrefetch& pf STAGE_ARG) {
+  // hybrid kernels: per-lane addresses are rebuilt every step instead of living across the item loop — hoisted, they left
+  // the 132-dof kernel 19 spilled registers and a dozen scratch reloads per step (the 72-dof kernels have the registers to
+  // keep them: recomputing costs those 2 %)
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) { s.rest_fact_valid = 0; s.reduced = 0; } } }   // new configuration: new factors
   stage_kinematics(s, m, lane);
@@ -1744,6 +1748,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 
 template <class TP, bool WELD>
 __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane STAGE_ARG) {
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
@@ -1968,17 +1973,17 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
   const int lane = threadIdx.x;
   const bool chunked = st.sched_mode == 1;
   // the first ticket is requested before the launch constants are staged: its round trip hides behind them
-  unsigned int t_next = 0;
-  if (chunked && lane == 0) t_next = atomicAdd(&st.csched->ticket, 1u);
+  unsigned int t_first = 0;
+  if (chunked && lane == 0) t_first = atomicAdd(&st.csched->ticket, 1u);
   stage_launch_constants(s, m);
+  unsigned int t_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)t_first);
   STAGE_INIT();
   const int n_chunks = chunked ? st.n_chunks : 1;
   const unsigned int epoch = chunked ? (unsigned int)__builtin_amdgcn_readfirstlane((int)st.csched->epoch) : 0u;
   for (;;) {
     int slot = (int)blockIdx.x, chunk = 0, step0 = 0, step1 = n_steps;
     if (chunked) {
-      const unsigned int t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t_next);
-      TRACE_SUB(1);
+      const unsigned int t = t_next;
       if (t >= (unsigned int)st.n_worlds * (unsigned int)n_chunks) {
         // out of items.  The last workgroup to get here rewinds the counters for the next launch (no host-side state,
         // so hipGraph replays stay valid); every workgroup has taken its final ticket by then.
@@ -2041,10 +2046,6 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           pf.next_row = step + 1 < step1 ? tab + (size_t)((rp.start + step + 1) % rp.table_steps) * rp.n_act : nullptr;
           WSYNC();
         }
-#ifdef NMF_TICKET_EARLY
-        // (experiment) the next item's ticket one step before this item ends: its round trip is off the item boundary
-        if (chunked && lane == 0 && step == step1 - 1) t_next = atomicAdd(&st.csched->ticket, 1u);
-#endif
         STAGE(0);
         physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, pf STAGE_PASS);     // pure outputs: the launch's last step only
         physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
@@ -2055,11 +2056,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     }
     TRACE_BUSY_END();
     TRACE_SUB_RESET();
-#ifndef NMF_TICKET_EARLY
     // the next item's ticket BEFORE this item's state goes out: a wave's memory operations complete in order, so a ticket
-    // requested behind the ~1300 write-through stores of the hand-off would come back only after all of them
-    if (chunked && lane == 0) t_next = atomicAdd(&st.csched->ticket, 1u);
-#endif
+    // requested behind the write-through stores of the hand-off would come back only after all of them.  (The build
+    // switches the compiler's atomic optimizer off: it rewrites a one-lane atomic with a returned value into a wave-wide
+    // form that waits for the return on the spot.)  Measured and dropped: taking the ticket a step earlier (after the
+    // collision stage of the item's last step: +0.3 % on 20-step launches, -0.2 % on 50-step ones).
+    unsigned int t_new = 0;
+    if (chunked && lane == 0) t_new = atomicAdd(&st.csched->ticket, 1u);
     {
       // the world's running sums of this launch: lane 1 steps, 2 contacts, 3 solver iterations, 4 overflow steps (integers as
       // bit patterns), 5 shader cycles (float).  Inner items pass them on with the state; the final item adds them to the
@@ -2079,6 +2082,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     }
     if (!chunked) break;
     TRACE_SUB(0);
+    t_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)t_new);      // scalar across the loop's back edge
+    TRACE_SUB(1);
     __syncthreads();      // the next item's state loads overwrite the LDS the stores above read
   }
   TRACE_FLUSH();

@@ -7,6 +7,6 @@ NAME=$1; shift
 mkdir -p "$ROOT/build"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp \
   -fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math -fno-signed-zeros -fassociative-math -fno-trapping-math \
-  -fno-math-errno -fapprox-func -fPIC -shared "$@" -I"$ROOT/include" -I"$ROOT/flygym_amd/csrc" \
+  -fno-math-errno -fapprox-func -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared "$@" -I"$ROOT/include" -I"$ROOT/flygym_amd/csrc" \
   "$ROOT/flygym_amd/csrc/nmf_capi.hip" -o "$ROOT/build/libnmf_$NAME.so" 2>&1 | grep -v "occupancy target\|nmf_step_kernel(const\|\^\|warnings generated" || true
 python "$ROOT/scripts/kernel_stats.py" "$ROOT/build/libnmf_$NAME.so" | grep "step_kernel" | head -4
