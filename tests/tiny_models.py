@@ -1,0 +1,72 @@
+"""Hand-built one-body models for closed-form contact tests (test helper).
+
+A single free body of mass ``mass`` carrying one contact geom — a sphere, written as a capsule with coincident ends, so
+the collision stage reports its two end-sphere contacts at the same point — over a ground plane with an arbitrary unit
+normal.  Everything the engine needs is written out by hand in the compiled-model format
+(``flygym_amd.compiler.model.CompiledModel``): nothing of the fly's model compiler is involved, so the contact
+constants under test (``pair_solref`` / ``pair_solimp`` / friction / margin, ``geom_invweight0``) are exactly the ones
+given here.  The rotational inertia is made huge: friction at the contact point cannot spin the body up during a test,
+and the translational response at the contact point is 1 / mass.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from flygym_amd.compiler.model import CompiledModel, EngineSemantics
+
+
+def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solref=(2e-4, 1.0),
+                    solimp=(0.98, 0.99, 0.5, 0.9999, 2.0), margin=1e-3, gravity=(0.0, 0.0, -9810.0), timestep=1e-4,
+                    start_height=None, semantics: EngineSemantics | None = None) -> CompiledModel:
+    n = np.asarray(normal, dtype=np.float64)
+    n = n / np.linalg.norm(n)
+    sem = semantics or EngineSemantics()
+    m = CompiledModel()
+    f, i = (lambda *a: np.asarray(a, dtype=np.float64)), (lambda *a: np.asarray(a, dtype=np.int32))
+    big = 1e9 * mass                                    # rotational inertia: effectively no rotation (friction torque ~ m g radius)
+    start = (radius if start_height is None else start_height) * n
+    m.update(
+        body_parent=i(-1), body_dofadr=i(0), body_dofnum=i(6), body_pos=f([0, 0, 0]), body_quat=f([1, 0, 0, 0]),
+        body_mass=f(mass), body_ipos=f([0, 0, 0]), body_inertia=f([big, big, big, 0, 0, 0]),
+        dof_body=i(0, 0, 0, 0, 0, 0), dof_parent=i(-1, 0, 1, 2, 3, 4), dof_axis=np.zeros((6, 3)),
+        dof_armature=np.zeros(6), dof_damping=np.zeros(6), dof_stiffness=np.zeros(6), dof_springref=np.zeros(6),
+        seg_body=i(0), seg_pos=f([0, 0, 0]), seg_quat=f([1, 0, 0, 0]), seg_invweight0=f([1.0 / mass, 1.0 / big]),
+        site_body=np.zeros(0, np.int32), site_pos=np.zeros((0, 3)),
+        act_type=np.zeros(0, np.int32), act_trn=np.zeros(0, np.int32), act_limited=np.zeros((0, 2), np.int32),
+        act_geom=np.zeros(0, np.int32), act_gain=np.zeros(0), act_bias=np.zeros((0, 2)), act_forcerange=np.zeros((0, 2)),
+        act_ctrlrange=np.zeros((0, 2)), key_ctrl=np.zeros(0),
+        key_qpos=f(*start, 1, 0, 0, 0), qpos0=f(*start, 1, 0, 0, 0),
+        geom_body=i(0), geom_type=i(0), geom_hulladr=i(0), geom_hullnum=i(0), geom_sensor=i(-1), geom_seg=i(0),
+        geom_p0=f([0, 0, 0]), geom_p1=f([0, 0, 0]), geom_radius=f(radius), geom_bsphere=f([0, 0, 0, radius]),
+        geom_invweight0=f(1.0 / mass), hull_vert=np.zeros((1, 3)), hull_skin=f(1e-3),
+        pair_friction=f([mu, mu, 0.02, 1e-4, 1e-4]), pair_solref=f(list(solref)), pair_solimp=f(list(solimp)), pair_margin=f(margin),
+        opt_timestep=f(timestep), opt_gravity=f(*gravity), opt_tolerance=f(1e-8), opt_solver=i(100, 0),
+        stat_meaninertia=f(mass), plane=f(*n, 0.0), terrain_type=i(0), terrain_params=np.zeros(5),
+        weld_active=i(0), weld_params=np.zeros(16), n_sensor=i(0), star=i(0, 0, 0, 0), sem_options=sem.flags(),
+    )
+    return m
+
+
+def impedance(r, solimp):
+    """MuJoCo's documented solimp curve d(r): d0, dmax, width, midpoint, power."""
+    d0, dmax, width, mid, power = solimp
+    x = min(1.0, abs(r) / width)
+    if x <= mid:
+        y = x ** power / mid ** (power - 1.0)
+    else:
+        y = 1.0 - (1.0 - x) ** power / (1.0 - mid) ** (power - 1.0)
+    return d0 + y * (dmax - d0)
+
+
+def contact_row_constants(r, mass, mu, solref, solimp, timestep, pyramid_plain=False):
+    """(K d(r), B, D) of one pyramid row of a contact at signed position r = distance - margin, from the documented
+    formulas with the reference's parameters: K = 1 / (dmax^2 tc^2 zeta^2), B = 2 / (dmax tc) with tc >= 2 dt;
+    R = (1 - d) / d * (1 + mu^2) / mass per contact, pyramid rows 2 mu^2 R (or R: pyramid_R = "plain")."""
+    tc, zeta = max(solref[0], 2.0 * timestep), solref[1]
+    dmax = solimp[1]
+    K, B = 1.0 / (dmax * dmax * tc * tc * zeta * zeta), 2.0 / (dmax * tc)
+    d = impedance(r, solimp)
+    Rn = (1.0 - d) / d * (1.0 + mu * mu) / mass
+    R = Rn if pyramid_plain else 2.0 * mu * mu * Rn
+    return K * d, B, 1.0 / R
