@@ -232,3 +232,60 @@ def test_config3_vision_at_full_size(torch_mod, bench_model):
         assert np.array_equal(ticks[-1][int(w), e].cpu().numpy(), exact.astype(np.float32))
         body_seen += int((want == np.array(scene.body_rgb, dtype=np.uint8)).all(axis=-1).sum())
     assert body_seen > 8000
+
+
+def test_closed_form_contact_states_on_the_kernel(torch_mod, oracle_lib):
+    """The closed-form soft-contact anchors of tests/test_oracle_closed_form.py on the HIP kernel itself (a hand-built
+    one-body model on the general-tree kernel): rest penetration, creep velocity on an incline with both rows of the
+    sliding axis active (tan 0.3) and with the downhill-side row off (tan 0.8), and the stick / slip threshold of the
+    pyramid along an axis — predictions from MuJoCo's documented solref / solimp / pyramid formulas alone; the float64
+    oracle started from the kernel's steady state must stay on it."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from tiny_models import TinyWorld, sphere_on_plane
+    import test_oracle_closed_form as cf
+
+    def run(normal, steps):
+        m = sphere_on_plane(cf.MASS, cf.RADIUS, normal=normal, mu=cf.MU, solref=cf.SOLREF, solimp=cf.SOLIMP, margin=cf.MARGIN,
+                            start_height=cf.RADIUS + cf.MARGIN)
+        sim = HIPSimulation(TinyWorld(m), n_worlds=3, device=0)
+        sim.step(steps)
+        torch.cuda.synchronize()
+        return m, sim
+
+    # at rest on the level plane
+    m, sim = run((0.0, 0.0, 1.0), 400)
+    q, v = sim.field("qpos").cpu().numpy().astype(np.float64), sim.field("qvel").cpu().numpy()
+    assert int(sim.field("stats")[0, 0].item()) == 2 and np.abs(v).max() < 1e-3
+    r = q[0, 2] - cf.RADIUS - cf.MARGIN
+    assert r == pytest.approx(cf.rest_position(cf.MASS * cf.G), rel=2e-2)           # float32: one ulp of z is 2e-3 of r*
+    assert np.array_equal(q[0], q[2])
+    # creep on an incline
+    for slope in (0.3, 0.8):
+        theta = np.arctan(slope * cf.MU)
+        n = cf.tilted_normal(theta, 0.0)
+        m, sim = run(n, 600)
+        v = sim.field("qvel").cpu().numpy().astype(np.float64)[0, :3]
+        v_pred, r_pred = cf.creep_prediction(theta)
+        t1, t2 = cf.plane_frame(n)
+        assert -np.dot(v, t2) == pytest.approx(v_pred, rel=2e-2), f"slope {slope}"
+        assert abs(np.dot(v, n)) < 2e-2 * v_pred and abs(np.dot(v, t1)) < 2e-2 * v_pred
+        assert np.abs(sim.field("qacc").cpu().numpy()[0, :3]).max() < 1e-3 * cf.G
+        # the float64 oracle, started from the kernel's state, stays on it
+        o = oracle_lib.Oracle(m.to_blob(), "f64")
+        o.qpos[:] = sim.field("qpos")[0].cpu().numpy(); o.qvel[:] = sim.field("qvel")[0].cpu().numpy()
+        o.arr("qacc_warmstart")[:] = sim.field("qacc_warmstart")[0].cpu().numpy()
+        o.step(50)
+        assert -np.dot(o.qvel[:3], t2) == pytest.approx(v_pred, rel=1e-3)
+    # stick / slip threshold along a pyramid axis (mu = 1: 45 degrees)
+    for factor in (0.9, 1.1):
+        theta = np.arctan(factor * cf.MU)
+        m, sim = run(cf.tilted_normal(theta, 0.0), 1500)
+        v1 = float(np.linalg.norm(sim.field("qvel")[0, :3].cpu().numpy()))
+        sim.step(1500)
+        v2 = float(np.linalg.norm(sim.field("qvel")[0, :3].cpu().numpy()))
+        acc = (v2 - v1) / (1500 * cf.DT)
+        if factor < 1:
+            assert abs(acc) < 1e-3 * cf.G
+        else:
+            assert 0.6 * cf.G * np.cos(theta) * (np.tan(theta) - cf.MU) < acc < cf.G * np.sin(theta)

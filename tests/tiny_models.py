@@ -70,3 +70,25 @@ def contact_row_constants(r, mass, mu, solref, solimp, timestep, pyramid_plain=F
     Rn = (1.0 - d) / d * (1.0 + mu * mu) / mass
     R = Rn if pyramid_plain else 2.0 * mu * mu * Rn
     return K * d, B, 1.0 / R
+
+
+class _NoFly:
+    """What HIPSimulation asks of a fly when it builds its index maps: nothing to index here."""
+    name = "body"
+    actuators: list = []
+
+    def get_jointdofs_order(self):
+        return []
+
+
+class TinyWorld:
+    """The part of a world ``HIPSimulation`` reads, around a hand-built compiled model."""
+
+    def __init__(self, model: CompiledModel):
+        self._model = model
+        self.fly_lookup = {"body": _NoFly()}
+        self.noslip_iterations = 0
+        self.legpos_to_groundcontactsensors_by_fly = None
+
+    def compile_model(self):
+        return self._model
