@@ -65,6 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--worlds-per-gpu", type=int, default=4096)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --worlds-per-gpu on every GPU; strong: --worlds-per-gpu worlds in TOTAL, sharded over the GPUs")
+    ap.add_argument("--shard-policy", choices=["spread", "fill"], default="spread",
+                    help="--scaling strong only.  spread: every GPU gets a share (highest aggregate rate: a step takes ~80 us for "
+                         "128 worlds and ~86 us for 2048); fill: use only ceil(total / resident worlds per GPU) GPUs — the same "
+                         "rate to within ~6 %% from far fewer GPUs; the other ranks idle (flygym_amd.sharding.shard_plan)")
     ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="physics steps fused into one kernel launch (= one control tick)")
     ap.add_argument("--workload", choices=["cpg", "replay"], default="cpg",
@@ -211,6 +215,34 @@ def traffic_model(n_local, spl, args):
     return None, issue
 
 
+def idle_rank(args, torch, dist, device, total_worlds, shard_sizes, rank, world_size, n_ticks):
+    """A rank that holds no worlds (--shard-policy fill): it takes part in every collective of the job — the per-tick
+    observation all-gather (with an empty block), the barriers of the timing bracket, the result reductions — in the
+    order the working ranks issue them, and nothing else."""
+    from flygym_amd.sharding import ObsGather
+
+    nj = {"legs_only": 66, "legs_active_only": 42, "all_biological": 126}[args.joint_preset]
+    gather = ObsGather(0, nj, 42, device, total_worlds=total_worlds, shard_sizes=shard_sizes)
+    empty = [torch.zeros((0, w), dtype=torch.float32, device=device) for w in (7 + nj, 6 + nj, 48, 96)]
+
+    def fence():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    gather.tick(*empty)
+    fence(); fence()
+    for _ in range(n_ticks - 1):
+        gather.tick(*empty)
+    gather.drain()
+    fence()
+    dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=device), op=dist.ReduceOp.MAX)
+    dist.all_reduce(torch.zeros(4, dtype=torch.float64, device=device), op=dist.ReduceOp.SUM)
+    dist.all_reduce(torch.ones(1, dtype=torch.float64, device=device), op=dist.ReduceOp.MIN)
+    probe = torch.zeros(world_size, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(probe, torch.tensor([rank + 1], dtype=torch.int32, device=device))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     env_ws = os.environ.get("WORLD_SIZE")
@@ -223,7 +255,7 @@ def main():
     from flygym_amd import HIPSimulation, make_model
     from flygym_amd.compose import ActuatorType
     from flygym_amd.replay import ReplayTargetData
-    from flygym_amd.sharding import ObsGather, shard_range
+    from flygym_amd.sharding import ObsGather, resident_worlds, shard_plan
 
     world_size = int(env_ws or "1")
     rank = int(os.environ.get("RANK", "0"))
@@ -241,15 +273,27 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    resident = resident_worlds({"legs_only": 72, "legs_active_only": 48, "all_biological": 132}[args.joint_preset])
     if args.scaling == "strong":
         total_worlds = args.worlds_per_gpu
-        first_world, last_world = shard_range(total_worlds, rank, world_size)
+        if total_worlds < world_size and args.shard_policy == "spread":
+            raise SystemExit("more ranks than worlds")
+        shard_sizes = shard_plan(total_worlds, world_size, resident, args.shard_policy)
     else:
         total_worlds = args.worlds_per_gpu * world_size
-        first_world, last_world = rank * args.worlds_per_gpu, (rank + 1) * args.worlds_per_gpu
-    n_local = last_world - first_world
-    if n_local <= 0:
-        raise SystemExit("more ranks than worlds")
+        shard_sizes = [args.worlds_per_gpu] * world_size
+    first_world = sum(shard_sizes[:rank])
+    n_local = shard_sizes[rank]
+    active_gpus = sum(1 for x in shard_sizes if x > 0)
+    shard_note = None
+    if max(shard_sizes) < resident and world_size > 1:
+        # a launch below residency is pure latency: a step takes as long for 128 worlds as for 2048 (measured on BASELINE
+        # config 5's workload: 78.8 us at 128 worlds per GPU, 85.9 us at 2048), so this job cannot scale with the GPU count
+        shard_note = (f"{max(shard_sizes)} worlds per GPU are below the {resident} one MI355X steps at once: the step time no longer "
+                      f"falls with the shard size, so {active_gpus} GPUs deliver about what {max(1, -(-total_worlds // resident))} would "
+                      "(--shard-policy fill uses only those)")
+        if rank == 0:
+            print("bench.py: " + shard_note, file=sys.stderr)
     if args.vision != "off":
         args.steps_per_launch = args.vision_every      # one launch per vision tick
     spl = max(1, min(args.steps_per_launch, args.steps))
@@ -258,6 +302,9 @@ def main():
     n_launches = args.steps // spl
     repeats = args.repeats if args.repeats > 0 else (1 if args.steps >= 500 else min(100, max(2, math.ceil(1000 / args.steps))))
 
+    if n_local == 0:         # --shard-policy fill left this rank without worlds: it only keeps the collectives company
+        return idle_rank(args, torch, dist, torch.device("cuda", local_rank), total_worlds, shard_sizes, rank, world_size,
+                         1 + repeats * n_launches)
     fly, world, _ = make_model(joints_preset=args.joint_preset, simplify_geom=args.simplify_geom)
     if args.terrain != "flat":
         import flygym_amd.compose as C
@@ -324,7 +371,8 @@ def main():
     # observation gather: double-buffered so that the RCCL all-gather of tick k runs on RCCL's stream while the
     # stepping kernel of tick k + 1 already runs on the compute stream (the only exchange of the path)
     nj = sim.model.nv - 6                # joint angles, joint velocities, position-actuator forces, contact sensors
-    gather = ObsGather(n_local, nj, 42, sim.device, total_worlds=total_worlds) if use_dist else None
+    gather = ObsGather(n_local, nj, 42, sim.device, total_worlds=total_worlds, shard_sizes=shard_sizes,
+                       packer=sim.pack_observations) if use_dist else None
     assert args.joint_preset != "legs_only" or 2 * nj + 42 + 96 == OBS_DIM
 
     n_events = repeats * n_launches
@@ -440,6 +488,7 @@ def main():
                                 "(checker ground, sky, one sphere, the fly's own body) and resampled to 2 x 721 x 2 ommatidia readings in one kernel"}[args.vision]),
                 "control": args.workload,
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
+                "shard_sizes": shard_sizes, "active_gpus": active_gpus, "resident_worlds_per_gpu": resident, "shard_note": shard_note,
                 "settle_steps": {"neutral": settle_neutral, "gait": settle_gait, "warmup": args.warmup},
                 "repeats": repeats, "timed_steps_total": args.steps * repeats,
                 "elapsed_s": {"total": total_elapsed, "per_region": elapsed},

@@ -109,6 +109,7 @@ def lib():
             "nmf_field_ptr": (vp, [vp, ci, ctypes.POINTER(ctypes.c_int32)]),
             "nmf_gather": (ci, [vp, ci, vp, ci, ci, vp, vp]),
             "nmf_scatter": (ci, [vp, ci, vp, ci, vp, vp]),
+            "nmf_pack_observations": (ci, [vp, ci, ci, vp, ci, vp]),
             "nmf_step_count": (ctypes.c_int64, [vp]),
             "nmf_shader_clock": (ci, [vp, ctypes.POINTER(ctypes.c_double), ci]),
             "nmf_time_launches": (ctypes.c_double, [vp, vp, ci, ci, vp, ci, ci, vp]),

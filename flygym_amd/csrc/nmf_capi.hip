@@ -614,6 +614,21 @@ extern "C" int nmf_scatter(nmf_batch* b, int field, const int32_t* ids_dev, int 
   return 0;
 }
 
+extern "C" int nmf_pack_observations(nmf_batch* b, int n_joint, int n_act, float* out_dev, int row_stride, void* stream) {
+  if (!b || !out_dev) return fail("nmf_pack_observations: null argument");
+  const nmf_model* m = b->model;
+  const int width = 2 * n_joint + n_act + 96;
+  if (n_joint < 0 || n_joint > m->nv - 6 || n_act < 0 || n_act > m->nu || row_stride < width)
+    return fail("nmf_pack_observations: need 0 <= n_joint <= nv - 6, 0 <= n_act <= nu and row_stride >= 2 n_joint + n_act + 96");
+  DEVICE_GUARD(b);
+  const size_t total = (size_t)b->n_worlds * width;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(nmf::nmf_pack_obs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->st.qpos, b->st.qvel,
+                     b->st.actuator_force, b->st.sensordata, m->nq, m->nv, m->nu, n_joint, n_act, b->n_worlds, out_dev, row_stride);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int64_t nmf_step_count(const nmf_batch* b) { return b ? b->steps : 0; }
 
 extern "C" int nmf_shader_clock(nmf_batch* b, double* hz_out, int reset) {

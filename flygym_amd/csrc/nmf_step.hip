@@ -2115,6 +2115,25 @@ __global__ void nmf_scatter_kernel(float* __restrict__ dstf, int width, const in
   }
 }
 
+// The observation block of the multi-GPU exchange in one launch: per world [joint angles nj | joint velocities nj |
+// position-actuator forces n_act | contact sensors 96] (what the reference reads with four getter kernels,
+// warp/simulation.py:73-211), rows `stride` floats apart.
+__global__ void nmf_pack_obs_kernel(const float* __restrict__ qpos, const float* __restrict__ qvel, const float* __restrict__ force,
+                                    const float* __restrict__ sens, int nq, int nv, int nu, int nj, int n_act, int n_worlds,
+                                    float* __restrict__ out, int stride) {
+  const int width = 2 * nj + n_act + 96;
+  const size_t total = (size_t)n_worlds * width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i / width), k = (int)(i % width);
+    float v;
+    if (k < nj) v = qpos[(size_t)w * nq + 7 + k];
+    else if (k < 2 * nj) v = qvel[(size_t)w * nv + 6 + (k - nj)];
+    else if (k < 2 * nj + n_act) v = force[(size_t)w * nu + (k - 2 * nj)];
+    else v = sens[(size_t)w * 96 + (k - 2 * nj - n_act)];
+    out[(size_t)w * stride + k] = v;
+  }
+}
+
 // Block order for the next launch.  A launch of n_worlds > resident waves runs in rounds and lasts until its last wave
 // finishes; a fly's cost (shader cycles of its last launch) follows its contacts and Newton iterations and spreads 2x
 // over a gait cycle.  Measured on 4096 worlds (ms per 50-step launch: in-order / costliest first / other packings):

@@ -5,7 +5,7 @@ The reference is single-GPU (``src/flygym/warp/utils.py:192-202``); this is new 
 
 from __future__ import annotations
 
-__all__ = ["shard_range", "gather_observations", "ObsGather", "OBS_LAYOUT"]
+__all__ = ["shard_range", "shard_plan", "resident_worlds", "gather_observations", "ObsGather", "OBS_LAYOUT"]
 
 # joint angles, joint velocities, position-actuator forces, 6 x 16 contact-sensor floats
 OBS_LAYOUT = (("joint_angles", 66), ("joint_velocities", 66), ("actuator_forces", 42), ("contact", 96))
@@ -18,6 +18,35 @@ def shard_range(total_worlds: int, rank: int, world_size: int) -> tuple[int, int
     base, extra = divmod(total_worlds, world_size)
     first = rank * base + min(rank, extra)
     return first, first + base + (1 if rank < extra else 0)
+
+
+def resident_worlds(nv: int) -> int:
+    """Worlds one MI355X steps at once (one wavefront per world; 256 CUs x the flies a CU holds — register- or
+    LDS-limited, ``scripts/kernel_stats.py``): 8 per CU for the leg skeletons (nv <= 72), 7 for ALL_BIOLOGICAL (nv 132),
+    5 for ALL_POSSIBLE (nv 210) and the general-tree kernels' 4 / 3 rounded to the smaller figure."""
+    return 2048 if nv <= 72 else 1792 if nv <= 132 else 1280 if nv <= 210 else 768
+
+
+def shard_plan(total_worlds: int, world_size: int, resident: int = 2048, policy: str = "fill") -> list[int]:
+    """Worlds per rank for a FIXED total (strong scaling).
+
+    A launch with fewer worlds than a GPU holds at once is pure latency: a step takes as long for 128 worlds as for 2048
+    (one wave per world, ~50-80 us per step whatever the count), so spreading a small batch over more GPUs buys nothing
+    and adds the observation exchange.  BASELINE config 5 is the case in point: 1024 flies on 8 GPUs = 128 per GPU ->
+    measured 1.61 M env-steps/s per GPU = 12.9 M on eight, where ONE GPU steps all 1024 at 13.6 M (same workload).
+
+    ``policy="fill"`` (default): use ``min(world_size, ceil(total / resident))`` ranks — fill a GPU to its residency
+    before taking the next — and split the worlds evenly over those; the remaining ranks get 0 worlds (they stay in the
+    collectives and idle).  ``policy="spread"``: every rank gets a share (``shard_range``), whatever its size."""
+    if total_worlds <= 0 or world_size <= 0:
+        raise ValueError("need positive total_worlds and world_size")
+    if policy == "spread":
+        return [b - a for a, b in (shard_range(total_worlds, r, world_size) for r in range(world_size))]
+    if policy != "fill":
+        raise ValueError("policy must be 'fill' or 'spread'")
+    n_active = min(world_size, max(1, -(-total_worlds // max(1, resident))))
+    sizes = [b - a for a, b in (shard_range(total_worlds, r, n_active) for r in range(n_active))]
+    return sizes + [0] * (world_size - n_active)
 
 
 def gather_observations(obs_local, out=None):
@@ -47,7 +76,11 @@ class ObsGather:
     ``n_max`` rows and :meth:`rows` maps a gathered buffer back to the global world order.
     """
 
-    def __init__(self, n_local: int, nj: int, n_act: int, device, *, total_worlds: int | None = None, group=None):
+    def __init__(self, n_local: int, nj: int, n_act: int, device, *, total_worlds: int | None = None, group=None,
+                 shard_sizes: list[int] | None = None, packer=None):
+        """``shard_sizes``: worlds per rank when they are not ``shard_range``'s (``shard_plan``: some ranks may hold none).
+        ``packer``: ``HIPSimulation.pack_observations`` — packs the block in one launch instead of four tensor copies."""
+        self._packer = packer
         import torch
         import torch.distributed as dist
 
@@ -58,7 +91,13 @@ class ObsGather:
         self.n_local, self.nj, self.n_act = int(n_local), int(nj), int(n_act)
         self.obs_dim = 2 * self.nj + self.n_act + 96
         self.total_worlds = int(total_worlds) if total_worlds is not None else self.n_local * self.world_size
-        self.n_max = -(-self.total_worlds // self.world_size)
+        if shard_sizes is not None:
+            if len(shard_sizes) != self.world_size or sum(shard_sizes) != self.total_worlds or shard_sizes[self.rank] != self.n_local:
+                raise ValueError("shard_sizes must list every rank's worlds and add up to total_worlds")
+            self.shard_sizes = [int(x) for x in shard_sizes]
+        else:
+            self.shard_sizes = [b - a for a, b in (shard_range(self.total_worlds, r, self.world_size) for r in range(self.world_size))]
+        self.n_max = max(self.shard_sizes)
         if self.n_local > self.n_max:
             raise ValueError("n_local exceeds the padded shard size")
         self.local = [torch.zeros((self.n_max, self.obs_dim), dtype=torch.float32, device=device) for _ in range(2)]
@@ -70,6 +109,9 @@ class ObsGather:
     def pack(self, out, qpos, qvel, actuator_force, sensordata):
         """Columns in OBS_LAYOUT order from the engine's raw fields (views; device-side copies only)."""
         nj, na, n = self.nj, self.n_act, self.n_local
+        if self._packer is not None and n > 0:
+            self._packer(out, na)
+            return out
         out[:n, 0:nj] = qpos[:, 7:7 + nj]
         out[:n, nj:2 * nj] = qvel[:, 6:6 + nj]
         out[:n, 2 * nj:2 * nj + na] = actuator_force[:, :na]
@@ -113,6 +155,5 @@ class ObsGather:
         """Index tensor selecting, from a gathered buffer, the rows of the real worlds in global world order."""
         idx = []
         for r in range(self.world_size):
-            a, b = shard_range(self.total_worlds, r, self.world_size)
-            idx.extend(range(r * self.n_max, r * self.n_max + (b - a)))
+            idx.extend(range(r * self.n_max, r * self.n_max + self.shard_sizes[r]))
         return self._torch.as_tensor(idx, dtype=self._torch.long, device=self.full[0].device)

@@ -249,6 +249,19 @@ class HIPSimulation:
         self._profile_events.clear()
         self._physics_time_folded_ns = int(value)
 
+    def pack_observations(self, out, n_act: int = 42):
+        """Write the observation block ``[joint angles | joint velocities | forces of the first n_act actuators | 96
+        contact-sensor floats]`` of every world into the rows of ``out`` (float32, ``(>= n_worlds, >= width)``, unit
+        column stride) in one launch (``nmf_pack_observations``): the input of the multi-GPU all-gather."""
+        t = self._torch
+        nj = self.model.nv - 6
+        width = 2 * nj + n_act + 96
+        if out.dtype != t.float32 or out.device != self.device or out.ndim != 2 or out.shape[0] < self.n_worlds \
+                or out.shape[1] < width or out.stride(1) != 1:
+            raise ValueError(f"pack_observations needs a float32 ({self.n_worlds}+, {width}+) tensor on {self.device}")
+        _native.check(self._lib.nmf_pack_observations(self._batch_h, nj, int(n_act), out.data_ptr(), int(out.stride(0)), self._stream()))
+        return out
+
     def shader_clock_hz(self, reset: bool = False) -> float:
         """Shader clock (Hz) the stepping launches since the last ``reset=True`` call ran at (``nmf_shader_clock``;
         synchronises).  0.0 if there were none."""

@@ -100,6 +100,13 @@ int nmf_gather(nmf_batch* batch, int field, const int32_t* ids_dev, int n_ids, i
 int nmf_scatter(nmf_batch* batch, int field, const int32_t* ids_dev, int n_ids,
                 const float* src_dev, void* stream);
 
+/* The observation block of the multi-GPU exchange, packed in ONE launch: out[w][0 .. 2 n_joint + n_act + 96) =
+ * [joint angles (qpos 7 ..) | joint velocities (qvel 6 ..) | forces of the first n_act actuators | the 96 contact-sensor
+ * floats], rows row_stride floats apart.  Replaces the four getter launches the reference would need per tick
+ * (get_joint_angles / get_joint_velocities / get_actuator_forces / contact sensors, warp/simulation.py:73-211) as the
+ * input of the RCCL all-gather (flygym_amd.sharding.ObsGather; the reference is single-GPU, warp/utils.py:192-202). */
+int nmf_pack_observations(nmf_batch* batch, int n_joint, int n_act, float* out_dev, int row_stride, void* stream);
+
 /* Number of physics steps taken since the last reset (host-side counter, no sync). */
 int64_t nmf_step_count(const nmf_batch* batch);
 

