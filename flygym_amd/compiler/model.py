@@ -41,7 +41,7 @@ GEOM_CAPSULE, GEOM_HULL = 0, 1
 ACT_POSITION, ACT_ADHESION, ACT_MOTOR = 0, 1, 2
 
 _MAGIC = b"NMFMODEL"
-_VERSION = 3
+_VERSION = 4      # 4: sem_options[4] = terrain side faces; sem_options / act_geom mandatory (a v3 blob is refused, not half-read)
 
 
 class EngineSemantics:
@@ -62,13 +62,16 @@ class EngineSemantics:
     * ``max_hull_contacts``: 1..4 manifold points per plane-hull pair (4 = deepest vertex + up to 3 more within
       ``hull_skin``; 1 = deepest vertex only);
     * ``weld_relpose``: ``"spawn"`` (tether target = the root body's spawn pose) | ``"identity"`` (target = world origin,
-      identity orientation).
+      identity orientation);
+    * ``terrain_walls``: ``"box"`` (the cells of a terrain are boxes: their side faces collide, horizontal normals —
+      ``compose.world.terrain_probe``) | ``"heightfield"`` (round 2: tops only, vertical normals).  Build-defined terrains,
+      no MuJoCo counterpart in the reference snapshot.
     """
 
     _CHOICES = dict(mesh_inertia=("exact", "convex"), capsule_fit=("inertia_box", "aabb"),
                     invweight0=("segment", "fused_body"), pyramid_R=("2mu2", "plain"),
                     adhesion_contacts=("segment_geom", "fused_body"), sensor_frame=("world", "contact"),
-                    weld_relpose=("spawn", "identity"))
+                    weld_relpose=("spawn", "identity"), terrain_walls=("box", "heightfield"))
 
     def __init__(self, **kw):
         self.mesh_inertia = "exact"
@@ -79,6 +82,7 @@ class EngineSemantics:
         self.sensor_frame = "world"
         self.max_hull_contacts = 4
         self.weld_relpose = "spawn"
+        self.terrain_walls = "box"
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError(f"unknown engine semantic '{k}'")
@@ -94,10 +98,11 @@ class EngineSemantics:
 
     def flags(self) -> np.ndarray:
         """int32[8] blob entry ``sem_options`` read by the oracle and the kernel: pyramid_R plain, adhesion over the fused
-        body, sensor in the contact frame, max hull contacts, 0, 0, 0, 0."""
+        body, sensor in the contact frame, max hull contacts, terrain side faces collide, 0, 0, 0."""
         self.validate()
         return np.array([int(self.pyramid_R == "plain"), int(self.adhesion_contacts == "fused_body"),
-                         int(self.sensor_frame == "contact"), int(self.max_hull_contacts), 0, 0, 0, 0], dtype=np.int32)
+                         int(self.sensor_frame == "contact"), int(self.max_hull_contacts), int(self.terrain_walls == "box"),
+                         0, 0, 0], dtype=np.int32)
 
     def as_dict(self):
         return {k: getattr(self, k) for k in (*self._CHOICES, "max_hull_contacts")}

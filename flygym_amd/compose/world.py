@@ -139,9 +139,12 @@ class _TerrainWorld(FlatGroundWorld):
     """Ground whose height is a piecewise-constant function of (x, y).
 
     The reference snapshot has only the flat plane and the tether (flygym 1.x's terrains were
-    dropped); the terrains below are build-defined.  Collision treats the ground as a height map: every
-    collision vertex / capsule end is tested against the ground height under it with a vertical normal, so the
-    vertical faces of blocks and gap walls exert no force (the same simplification as a height field).
+    dropped; its extension point is ``BaseWorld._attach_fly_mjcf``, reference ``world.py:70-93``, where box geoms would
+    be added); the terrains below are build-defined.  The ground is a lattice of axis-aligned cells of constant height
+    — i.e. boxes: every collision probe (capsule end sphere, hull vertex) is tested against the TOP of the cell it is
+    over (vertical normal) and against the SIDE FACES of the cells around it (horizontal normals), see
+    :func:`terrain_probe`.  Round 2 had the tops only (a height field: a tarsus swung into the side of a block was thrown
+    upwards by the block's top once inside it).
     """
 
     def terrain_height(self, x, y):
@@ -149,6 +152,10 @@ class _TerrainWorld(FlatGroundWorld):
         import numpy as np
 
         return _terrain_height(self.terrain_type, self.terrain_params, np.asarray(x, dtype=float), np.asarray(y, dtype=float))
+
+    def terrain_probe(self, p, rho=0.0):
+        """numpy restatement of the probe-vs-terrain rule shared by the oracle and the HIP kernel: :func:`terrain_probe`."""
+        return terrain_probe(self.terrain_type, self.terrain_params, p, rho)
 
 
 def _terrain_height(kind, p, x, y):
@@ -166,6 +173,85 @@ def _terrain_height(kind, p, x, y):
         blk = _terrain_height(2, (p[0], 0.35, 0.0, 0.0), x, y)
         return np.where(stripe == 1, gap, np.where(stripe == 2, blk, 0.0))
     return np.zeros(np.broadcast(x, y).shape)
+
+
+WALL_NORMALS = ((1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, -1.0, 0.0))     # wall codes 1..4
+_PROBE_EPS = 1e-4     # how far across a cell boundary the neighbour's height is read (cells are >= 0.3 mm wide)
+
+
+def _cell_bounds(kind, p, x, y):
+    """Bounds (x_lo, x_hi, y_lo, y_hi) of the constant-height cell of the lattice that holds (x, y); +-inf where the
+    lattice does not divide that axis."""
+    import numpy as np
+
+    inf = np.inf
+    if kind == 1:
+        period = p[0] + p[1]
+        k = np.floor(x / period)
+        u = x - k * period
+        return (k * period if u < p[0] else k * period + p[0]), (k * period + p[0] if u < p[0] else (k + 1) * period), -inf, inf
+    if kind == 2:
+        i, j = np.floor(x / p[0]), np.floor(y / p[0])
+        return i * p[0], (i + 1) * p[0], j * p[0], (j + 1) * p[0]
+    if kind == 3:
+        st = np.floor(x / p[3])
+        k = st - 3 * np.floor(st / 3)
+        lo, hi = st * p[3], (st + 1) * p[3]
+        if k == 1:
+            a, b, c, d = _cell_bounds(1, (1.0, p[1], p[2], 0.0), x, y)
+        elif k == 2:
+            a, b, c, d = _cell_bounds(2, (p[0], 0.35, 0.0, 0.0), x, y)
+        else:
+            a, b, c, d = -inf, inf, -inf, inf
+        return max(a, lo), min(b, hi), c, d
+    return -inf, inf, -inf, inf
+
+
+def terrain_probe(kind, params, p, rho=0.0):
+    """One collision probe — a point ``p`` (hull vertex, ``rho`` = 0) or a sphere of radius ``rho`` centred at ``p``
+    (capsule end) — against a terrain of box cells.  Returns ``(dist_top, dist_wall, wall)``:
+
+    * ``dist_top``: signed distance of the probe's lowest point to the top of the cell it is over (normal +z), or +inf
+      when the probe is inside that cell's box and its nearest way out is through a side face;
+    * ``dist_wall`` / ``wall``: signed distance to the nearest side face that faces the probe and the face's code
+      (1..4 = outward normal +x, -x, +y, -y; 0 and +inf if there is none).
+
+    With ``z_b = p_z - rho`` the probe's lowest point, ``h0`` the height of its cell, ``delta_e`` the distance from ``p``
+    to the cell's boundary in direction e and ``h_e`` the height of the cell across it:
+
+    * a neighbour with ``h_e > z_b`` shows the probe a side face at ``dist = delta_e - rho`` whose outward normal is -e;
+    * ``z_b >= h0`` (above its own cell): ``dist_top = z_b - h0``;
+    * ``z_b < h0`` (inside its own cell's box): the ways out are up (``h0 - z_b``) and sideways through every face with a
+      neighbour the probe would be clear of (``h_e <= z_b``: ``delta_e + rho``).  The shortest wins: sideways gives a face
+      at ``dist = -(delta_e + rho)`` with outward normal +e and ``dist_top`` = +inf; up gives ``dist_top = z_b - h0``;
+    * of all the faces found the one with the smallest distance is reported.
+
+    A contact exists where a distance is within the pair's margin; its point is the probe's surface point along the
+    normal moved half the distance back (as for the plane).  Neighbour heights are read ``1e-4`` mm across the boundary.
+    """
+    import numpy as np
+
+    x, y, z = (float(v) for v in p)
+    h0 = float(_terrain_height(kind, params, np.float64(x), np.float64(y)))
+    x_lo, x_hi, y_lo, y_hi = _cell_bounds(kind, params, x, y)
+    zb = z - rho
+    delta = (x_hi - x, x - x_lo, y_hi - y, y - y_lo)                     # towards +x, -x, +y, -y
+    across = ((x_hi + _PROBE_EPS, y), (x_lo - _PROBE_EPS, y), (x, y_hi + _PROBE_EPS), (x, y_lo - _PROBE_EPS))
+    he = [float(_terrain_height(kind, params, np.float64(a), np.float64(b))) if np.isfinite(d) else h0
+          for d, (a, b) in zip(delta, across)]
+    best, code = np.inf, 0
+    for e in range(4):                                                    # side faces that look at the probe
+        if np.isfinite(delta[e]) and he[e] > zb and delta[e] - rho < best:
+            best, code = delta[e] - rho, (2, 1, 4, 3)[e]                  # normal -e
+    if zb >= h0:
+        return zb - h0, best, code
+    pen, out = h0 - zb, 0
+    for e in range(4):                                                    # inside its own cell's box: the ways out
+        if np.isfinite(delta[e]) and he[e] <= zb and delta[e] + rho < pen:
+            pen, out = delta[e] + rho, (1, 2, 3, 4)[e]                    # through the face towards e: normal +e
+    if out == 0:
+        return zb - h0, best, code
+    return (np.inf, -pen, out) if -pen < best else (np.inf, best, code)
 
 
 class GappedTerrainWorld(_TerrainWorld):

@@ -112,7 +112,7 @@ extern "C" nmf_model* nmf_model_create(const void* blob, size_t nbytes) {
   uint32_t version, n;
   memcpy(&version, m->blob.data() + 8, 4);
   memcpy(&n, m->blob.data() + 12, 4);
-  if (version != 3) { delete m; fail("nmf_model_create: unsupported blob version"); return nullptr; }
+  if (version != 4) { delete m; fail("nmf_model_create: unsupported blob version (this library reads NMFMODEL v4)"); return nullptr; }
   if ((uint64_t)n > (nbytes - 16) / sizeof(BlobEntry)) { delete m; fail("nmf_model_create: entry table does not fit the blob"); return nullptr; }
   const BlobEntry* e = (const BlobEntry*)(m->blob.data() + 16);
   for (uint32_t k = 0; k < n; ++k) {
@@ -391,7 +391,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     for (int k = 0; k < 5; ++k) d.weld_solimp[k] = scalar("weld_params", 9 + k);
     for (int k = 0; k < 2; ++k) d.weld_invweight[k] = scalar("weld_params", 14 + k); }
   { const HostArray* so = model->find("sem_options");
-    if (!so || !so->is_int || so->i.size() < 4) { delete b; fail("nmf_batch_create: model lacks sem_options"); return nullptr; }
+    if (!so || !so->is_int || so->i.size() < 5) { delete b; fail("nmf_batch_create: model lacks sem_options"); return nullptr; }
+    d.sem_terrain_walls = so->i[4];
     d.sem_pyramid_plain = so->i[0]; d.sem_adhesion_fused = so->i[1]; d.sem_sensor_contact_frame = so->i[2];
     d.sem_max_hull_contacts = so->i[3] >= 1 && so->i[3] <= 4 ? so->i[3] : 4; }
   { const HostArray* tt = model->find("terrain_type"); d.terrain_type = tt && tt->is_int && !tt->i.empty() ? tt->i[0] : 0; }

@@ -121,6 +121,7 @@ struct DevModel {
   const NMF_G int* act_geom;      // adhesion actuators: contact geom of the adhesion segment (-1: none)
   // named engine semantics (blob entry sem_options; flygym_amd.compiler.model.EngineSemantics), shared with the oracle
   int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
+  int sem_terrain_walls;    // terrains: the cells' side faces collide (flygym_amd/compose/world.py::terrain_probe)
   const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   const NMF_G float *key_qpos, *key_ctrl;
   const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;

@@ -137,6 +137,7 @@ typedef struct {
   /* named engine semantics (blob entry sem_options, flygym_amd.compiler.model.EngineSemantics): the low-confidence
    * rows of SURVEY.md Appendix A as switches, read here and by the HIP kernel alike */
   int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
+  int sem_terrain_walls;    /* terrains: side faces of the cells collide (flygym_amd/compose/world.py::terrain_probe) */
 } omodel;
 
 typedef struct {
@@ -185,6 +186,7 @@ typedef struct {
 EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   (void)nbytes;
   if (memcmp(blob, "NMFMODEL", 8) != 0) return NULL;
+  { uint32_t version; memcpy(&version, blob + 8, 4); if (version != 4) return NULL; }   /* older blobs lack entries read below */
   omodel* m = (omodel*)calloc(1, sizeof(omodel));
   int64_t c;
   m->body_parent = blob_int(blob, "body_parent", &c); m->nb = (int)c;
@@ -213,7 +215,7 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   m->act_geom = blob_int(blob, "act_geom", NULL);
   { int* so = blob_int(blob, "sem_options", NULL);
     m->sem_pyramid_plain = so[0]; m->sem_adhesion_fused = so[1]; m->sem_sensor_contact_frame = so[2];
-    m->sem_max_hull_contacts = so[3] >= 1 && so[3] <= 4 ? so[3] : 4; free(so); }
+    m->sem_max_hull_contacts = so[3] >= 1 && so[3] <= 4 ? so[3] : 4; m->sem_terrain_walls = so[4]; free(so); }
   m->act_gain = blob_real(blob, "act_gain", NULL);
   m->act_bias = blob_real(blob, "act_bias", NULL);
   m->act_forcerange = blob_real(blob, "act_forcerange", NULL);
@@ -525,9 +527,72 @@ static real terrain_height(const omodel* m, real x, real y) {
   return terrain_kind(m->terrain_type, p, x, y);
 }
 
-static real vheight(const omodel* m, const real* R, const real* xp, const real* v) {
+
+/* The terrain as boxes: bounds (x_lo, x_hi, y_lo, y_hi) of the constant-height cell that holds (x, y); +-NMF_FAR where the
+ * lattice does not divide that axis.  Restates flygym_amd/compose/world.py::_cell_bounds. */
+#define NMF_FAR ((real)1e30)
+static void cell_bounds_kind(int kind, const real* p, real x, real y, real* b) {
+  b[0] = -NMF_FAR; b[1] = NMF_FAR; b[2] = -NMF_FAR; b[3] = NMF_FAR;
+  if (kind == 1) {
+    real period = p[0] + p[1]; real k = R_FLOOR(x / period); real u = x - k * period;
+    if (u < p[0]) { b[0] = k * period; b[1] = k * period + p[0]; } else { b[0] = k * period + p[0]; b[1] = (k + 1) * period; }
+  } else if (kind == 2) {
+    real i = R_FLOOR(x / p[0]), j = R_FLOOR(y / p[0]);
+    b[0] = i * p[0]; b[1] = (i + 1) * p[0]; b[2] = j * p[0]; b[3] = (j + 1) * p[0];
+  }
+}
+static void cell_bounds(const omodel* m, real x, real y, real* b) {
+  const real* p = m->terrain;
+  if (m->terrain_type == 3) {
+    real st = R_FLOOR(x / p[3]); real k = st - 3 * R_FLOOR(st / 3);
+    real gp[3] = {(real)1.0, p[1], p[2]}, bp[2] = {p[0], (real)0.35};
+    cell_bounds_kind(k == 1 ? 1 : (k == 2 ? 2 : 0), k == 1 ? gp : bp, x, y, b);
+    real lo = st * p[3], hi = (st + 1) * p[3];
+    if (b[0] < lo) b[0] = lo;
+    if (b[1] > hi) b[1] = hi;
+    return;
+  }
+  cell_bounds_kind(m->terrain_type, p, x, y, b);
+}
+/* One collision probe (point, rho = 0, or sphere of radius rho at pw; z measured from the ground plane) against the
+ * terrain's boxes: *dtop = signed distance of its lowest point to the top of the cell it is over (NMF_FAR if it is inside
+ * that box and leaves it sideways), *dwall / *wall = signed distance to the nearest side face that concerns it and the
+ * face's code 1..4 (outward normal +x, -x, +y, -y; NMF_FAR / 0: none).  Restates
+ * flygym_amd/compose/world.py::terrain_probe line by line. */
+static const real kWallNormal[4][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+#define NMF_PROBE_EPS ((real)1e-4)
+static void terrain_probe(const omodel* m, const real* pw, real zc, real rho, real* dtop, real* dwall, int* wall) {
+  real x = pw[0], y = pw[1];
+  real h0 = terrain_height(m, x, y);
+  real zb = zc - rho;
+  *dtop = zb - h0; *dwall = NMF_FAR; *wall = 0;
+  if (!m->sem_terrain_walls) return;
+  real b[4]; cell_bounds(m, x, y, b);
+  real delta[4] = {b[1] - x, x - b[0], b[3] - y, y - b[2]};
+  real he[4];
+  he[0] = b[1] < NMF_FAR ? terrain_height(m, b[1] + NMF_PROBE_EPS, y) : h0;
+  he[1] = b[0] > -NMF_FAR ? terrain_height(m, b[0] - NMF_PROBE_EPS, y) : h0;
+  he[2] = b[3] < NMF_FAR ? terrain_height(m, x, b[3] + NMF_PROBE_EPS) : h0;
+  he[3] = b[2] > -NMF_FAR ? terrain_height(m, x, b[2] - NMF_PROBE_EPS) : h0;
+  static const int facing[4] = {2, 1, 4, 3}, leaving[4] = {1, 2, 3, 4};
+  for (int e = 0; e < 4; e++)          /* side faces that look at the probe */
+    if (delta[e] < NMF_FAR && he[e] > zb && delta[e] - rho < *dwall) { *dwall = delta[e] - rho; *wall = facing[e]; }
+  if (zb >= h0) return;
+  real pen = h0 - zb; int code = 0;    /* inside its own cell's box: the ways out */
+  for (int e = 0; e < 4; e++)
+    if (delta[e] < NMF_FAR && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = leaving[e]; }
+  if (code) { *dtop = NMF_FAR; if (-pen < *dwall) { *dwall = -pen; *wall = code; } }
+}
+
+/* hull vertex v (body frame) against the terrain: its distance to the top of its cell (NMF_FAR when a side face owns it) */
+static real hull_vertex_probe(const omodel* m, const real* R, const real* xp, const real* nb, real c0, const real* v,
+                              real* dwall, int* wall) {
   real pw[3]; mat_vec(pw, R, v);
-  return terrain_height(m, pw[0] + xp[0], pw[1] + xp[1]);
+  for (int k = 0; k < 3; k++) pw[k] += xp[k];
+  real dtop, dw; int w;
+  terrain_probe(m, pw, dot3(nb, v) + c0, (real)0, &dtop, &dw, &w);
+  if (dwall) { *dwall = dw; *wall = w; }
+  return dtop;
 }
 
 static void collide(const omodel* m, odata* d) {
@@ -547,10 +612,17 @@ static void collide(const omodel* m, odata* d) {
         real pw[3]; mat_vec(pw, R, pl);
         for (int k = 0; k < 3; k++) pw[k] += xp[k];
         real r = m->geom_radius[g];
-        real dist = dot3(n, pw) - pd - r - terrain_height(m, pw[0], pw[1]);
-        if (dist > margin) continue;
-        real ps[3] = {pw[0] - n[0] * r, pw[1] - n[1] * r, pw[2] - n[2] * r};
-        add_contact(m, d, g, dist, ps, n);
+        real dist = dot3(n, pw) - pd - r, dwall = NMF_FAR; int wall = 0;
+        if (m->terrain_type) terrain_probe(m, pw, dot3(n, pw) - pd, r, &dist, &dwall, &wall);
+        if (dist <= margin) {
+          real ps[3] = {pw[0] - n[0] * r, pw[1] - n[1] * r, pw[2] - n[2] * r};
+          add_contact(m, d, g, dist, ps, n);
+        }
+        if (wall && dwall <= margin) {      /* a side face of the terrain: horizontal normal */
+          const real* nw = kWallNormal[wall - 1];
+          real ps[3] = {pw[0] - nw[0] * r, pw[1] - nw[1] * r, pw[2] - nw[2] * r};
+          add_contact(m, d, g, dwall, ps, nw);
+        }
       }
     } else {
       real nb[3]; matT_vec(nb, R, n);
@@ -558,11 +630,22 @@ static void collide(const omodel* m, odata* d) {
       const real* V = m->hull_vert + 3 * m->geom_hulladr[g];
       int nvv = m->geom_hullnum[g];
       /* vertex distance to the ground under it (flat ground: the plane distance) */
-#define VDIST(i) (dot3(nb, V + 3 * (i)) + c0 - (m->terrain_type ? vheight(m, R, xp, V + 3 * (i)) : (real)0))
+#define VDIST(i) (m->terrain_type ? hull_vertex_probe(m, R, xp, nb, c0, V + 3 * (i), NULL, NULL) : dot3(nb, V + 3 * (i)) + c0)
       int ia = -1; real dmin = 0;
+      int iw = -1, wall = 0; real dwmin = NMF_FAR;       /* the vertex nearest to (deepest in) a side face of the terrain */
       for (int i = 0; i < nvv; i++) {
-        real di = VDIST(i);
+        real di;
+        if (m->terrain_type) {
+          real dw; int w;
+          di = hull_vertex_probe(m, R, xp, nb, c0, V + 3 * i, &dw, &w);
+          if (w && dw < dwmin) { dwmin = dw; iw = i; wall = w; }
+        } else di = dot3(nb, V + 3 * i) + c0;
         if (ia < 0 || di < dmin) { ia = i; dmin = di; }
+      }
+      if (iw >= 0 && dwmin <= margin) {
+        real pw[3]; mat_vec(pw, R, V + 3 * iw);
+        for (int q = 0; q < 3; q++) pw[q] += xp[q];
+        add_contact(m, d, g, dwmin, pw, kWallNormal[wall - 1]);
       }
       if (ia < 0 || dmin > margin) continue;
       real thr = dmin + m->hull_skin; if (thr > margin) thr = margin;
@@ -1027,7 +1110,7 @@ EXPORT void* SFX(nmfo_ptr)(const void* mv, void* dv, const char* name, int* coun
   F("qfrc_constraint", d->qfrc_constraint, nv) F("actuator_force", d->actuator_force, m->nu)
   F("sensordata", d->sensordata, 96) F("seg_xpos", d->seg_xpos, 3 * m->nseg)
   F("seg_xquat", d->seg_xquat, 4 * m->nseg) F("site_xpos", d->site_xpos, 3 * m->nsite)
-  F("con_dist", d->con_dist, d->ncon) F("con_pos", d->con_pos, 3 * d->ncon)
+  F("con_dist", d->con_dist, d->ncon) F("con_pos", d->con_pos, 3 * d->ncon) F("con_frame", d->con_frame, 9 * d->ncon)
   F("efc_force", d->efc_force, d->nefc) F("efc_aref", d->efc_aref, d->nefc) F("efc_D", d->efc_D, d->nefc)
   F("J", d->J, d->nefc * nv) F("cvel", d->cvel, 6 * m->nb) F("S", d->S, 6 * nv) F("time", &d->time, 1)
   F("solver_cost", &d->solver_cost, 1)

@@ -85,7 +85,7 @@ class Oracle:
         n = ctypes.c_int(0)
         p = self._call("nmfo_ptr", self._m, self._d, name.encode(), ctypes.byref(n))
         if not p and n.value == 0:
-            if name in ("con_dist", "con_pos", "efc_force", "efc_aref", "efc_D", "J", "site_xpos"):
+            if name in ("con_dist", "con_pos", "con_frame", "efc_force", "efc_aref", "efc_D", "J", "site_xpos"):
                 return np.zeros(0, dtype=self.dtype)
             raise KeyError(name)
         ctype = ctypes.c_double if self.precision == "f64" else ctypes.c_float

@@ -18,7 +18,9 @@ from flygym_amd.compiler.model import CompiledModel, EngineSemantics
 
 def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solref=(2e-4, 1.0),
                     solimp=(0.98, 0.99, 0.5, 0.9999, 2.0), margin=1e-3, gravity=(0.0, 0.0, -9810.0), timestep=1e-4,
-                    start_height=None, semantics: EngineSemantics | None = None) -> CompiledModel:
+                    start_height=None, semantics: EngineSemantics | None = None, terrain=None, start_xy=None) -> CompiledModel:
+    """``terrain``: ``(type, (p0, p1, p2, p3))`` of a build-defined terrain (flygym_amd/compose/world.py) over the z = 0
+    plane; ``start_xy``: where the sphere starts (with ``start_height`` above z = 0)."""
     n = np.asarray(normal, dtype=np.float64)
     n = n / np.linalg.norm(n)
     sem = semantics or EngineSemantics()
@@ -26,6 +28,10 @@ def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solre
     f, i = (lambda *a: np.asarray(a, dtype=np.float64)), (lambda *a: np.asarray(a, dtype=np.int32))
     big = 1e9 * mass                                    # rotational inertia: effectively no rotation (friction torque ~ m g radius)
     start = (radius if start_height is None else start_height) * n
+    if start_xy is not None:
+        start = np.array([start_xy[0], start_xy[1], radius if start_height is None else start_height], dtype=np.float64)
+    t_type, t_par = (0, (0.0, 0.0, 0.0, 0.0)) if terrain is None else terrain
+    t_max = {0: 0.0, 1: 0.0, 2: t_par[1], 3: 0.35}[t_type]
     m.update(
         body_parent=i(-1), body_dofadr=i(0), body_dofnum=i(6), body_pos=f([0, 0, 0]), body_quat=f([1, 0, 0, 0]),
         body_mass=f(mass), body_ipos=f([0, 0, 0]), body_inertia=f([big, big, big, 0, 0, 0]),
@@ -42,7 +48,7 @@ def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solre
         geom_invweight0=f(1.0 / mass), hull_vert=np.zeros((1, 3)), hull_skin=f(1e-3),
         pair_friction=f([mu, mu, 0.02, 1e-4, 1e-4]), pair_solref=f(list(solref)), pair_solimp=f(list(solimp)), pair_margin=f(margin),
         opt_timestep=f(timestep), opt_gravity=f(*gravity), opt_tolerance=f(1e-8), opt_solver=i(100, 0),
-        stat_meaninertia=f(mass), plane=f(*n, 0.0), terrain_type=i(0), terrain_params=np.zeros(5),
+        stat_meaninertia=f(mass), plane=f(*n, 0.0), terrain_type=i(t_type), terrain_params=f(*t_par, t_max),
         weld_active=i(0), weld_params=np.zeros(16), n_sensor=i(0), star=i(0, 0, 0, 0), sem_options=sem.flags(),
     )
     return m
