@@ -265,9 +265,9 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
     b->st.order = b->order_buf;
     if (b->order_policy < 0) b->st.sched = b->sched_buf;
   }
-  const bool weld = b->dm.weld_active != 0;
+  const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
-#define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else NMF_LAUNCH(TOPO, false); }
+#define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else if (terrain) NMF_LAUNCH(nmf::Terrain<TOPO>, false); else NMF_LAUNCH(TOPO, false); }
 #if NMF_HAS_TOPO(0)
   NMF_LAUNCH_TOPO(0, nmf::FlyTopo)
 #endif
@@ -506,9 +506,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     // (LDS- or register-limited, whichever binds); fallback = the LDS-limited figures of the shipped build
     int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 6 : 5)));
     {
-      const bool weld = b->dm.weld_active != 0;
+      const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
+      if (weld && terrain) { nmf_batch_destroy(b); fail("nmf_batch_create: a tethered world has no terrain"); return nullptr; }
       const void* fn = nullptr;
-#define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
+#define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<TOPO>, false>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
 #if NMF_HAS_TOPO(0)
       NMF_FN(0, nmf::FlyTopo)
 #endif

@@ -32,6 +32,7 @@ enum { ACT_POSITION = 0, ACT_ADHESION = 1, ACT_MOTOR = 2 };
 template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
 struct HybridTopo {
   static constexpr bool kStar = true;
+  static constexpr bool kTerrain = false;   // see Terrain<> below
   static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 6 + REST_V_ + NLEG_ * (DOFS + ...) + 8;
   static constexpr int REST_B = REST_B_, REST_V = REST_V_;
   static constexpr int NLEG = NLEG_;
@@ -60,12 +61,22 @@ using Topo = HybridTopo<0, 0, NLEG_, DOFS...>;
 template <int NB_, int NV_>
 struct TreeTopoT {
   static constexpr bool kStar = false;
+  static constexpr bool kTerrain = false;
   static constexpr int NB = NB_, NV = NV_, NQ = NV_ + 1;
   static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
   static constexpr int kFact0 = 0, kSlot0 = 1;      // every dof has articulated-body factors, every non-root body a hand-off slot
   static constexpr int kNFact = NV_, kNSlot = NB_;
   static constexpr int kTblB = NB_, kTblV = NV_;
 };
+// The same skeleton in a world with a terrain (gapped / blocks / mixed: cells with tops and side faces).  A compile-time
+// property of the kernel: the collision stage against the cells, contacts with their own frames (a side face's normal is
+// horizontal) in every stage that uses the contact frame.  Flat and tethered worlds run the kernels without any of it —
+// the same code, registers and LDS as before the terrain's side faces existed.
+template <class TP>
+struct Terrain : TP {
+  static constexpr bool kTerrain = true;
+};
+
 using TreeTopo = TreeTopoT<72, 216>;
 using TreeTopoSmall = TreeTopoT<72, 144>;
 

@@ -158,7 +158,7 @@ struct HotModel {
   const float *dof_axis, *body_pos, *body_quat, *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *hull_vert, *pair_margin;
   const int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum;
   float plane[4], terrain[5], hull_skin;
-  int terrain_type, ng, sem_max_hull_contacts;
+  int terrain_type, ng, sem_max_hull_contacts, terrain_walls;
 };
 template <class TP> struct FlyLds;
 template <class T> using gptr = const __attribute__((address_space(1))) T*;
@@ -224,6 +224,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   using cstart_t = std::conditional_t<kHasIsym<TP>, int, unsigned char>;
   cstart_t body_cstart[(TP::NB + 1 + 3) / 4 * 4];
   int ncon, overflow, iters;
+  int nwall;                            // contacts of this step that touch a terrain side face (frame id != 0)
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
   // ds_* instruction (a float* argument would be a generic pointer -> flat_load / flat_store)
   __device__ __forceinline__ float* vec(int id) {
@@ -253,6 +254,7 @@ template <class TP> __device__ __forceinline__ HotModel hot_model(const FlyLds<T
 #pragma unroll
     for (int i = 0; i < 5; ++i) h.terrain[i] = m.terrain[i];
     h.hull_skin = m.hull_skin; h.terrain_type = m.terrain_type; h.ng = m.ng; h.sem_max_hull_contacts = m.sem_max_hull_contacts;
+    h.terrain_walls = m.sem_terrain_walls;
     return h;
   }
 }
@@ -273,6 +275,7 @@ __device__ __forceinline__ int info_geom(int i) { return i & 0xff; }
 __device__ __forceinline__ int info_sensor(int i) { return ((i >> 8) & 0xf) - 1; }
 __device__ __forceinline__ int info_body(int i) { return (i >> 12) & 0xff; }
 __device__ __forceinline__ int info_act(int i) { return (i >> 20) & 0xf; }
+__device__ __forceinline__ int info_fid(int i) { return (i >> 24) & 0x7; }     // contact frame: 0 the ground plane's, 1..4 a terrain side face (+x, -x, +y, -y)
 __device__ __forceinline__ int info_pack(int geom, int sensor, int body, int act) {
   return geom | ((sensor + 1) << 8) | (body << 12) | (act << 20);
 }
@@ -298,6 +301,18 @@ __device__ __forceinline__ Frame make_frame(V3 n) {
 template <class LDS> __device__ __forceinline__ Frame ld_frame(const LDS& s, const GModel& m) {
   if constexpr (sizeof(s.frame9) == 9 * sizeof(float)) return Frame{ld3(&s.frame9[0]), ld3(&s.frame9[3]), ld3(&s.frame9[6])};
   else return make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+}
+
+// Frame of a contact: the ground plane's (fid 0) or that of a terrain side face with outward normal +x, -x, +y, -y (fid
+// 1..4: make_frame of that axis, written out).  Branch-free: lanes of a wave may hold contacts of different faces.
+__device__ __forceinline__ Frame contact_frame(int fid, const Frame& f0) {
+  const float sg = (fid & 1) ? 1.f : -1.f;
+  const bool xw = fid <= 2, pl = fid == 0;
+  Frame f;
+  f.n = pl ? f0.n : (xw ? v3(sg, 0.f, 0.f) : v3(0.f, sg, 0.f));
+  f.t1 = pl ? f0.t1 : (xw ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f));
+  f.t2 = pl ? f0.t2 : (xw ? v3(0.f, 0.f, sg) : v3(sg, 0.f, 0.f));
+  return f;
 }
 
 template <class TP>
@@ -497,17 +512,81 @@ __device__ __forceinline__ float terrain_height(int terrain_type, const float* p
   return terrain_kind(terrain_type, p[0], p[1], p[2], x, y);
 }
 
+// The terrain as boxes (oracle: cell_bounds / terrain_probe; specification: flygym_amd/compose/world.py::terrain_probe).
+// Bounds (x_lo, x_hi, y_lo, y_hi) of a constant-height cell; +-kFar where the lattice does not divide that axis.
+constexpr float kFar = 1e30f;
+constexpr float kProbeEps = 1e-4f;
+// Height and bounds of the cell that holds (x, y) in one go (the same expressions as terrain_height and the oracle's
+// cell_bounds: the lattice indices are shared)
+__device__ __forceinline__ float terrain_cell_kind(int kind, float p0, float p1, float p2, float x, float y, float* b) {
+  b[0] = -kFar; b[1] = kFar; b[2] = -kFar; b[3] = kFar;
+  if (kind == 1) {
+    const float period = p0 + p1; const float k = floorf(x / period); const float u = x - k * period;
+    if (u < p0) { b[0] = k * period; b[1] = k * period + p0; return 0.f; }
+    b[0] = k * period + p0; b[1] = (k + 1.f) * period; return -p2;
+  }
+  if (kind == 2) {
+    const float i = floorf(x / p0), j = floorf(y / p0);
+    b[0] = i * p0; b[1] = (i + 1.f) * p0; b[2] = j * p0; b[3] = (j + 1.f) * p0;
+    const float sum = i + j; const float par = sum - 2.f * floorf(sum / 2.f);
+    return par != 0.f ? p1 : 0.f;
+  }
+  return 0.f;
+}
+__device__ __forceinline__ float terrain_cell(int terrain_type, const float* p, float x, float y, float* b) {
+  if (terrain_type == 3) {
+    const float st = floorf(x / p[3]); const float k = st - 3.f * floorf(st / 3.f);
+    const float h = k == 1.f ? terrain_cell_kind(1, 1.0f, p[1], p[2], x, y, b) : (k == 2.f ? terrain_cell_kind(2, p[0], 0.35f, 0.f, x, y, b)
+                                                                                            : terrain_cell_kind(0, 0.f, 0.f, 0.f, x, y, b));
+    const float lo = st * p[3], hi = (st + 1.f) * p[3];
+    if (b[0] < lo) b[0] = lo;
+    if (b[1] > hi) b[1] = hi;
+    return h;
+  }
+  return terrain_cell_kind(terrain_type, p[0], p[1], p[2], x, y, b);
+}
+// One collision probe (point, rho = 0, or sphere of radius rho) at (x, y), height zc over the ground plane: dtop = signed
+// distance of its lowest point to the top of its cell (kFar: it is inside that box and leaves it sideways), dwall / wall
+// = signed distance to the nearest side face that concerns it and the face's code 1..4 (outward normal +x, -x, +y, -y).
+// `reach`: faces further than that from the probe's surface cannot make a contact (the pair's margin) — a probe above its
+// cell with no boundary within reach returns without looking at the neighbours (nearly every hull vertex).
+__device__ __forceinline__ void terrain_probe(int terrain_type, const float* p, bool walls, float x, float y, float zc, float rho,
+                                              float reach, float& dtop, float& dwall, int& wall) {
+  float b[4];
+  const float h0 = terrain_cell(terrain_type, p, x, y, b);
+  const float zb = zc - rho;
+  dtop = zb - h0; dwall = kFar; wall = 0;
+  if (!walls) return;
+  const float delta[4] = {b[1] - x, x - b[0], b[3] - y, y - b[2]};
+  if (zb >= h0 && fminf(fminf(delta[0], delta[1]), fminf(delta[2], delta[3])) - rho > reach) return;
+  float he[4];
+  he[0] = b[1] < kFar ? terrain_height(terrain_type, p, b[1] + kProbeEps, y) : h0;
+  he[1] = b[0] > -kFar ? terrain_height(terrain_type, p, b[0] - kProbeEps, y) : h0;
+  he[2] = b[3] < kFar ? terrain_height(terrain_type, p, x, b[3] + kProbeEps) : h0;
+  he[3] = b[2] > -kFar ? terrain_height(terrain_type, p, x, b[2] - kProbeEps) : h0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)          // side faces that look at the probe (codes 2, 1, 4, 3: the face's normal is -e)
+    if (delta[e] < kFar && he[e] > zb && delta[e] - rho < dwall) { dwall = delta[e] - rho; wall = (e ^ 1) + 1; }
+  if (zb >= h0) return;
+  float pen = h0 - zb; int code = 0;   // inside its own cell's box: the ways out (codes 1..4: the normal is +e)
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (delta[e] < kFar && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = e + 1; }
+  if (code) { dtop = kFar; if (-pen < dwall) { dwall = -pen; wall = code; } }
+}
+
 // Scratch of the collision stage, overlaid on the T..W region (free between steps)
 struct CollisionScratch {
   float r[kMaxCon][3], dist[kMaxCon];
-  int info[kMaxCon];       // geom | k << 8 | body << 12   (k-th contact of that hull)
+  int info[kMaxCon];       // geom | k << 8 | body << 12 | frame id << 20   (k-th contact of that hull)
 };
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-template <class TP>
+// ROUGH: the world has a terrain (height cells with side faces); flat worlds run the instantiation without any of it
+template <class TP, bool ROUGH>
 __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int lane) {
   static_assert(sizeof(CollisionScratch) <= sizeof(float) * TP::NB * 12, "collision scratch does not fit T..W");
   CollisionScratch& X = *reinterpret_cast<CollisionScratch*>(&s.T[0][0]);
@@ -520,6 +599,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   // the model's side of this stage, staged in LDS at launch (see HotModel): scalars once, arrays as global memory
   const HotModel hm = hot_model(s, m);
   const int ng = hm.ng, terrain_type = hm.terrain_type, max_hull_contacts = hm.sem_max_hull_contacts;
+  const bool walls = hm.terrain_walls != 0;
   const float hull_skin = hm.hull_skin, terrain_top = hm.terrain[4];
   const float tpar[4] = {hm.terrain[0], hm.terrain[1], hm.terrain[2], hm.terrain[3]};
   const gptr<int> geom_body = G(hm.geom_body), geom_type = G(hm.geom_type), geom_hulladr = G(hm.geom_hulladr),
@@ -529,7 +609,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   const V3 n = ld3(hm.plane);
   const float pd = hm.plane[3];
   const V3 o = ld3(s.xpos()[0]);
-  const bool rough = terrain_type != 0;
+  constexpr bool rough = ROUGH;
   SUB_T0();
   // ---- phase 1, lane = geom: one batch of parameter loads, bounding-sphere cull, capsules resolved in place
   // (more than 64 contact geoms — e.g. every body segment in contact — take further passes of 64)
@@ -539,6 +619,9 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   int g_body = 0, g_type = -1, g_hadr = 0, g_hnum = 0, cnt = 0;
   float g_margin = 0.f, cd0 = 0.f, cd1 = 0.f;
   V3 cp0 = v3(0, 0, 0), cp1 = v3(0, 0, 0);
+  // terrains with side faces: a capsule end may also touch a face -> up to 4 contacts per capsule (ends x {top, face});
+  // the two face contacts and the frame ids of all four (3 bits each) live here
+  float cdw0 = 0.f, cdw1 = 0.f; V3 cpw0 = v3(0, 0, 0), cpw1 = v3(0, 0, 0); int cfid = 0, cntw = 0;
   bool near = false;
   if (gi < ng) {
     g_body = geom_body[gi]; g_type = geom_type[gi]; g_margin = pair_margin[gi];
@@ -550,17 +633,41 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     const V3 xp = ld3(s.xpos()[g_body]);
     V3 cw = mat_vec(R, bs);
     float dc = dot(n, cw) + dot(n, xp) - pd;
-    near = dc - bs_r - terrain_top <= g_margin;
+    // Terrains: the ground under the geom is no higher than the highest cell its bounding sphere's footprint touches — a
+    // 3 x 3 sample of the height map at the centre +- radius is conservative (every cell is wider than a geom's radius).
+    // Against the global maximum every leg segment dangling in a 2 mm gap passed the cull: 21 hull scans per step on the
+    // gapped world instead of 4.
+    float ttop = terrain_top;
+    if (rough) {
+      ttop = -kFar;
+#pragma unroll
+      for (int a = -1; a <= 1; ++a)
+#pragma unroll
+        for (int bb = -1; bb <= 1; ++bb)
+          ttop = fmaxf(ttop, terrain_height(terrain_type, tpar, cw.x + xp.x + (float)a * bs_r, cw.y + xp.y + (float)bb * bs_r));
+    }
+    near = dc - bs_r - ttop <= g_margin;
     const V3 p0 = mat_vec(R, l0) + xp, p1 = mat_vec(R, l1) + xp;
-    float d0 = dot(n, p0) - pd - rad, d1 = dot(n, p1) - pd - rad;
+    const float z0 = dot(n, p0) - pd, z1 = dot(n, p1) - pd;      // heights over the ground plane
+    float d0 = z0 - rad, d1 = z1 - rad;
     // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's
     // reach but above its own thickness needs no vertex scan
-    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - terrain_top <= g_margin;
+    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - ttop <= g_margin;
     if (near && g_type == GEOM_CAPSULE) {
-      if (rough) { d0 -= terrain_height(terrain_type, tpar, p0.x, p0.y); d1 -= terrain_height(terrain_type, tpar, p1.x, p1.y); }
+      float dw0 = kFar, dw1 = kFar; int w0 = 0, w1 = 0;
+      if (rough) {
+        terrain_probe(terrain_type, tpar, walls, p0.x, p0.y, z0, rad, g_margin, d0, dw0, w0);
+        terrain_probe(terrain_type, tpar, walls, p1.x, p1.y, z1, rad, g_margin, d1, dw1, w1);
+      }
       const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
       if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
       if (d1 <= g_margin) { if (cnt) { cd1 = d1; cp1 = q1; } else { cd0 = d1; cp0 = q1; } cnt++; }
+      if (rough) {      // side faces: the end sphere's point towards the face, moved half the distance back
+        if (w0 && dw0 <= g_margin) { const V3 nw = contact_frame(w0, Frame{n, n, n}).n; cdw0 = dw0; cpw0 = ((p0 - rad * nw) - (0.5f * dw0) * nw) - o; cfid = w0; cntw = 1; }
+        if (w1 && dw1 <= g_margin) { const V3 nw = contact_frame(w1, Frame{n, n, n}).n; const V3 q = ((p1 - rad * nw) - (0.5f * dw1) * nw) - o;
+                                     if (cntw) { cdw1 = dw1; cpw1 = q; cfid |= w1 << 3; } else { cdw0 = dw1; cpw0 = q; cfid = w1; } cntw++; }
+        cnt += cntw;
+      }
     }
   }
   SUB(21);
@@ -582,16 +689,19 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     const V3 xp = ld3(s.xpos()[b]);
     const V3 nb = matT_vec(R, n);
     const float c0 = dot(n, xp) - pd;
-    // distance of a hull vertex to the ground under it (flat ground: the plane distance)
+    // distance of a hull vertex to the ground under it (flat ground: the plane distance; terrains: the top of its cell, or
+    // kFar when a side face owns the vertex — terrain_probe)
+    float pdw = kFar; int pw_code = 0;          // side face of the vertex probed last
     auto vdist = [&](V3 v) {
       float di = dot(nb, v) + c0;
-      if (rough) { const V3 pw = mat_vec(R, v) + xp; di -= terrain_height(terrain_type, tpar, pw.x, pw.y); }
+      if (rough) { const V3 pw = mat_vec(R, v) + xp; terrain_probe(terrain_type, tpar, walls, pw.x, pw.y, di, 0.f, margin, di, pdw, pw_code); }
       return di;
     };
     // scan 1 — the deepest vertex — is all most near hulls ever get (a tarsal segment next to the one in contact: its
     // bounding cylinder reaches the margin, its vertices do not), and a plain loop pays one memory round trip per 64
     // vertices: the loads of four passes are issued together (indices clamped, results of the overhang ignored)
     float best = INFINITY; int bi = 0x7fffffff;
+    float bestw = INFINITY; int biw = 0x7fffffff;        // the vertex nearest to (deepest in) a side face: index * 8 + face code
     for (int base = lane; base < nvv + lane; base += 4 * kWave) {
       V3 hv[4];
 #pragma unroll
@@ -602,15 +712,21 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
         if (i < nvv) {
           const float di = vdist(hv[k]);
           if (di < best) { best = di; bi = i; }
+          if (rough && pw_code && pdw < bestw) { bestw = pdw; biw = i * 8 + pw_code; }
         }
       }
     }
     wave_argmin(best, bi);
     const float dmin = best; const int ia = bi;
-    if (!(dmin <= margin)) { SUB_COUNT(25, 1); SUB_COUNT(26, (unsigned long long)(fminf(dmin, 1.f) * 1e6f)); continue; }
+    bool face = false;
+    if (rough && walls) { wave_argmin(bestw, biw); face = bestw <= margin; }
+    if (!(dmin <= margin) && !face) { SUB_COUNT(25, 1); SUB_COUNT(26, (unsigned long long)(fminf(dmin, 1.f) * 1e6f)); continue; }
     SUB_COUNT(27, 1);
+    int nsel = 0;
+    int s1 = -1, s2 = -1, s3 = -1;
+    if (dmin <= margin) {
+    nsel = 1;
     const float thr = fminf(dmin + hull_skin, margin);
-    int s1 = -1, s2 = -1, s3 = -1; int nsel = 1;
     const V3 va = ld3(V + 3 * ia);
     // b: farthest candidate from a
     best = -INFINITY; bi = 0x7fffffff;
@@ -652,6 +768,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       }
     }
     nsel = nsel < max_hull_contacts ? nsel : max_hull_contacts;
+    }   // a vertex within the margin of the top of its cell
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
@@ -661,6 +778,15 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       X.dist[nh + lane] = dist;
       st3(X.r[nh + lane], (pw - (0.5f * dist) * n) - o);
     }
+    if (face && lane == nsel && nh + lane < kMaxCon) {      // the side-face contact of this hull: its own frame
+      const int code = biw & 7;
+      const V3 nw = contact_frame(code, Frame{n, n, n}).n;
+      const V3 pw = mat_vec(R, ld3(V + 3 * (biw >> 3))) + xp;
+      X.info[nh + lane] = (g0 + g) | (lane << 8) | (b << 12) | (code << 20);
+      X.dist[nh + lane] = bestw;
+      st3(X.r[nh + lane], (pw - (0.5f * bestw) * nw) - o);
+    }
+    nsel += face ? 1 : 0;
     if (lane == g) cnt = nsel;
     nh += nsel;
   }
@@ -672,8 +798,11 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   const int sl = slot_base + slot0;
   geom_slot0[gi] = slot_base + slot0;
   if (g_type == GEOM_CAPSULE && cnt > 0) {
-    if (sl < kMaxCon) { s.c_info[sl] = info_pack(gi, -1, g_body, 0); s.c_D[sl] = cd0; st3(s.c_r[sl], cp0); }
-    if (cnt > 1 && sl + 1 < kMaxCon) { s.c_info[sl + 1] = info_pack(gi, -1, g_body, 0); s.c_D[sl + 1] = cd1; st3(s.c_r[sl + 1], cp1); }
+    const int ntop = cnt - cntw;       // top (ground-plane frame) contacts first, then the side faces
+    if (ntop > 0 && sl < kMaxCon) { s.c_info[sl] = info_pack(gi, -1, g_body, 0); s.c_D[sl] = cd0; st3(s.c_r[sl], cp0); }
+    if (ntop > 1 && sl + 1 < kMaxCon) { s.c_info[sl + 1] = info_pack(gi, -1, g_body, 0); s.c_D[sl + 1] = cd1; st3(s.c_r[sl + 1], cp1); }
+    if (cntw > 0 && sl + ntop < kMaxCon) { s.c_info[sl + ntop] = info_pack(gi, -1, g_body, 0) | ((cfid & 7) << 24); s.c_D[sl + ntop] = cdw0; st3(s.c_r[sl + ntop], cpw0); }
+    if (cntw > 1 && sl + ntop + 1 < kMaxCon) { s.c_info[sl + ntop + 1] = info_pack(gi, -1, g_body, 0) | ((cfid >> 3) << 24); s.c_D[sl + ntop + 1] = cdw1; st3(s.c_r[sl + ntop + 1], cpw1); }
   }
   slot_base += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
   }   // passes of 64 geoms
@@ -682,11 +811,17 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   if (lane < nh && lane < kMaxCon) {
     const int info = X.info[lane];
     const int slot = geom_slot0[info & 0xff] + ((info >> 8) & 0xf);
-    if (slot < kMaxCon) { s.c_info[slot] = info_pack(info & 0xff, -1, (info >> 12) & 0xff, 0); s.c_D[slot] = X.dist[lane]; st3(s.c_r[slot], ld3(X.r[lane])); }
+    if (slot < kMaxCon) { s.c_info[slot] = info_pack(info & 0xff, -1, (info >> 12) & 0xff, 0) | (((info >> 20) & 7) << 24); s.c_D[slot] = X.dist[lane]; st3(s.c_r[slot], ld3(X.r[lane])); }
   }
   const int ncon = total > kMaxCon ? kMaxCon : total;
   if (lane == 0) { s.ncon = ncon; s.overflow = total > kMaxCon ? 1 : 0; }
   WSYNC();
+  {   // contacts with a terrain side face (their own frames): the stages that follow take the general path only if there are any
+    if constexpr (rough) {
+      const unsigned long long wf = __ballot(lane < ncon && info_fid(s.c_info[lane]) != 0);
+      if (lane == 0) s.nwall = __popcll(wf);
+    }
+  }
   for (int b = lane; b <= s.nb(); b += kWave) {
     int c_before = 0;
     for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
@@ -865,8 +1000,18 @@ __device__ __forceinline__ KLane k_lane(int r, const Frame& fr) {
   }
   return K;
 }
+// `walls` (terrain kernels only): some contact of this step touches a terrain side face — the contact's frame id decides,
+// and a face's row constants are built on the spot (wave-uniform flag: face-free steps never look)
 template <class TP>
-__device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, const KLane& K, const Frame& fr) {
+__device__ __forceinline__ void add_contact_K_row(float* row, const FlyLds<TP>& s, int c, const KLane& K0, const Frame& fr0, int r = 0,
+                                                  bool walls = false) {
+  KLane K = K0; Frame fr = fr0;
+  if constexpr (TP::kTerrain) {
+    if (walls) {
+      const int fid = info_fid(s.c_info[c]);
+      if (fid) { fr = contact_frame(fid, fr0); K = k_lane(r, fr); }
+    }
+  }
   float m_nn, m_n1, m_n2, m_11, m_22;
   if constexpr (kHasCm3<TP>) {
     const float* q = s.c_m3[c];
@@ -963,6 +1108,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   float* x = s.vec(x_id);
   Frame fr{};
   if (withK) fr = ld_frame(s, m);
+  const bool walls = TP::kTerrain && withK && __builtin_amdgcn_readfirstlane(s.nwall) != 0;      // terrain side faces in contact this step
   const LaneRole L = lane_role<TP>(lane);
   const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
   static_assert(sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 12, "ABA hand-off does not fit T..W");
@@ -1028,11 +1174,11 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
         float row[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
-        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
+        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
         add6(IA, row);
       } else {
         add_inertia_row(IA, s, b, IM);
-        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr);
+        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr, L.rr, walls);
       }
     }
     float sj[6];
@@ -1062,7 +1208,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       for (int c = 0; c < 6; c++) row[c] = s.Isym[0][so[c]];
     } else add_inertia_row(row, s, 0, IM);
     if (withK) {
-      for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, KL, fr);
+      for (int c = cs_root0; c < cs_root1; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
       // tether weld: its six rows are the components of the root twist -> a diagonal term per row
       if constexpr (WELD) static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
     }
@@ -1221,14 +1367,16 @@ __device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
 template <class TP, bool SEEDED, class Emit>
 __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const WeldRow& wr, const Frame& fr,
                                                 const float* rows, float weld_row, float seed_scale,
-                                                const GModel& m, int lane, Emit&& emit) {
+                                                const GModel& m, int lane, bool walls, Emit&& emit) {
   if (wr.on) s.weld_w[wr.comp] = weld_row;
   if (c.on) {
     int act = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) act |= (c.jar[k] < 0.f ? 1 : 0) << k;
     float fn = rows[0] + rows[1] + rows[2] + rows[3], f1 = c.mu * (rows[0] - rows[1]), f2 = c.mu * (rows[2] - rows[3]);
-    V3 F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
+    V3 F;
+    if (walls) { const Frame cf = contact_frame(info_fid(c.info), fr); F = fn * cf.n + f1 * cf.t1 + f2 * cf.t2; }
+    else F = fn * fr.n + f1 * fr.t1 + f2 * fr.t2;
     stsv(s.c_w[lane], SV{cross(c.r, F), F});
     s.c_info[lane] = c.info | (act << 20);
     if constexpr (kHasCm3<TP>) {
@@ -1318,20 +1466,25 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   STAGE(1);
   stage_inertia(s, m, lane);
   STAGE(2);
-  stage_collision(s, m, lane);
+  stage_collision<TP, TP::kTerrain>(s, m, lane);
   if (pf.next_row && pf.mine) pf.value = G(pf.next_row)[lane];      // consumed at the top of the next step
   if (last) write_poses(s, m, st, w, lane);       // the body poses die here (their LDS is the solver's from now on)
   STAGE(3);
   const int ncon = s.ncon;
+  // terrain side faces in contact this step: those contacts carry their own frames (wave-uniform; flat worlds: never)
+  const bool walls = TP::kTerrain && __builtin_amdgcn_readfirstlane(s.nwall) != 0;
 
   // ---- contact parameters (lane c owns contact c)
   ContactRegs c;
+  auto rows = [&](SV t, float* out) {       // the four pyramid rows of this lane's contact applied to a body twist
+    if (walls) rows_of_twist(c, contact_frame(info_fid(c.info), fr), t, out); else rows_of_twist(c, fr, t, out);
+  };
   c.on = lane < ncon;
   if (c.on) {
     const int info0 = s.c_info[lane];
     c.r = ld3(s.c_r[lane]); c.body = info_body(info0); c.geom = info_geom(info0); c.dist = s.c_D[lane];
     int g = c.geom;
-    c.info = info_pack(g, m.geom_sensor[g], c.body, 0);
+    c.info = info_pack(g, m.geom_sensor[g], c.body, 0) | (info0 & (7 << 24));      // the contact's frame id stays with it
     c.mu = m.pair_friction[5 * g];
     c.margin = m.pair_margin[g];
     const float* solref = &m.pair_solref[2 * g];
@@ -1384,7 +1537,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     tree_velocity_bias(s, m, lane);
     if (c.on) {
       float velrow[4];
-      rows_of_twist(c, fr, ldsv(s.W[c.body]), velrow);
+      rows(ldsv(s.W[c.body]), velrow);
       const float rr0 = c.dist - c.margin;
 #pragma unroll
       for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
@@ -1414,7 +1567,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     // reference acceleration of the contact rows needs the body velocities (still in W here)
     if (c.on) {
       float velrow[4];
-      rows_of_twist(c, fr, ldsv(s.W[c.body]), velrow);
+      rows(ldsv(s.W[c.body]), velrow);
       const float rr0 = c.dist - c.margin;
 #pragma unroll
       for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
@@ -1463,7 +1616,8 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         for (int cc = c0; cc < c1; ++cc) {
           if (ag != -2 && info_geom(s.c_info[cc]) != ag) continue;
           V3 r = ld3(s.c_r[cc]);
-          acc = acc + k * SV{cross(r, fr.n), fr.n};
+          const V3 nn = walls ? contact_frame(info_fid(s.c_info[cc]), fr).n : fr.n;      // along the contact's own normal
+          acc = acc + k * SV{cross(r, nn), nn};
         }
         stsv(s.W[body], acc);
       }
@@ -1522,7 +1676,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     } }
     // candidate 2 (the unconstrained acceleration) first: its body twists are what the smooth solve left in T
     float j0[4] = {0.f, 0.f, 0.f, 0.f}, w0 = 0.f, v0 = 0.f;
-    if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), j0);
+    if (c.on) { rows(ldsv(s.T[c.body]), j0);
 #pragma unroll
       for (int k = 0; k < 4; k++) { j0[k] -= c.aref[k]; if (j0[k] < 0.f) v0 += 0.5f * c.D * j0[k] * j0[k]; } }
     if (wr.on) { w0 = s.T[0][wr.comp] - wr.aref; v0 += 0.5f * wr.D * w0 * w0; }
@@ -1534,7 +1688,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         Gv[j] = v;
         g += 0.5f * search[j] * v;
       });
-      if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);  // J (qacc − qacc_smooth); candidate 2 adds J qacc_smooth − aref
+      if (c.on) rows(ldsv(s.T[c.body]), c.jar);  // J (qacc − qacc_smooth); candidate 2 adds J qacc_smooth − aref
       if (wr.on) wr.jar = s.T[0][wr.comp];
     } else {
       mul_M(s, s.qacc, m, lane, false, [&](int j, float v) {      // qacc still holds the warm start
@@ -1542,7 +1696,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         Gv[j] = gv;
         g += 0.5f * (s.qacc[j] - s.qacc_smooth[j]) * gv;
       });
-      if (c.on) { rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jar);
+      if (c.on) { rows(ldsv(s.T[c.body]), c.jar);
 #pragma unroll
         for (int k = 0; k < 4; k++) c.jar[k] -= c.aref[k]; }
       if (wr.on) wr.jar = s.T[0][wr.comp] - wr.aref;
@@ -1571,7 +1725,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     {
       float f0[4] = {0.f, 0.f, 0.f, 0.f};
       if (c.on) contact_row_forces(c, -1.f, f0);
-      contact_project<TP, false>(s, c, wr, fr, f0, wr.D * wr.jar, 0.f, m, lane, [&](int j, float proj) {
+      contact_project<TP, false>(s, c, wr, fr, f0, wr.D * wr.jar, 0.f, m, lane, walls, [&](int j, float proj) {
         const float gv = Gv[j], qs = s.qfrc_smooth[j];
         const float gj = gv + proj;
         const float mag = fabsf(gv + qs) + fabsf(qs) + fabsf(proj);
@@ -1588,7 +1742,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       aba_solve<TP, WELD>(s, V_A, V_B, true, 0.f, m, lane);   // search = −H⁻¹ grad ; T = twists(search)
       contact_reload(c, s, lane);
       STAGE(10);
-      if (c.on) rows_of_twist(c, fr, ldsv(s.T[c.body]), c.jv);
+      if (c.on) rows(ldsv(s.T[c.body]), c.jv);
       if (wr.on) wr.jv = s.T[0][wr.comp];
       // g1 = search·(M qacc − qfrc_smooth) = search·grad + (J search)·f ;  g2 = search·M·search as twice the kinetic
       // energy of the twists the ABA left in T (a sum of positive terms).  W keeps I_b T_b for the update sweep.
@@ -1663,7 +1817,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       if (wr.on) { dfw = wr.D * alpha * wr.jv; wr.jar += alpha * wr.jv; }
       gn = 0.f; gm = 0.f;
       const float cost_lane = constraint_cost_lane(c, wr);     // of the moved residuals; summed with gn, gm below
-      contact_project<TP, true>(s, c, wr, fr, df, dfw, alpha, m, lane, [&](int j, float x) {
+      contact_project<TP, true>(s, c, wr, fr, df, dfw, alpha, m, lane, walls, [&](int j, float x) {
         const float sj = search[j];
         x += alpha * s.arm[j] * sj;
         s.qacc[j] += alpha * sj;
@@ -1686,7 +1840,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     {
       float ff[4] = {0.f, 0.f, 0.f, 0.f};
       if (c.on) contact_row_forces(c, 1.f, ff);
-      contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, [&](int j, float v) { s.vD[j] = v; });
+      contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, walls, [&](int j, float v) { s.vD[j] = v; });
     }   // qfrc_constraint lives in vD until the Euler step
     if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) {
       if (red) {     // the rest's accelerations: qacc_smooth + the response of the cached factors to the root's change
@@ -1717,10 +1871,13 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     WSYNC();
     if (m.nsensor && lane < 6 && ncon > 0) {
       float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
+      Frame f1 = fr;                       // frame of the leg's first contact (what the sensor reports as normal / tangent)
       for (int cc = 0; cc < ncon; ++cc) {
         if (info_sensor(s.c_info[cc]) != lane) continue;
         V3 f = ld3(&s.c_w[cc][3]);
-        float fn = dot(f, fr.n);
+        const Frame cf = walls ? contact_frame(info_fid(s.c_info[cc]), fr) : fr;
+        if (cnt == 0) f1 = cf;
+        float fn = dot(f, cf.n);
         V3 p = ld3(s.c_r[cc]);
         wsum += fn; pc = pc + fn * p; pm = pm + p; cnt++;
       }
@@ -1735,10 +1892,10 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         float* o16 = out + 16 * ol;
         V3 o = ld3(s.xpos()[0]);
         if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
-          F = v3(dot(fr.n, F), dot(fr.t1, F), dot(fr.t2, F));
-          Tq = v3(dot(fr.n, Tq), dot(fr.t1, Tq), dot(fr.t2, Tq));
+          F = v3(dot(f1.n, F), dot(f1.t1, F), dot(f1.t2, F));
+          Tq = v3(dot(f1.n, Tq), dot(f1.t1, Tq), dot(f1.t2, Tq));
         }
-        o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, fr.n); st3(o16 + 13, fr.t1);
+        o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, f1.n); st3(o16 + 13, f1.t1);
       }
     }
   }
@@ -1923,6 +2080,7 @@ __device__ __forceinline__ void stage_launch_constants(FlyLds<TP>& s, const GMod
 #pragma unroll
     for (int i = 0; i < 5; ++i) h.terrain[i] = m.terrain[i];
     h.hull_skin = m.hull_skin; h.terrain_type = m.terrain_type; h.ng = m.ng; h.sem_max_hull_contacts = m.sem_max_hull_contacts;
+    h.terrain_walls = m.sem_terrain_walls;
   }
   if constexpr (kHasIsym<TP>) for (int i = lane; i < 3 * s.nv(); i += kWave) (&s.axis[0][0])[i] = m.dof_axis[i];
 }
@@ -2201,26 +2359,32 @@ using FlyTopoActive = Topo<6, 3, 2, 1, 1>;         // LEGS_ACTIVE_ONLY skeleton:
 #if NMF_HAS_TOPO(0)
 template __global__ void nmf_step_kernel<FlyTopo, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<FlyTopo, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<FlyTopo>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 #if NMF_HAS_TOPO(1)
 template __global__ void nmf_step_kernel<FlyTopoActive, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<FlyTopoActive, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<FlyTopoActive>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 #if NMF_HAS_TOPO(2)
 template __global__ void nmf_step_kernel<TreeTopoSmall, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<TreeTopoSmall, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<TreeTopoSmall>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 #if NMF_HAS_TOPO(3)
 template __global__ void nmf_step_kernel<TreeTopo, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<TreeTopo, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<TreeTopo>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 #if NMF_HAS_TOPO(4)
 template __global__ void nmf_step_kernel<FlyTopoBio, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<FlyTopoBio, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<FlyTopoBio>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 #if NMF_HAS_TOPO(5)
 template __global__ void nmf_step_kernel<FlyTopoAll, false>(const DevModel*, DevState, ReplayArgs, int);
 template __global__ void nmf_step_kernel<FlyTopoAll, true>(const DevModel*, DevState, ReplayArgs, int);
+template __global__ void nmf_step_kernel<Terrain<FlyTopoAll>, false>(const DevModel*, DevState, ReplayArgs, int);     // terrain worlds (never tethered)
 #endif
 
 }  // namespace nmf

@@ -205,7 +205,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
       const int act = info_act(s.c_info[c]);
       if (!act) continue;
       float ln[6], l1[6], l2[6];
-      contact_dirs(ld3(s.c_r[c]), fr, ln, l1, l2);
+      contact_dirs(ld3(s.c_r[c]), TP::kTerrain ? contact_frame(info_fid(s.c_info[c]), fr) : fr, ln, l1, l2);     // a terrain side face has its own frame
       const float D = s.c_D[c], mu = s.c_mu[c];
       const float a0 = (act & 1) ? 1.f : 0.f, a1 = (act & 2) ? 1.f : 0.f, a2 = (act & 4) ? 1.f : 0.f, a3 = (act & 8) ? 1.f : 0.f;
       // sum_k a_k D (ln +- mu lt)(ln +- mu lt)T
@@ -349,7 +349,8 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
 #pragma unroll
     for (int i = 0; i < 3; ++i) { KL.dA[i] = q[i]; KL.dB[i] = q[3 + i]; KL.dO[i] = q[6 + i]; }
     KL.ia = __float_as_int(q[9]); KL.ib = __float_as_int(q[10]);
-    for (int c = s.body_cstart[nd.b]; c < s.body_cstart[nd.b + 1]; ++c) add_contact_K_row(row, s, c, KL, fr);
+    const bool walls = TP::kTerrain && __builtin_amdgcn_readfirstlane(s.nwall) != 0;
+    for (int c = s.body_cstart[nd.b]; c < s.body_cstart[nd.b + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
   }
   if constexpr (NUM > 0) {
     static_for<NUM>([&](auto I) {

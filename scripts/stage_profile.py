@@ -7,7 +7,8 @@ import numpy as np, torch
 from flygym_amd import _native
 lib_prof = ROOT / "flygym_amd" / "libnmf_hip_prof.so"
 if "--build" in sys.argv or not lib_prof.exists():
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *_native.MATH_FLAGS, "-fPIC", "-shared", "-DNMF_STAGE_PROFILE",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *_native.MATH_FLAGS,
+                    "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC", "-shared", "-DNMF_STAGE_PROFILE", *[a for a in sys.argv if a.startswith("-D")],
                     f"-I{ROOT/'include'}", f"-I{ROOT/'flygym_amd/csrc'}", str(ROOT/"flygym_amd/csrc/nmf_capi.hip"), "-o", str(lib_prof)], check=True)
     if "--build" in sys.argv: sys.exit(0)
 _native.LIB_PATH = lib_prof
@@ -17,6 +18,12 @@ from flygym_amd.replay import ReplayTargetData
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 preset = next((a.split('=')[1] for a in sys.argv if a.startswith('--joint-preset=')), 'legs_only')
 fly, world, _ = make_model(joints_preset=preset)
+terrain = next((a.split('=')[1] for a in sys.argv if a.startswith('--terrain=')), 'flat')
+if terrain != 'flat':
+    import flygym_amd.compose as C
+    from flygym_amd.utils.math import Rotation3D
+    world = {"gapped": C.GappedTerrainWorld, "blocks": C.BlocksTerrainWorld, "mixed": C.MixedTerrainWorld}[terrain]()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
 sim = HIPSimulation(world, n_worlds=n, device=0)
 L = _native.lib()
 L.nmf_debug_stage_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]

@@ -194,7 +194,10 @@ def test_config4_terrain_at_full_size(torch_mod, terrain):
         assert worst < 60
         up = 1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)
         assert float(up.min()) > 0.5 and float((up > 0.9).float().mean()) > 0.97      # a stumble on a block edge, no fall (~1 % tilt past 0.9 at some point)
-        assert float((q[:, 0] - x0).median()) > 0.15                      # 1.8 gait cycles forward
+        # 1.8 gait cycles forward.  (Round 2, tops only: > 0.15 mm.  With the cells' side faces a tarsus that drops into a
+        # gap or meets a raised square is held by the wall instead of sliding through it: the open-loop gait, which does
+        # not know the terrain, gets 0.06 / 0.13 mm on the gapped / blocks worlds.)
+        assert float((q[:, 0] - x0).median()) > 0.03
         finals.append(q.clone())
         del sim
     assert torch.equal(finals[0], finals[1])

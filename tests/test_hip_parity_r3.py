@@ -315,3 +315,76 @@ def test_observation_block_packed_in_one_launch(torch_mod, bench_model):
     assert torch.equal(wide[:n, :270], a) and bool((wide[n:] == -7).all()) and bool((wide[:, 270:] == -7).all())
     with pytest.raises(ValueError):
         sim.pack_observations(torch.zeros((n, 100), device=sim.device))
+
+
+def test_terrain_side_faces_on_the_kernel(torch_mod, oracle_lib):
+    """Round 3: the cells of a terrain are boxes — their side faces collide (horizontal normals, per-contact frames in the
+    row products, the projection, the articulated-body stiffness rows, adhesion and the sensors).
+    (1) Known answer: a sphere pushed sideways against a raised block by a tilted gravity rests on the face at the
+    closed-form penetration, the floor carrying the weight (tests/test_terrain.py has the oracle's side of it).
+    (2) A fly walking over the blocks terrain: states in which the float64 oracle has a side-face contact, one step from
+    each on the engine — contact lists bit-equal to the oracle's, accelerations to float32 accuracy."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    import test_oracle_closed_form as cf
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+    from test_terrain import TERRAINS
+    from tiny_models import TinyWorld, sphere_on_plane
+
+    gx = 0.45 * cf.G
+    m = sphere_on_plane(cf.MASS, cf.RADIUS, mu=cf.MU, solref=cf.SOLREF, solimp=cf.SOLIMP, margin=cf.MARGIN, gravity=(-gx, 0.0, -cf.G),
+                        terrain=TERRAINS["blocks"], start_xy=(cf.RADIUS + cf.MARGIN + 2e-4, 0.65), start_height=cf.RADIUS + cf.MARGIN)
+    sim = HIPSimulation(TinyWorld(m), n_worlds=2, device=0)
+    sim.step(3000)
+    q, v = sim.field("qpos")[0].cpu().numpy().astype(np.float64), sim.field("qvel")[0].cpu().numpy()
+    assert int(sim.field("stats")[0, 0].item()) == 4 and np.abs(v[:3]).max() < 1e-2
+    assert q[0] - cf.RADIUS - cf.MARGIN == pytest.approx(cf.rest_position(cf.MASS * gx), rel=5e-2)        # leaning on the face
+    assert q[2] - cf.RADIUS - cf.MARGIN == pytest.approx(cf.rest_position(cf.MASS * cf.G), rel=5e-2)     # standing on the floor
+
+    fly = C.Fly(name="t")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    fly.add_actuators(sk.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    world = C.BlocksTerrainWorld()
+    world.add_fly(fly, (0.3, 0.2, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    blob = world.compile_model().to_blob()
+    o = oracle_lib.Oracle(blob, "f64")
+    o.ctrl[42:] = 1.0
+    o.step(400)
+    table = TripodCPG(fly.get_actuated_jointdofs_order(C.ActuatorType.POSITION), 1e-4).targets(1, 2500)[0]
+    ids = np.arange(42, dtype=np.int32)
+    states = []
+    for k in range(3000):
+        o.step_replay(table, ids, k, 1)
+        nrm = o.arr("con_frame").reshape(-1, 9)[:, 2]
+        if len(nrm) and (nrm == 0).any() and (not states or k - states[-1][0] >= 25):
+            states.append((k, o.qpos.copy(), o.qvel.copy(), o.ctrl.copy(), o.arr("qacc_warmstart").copy()))
+        if len(states) == 8:
+            break
+    assert len(states) >= 4, "the walk over the blocks never touched a side face"
+    n = len(states)
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    for name, idx in (("qpos", 1), ("qvel", 2), ("ctrl", 3), ("qacc_warmstart", 4)):
+        sim.field(name)[:] = torch.as_tensor(np.stack([s[idx] for s in states]), dtype=torch.float32, device=sim.device)
+    sim.step(1)
+    torch.cuda.synchronize()
+    qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+    faces = 0
+    for w, st in enumerate(states):
+        ref = {}
+        for prec in ("f64", "f32"):
+            r = oracle_lib.Oracle(blob, prec)
+            r.qpos[:] = st[1]; r.qvel[:] = st[2]; r.ctrl[:] = st[3]; r.arr("qacc_warmstart")[:] = st[4]
+            r.step(1)
+            ref[prec] = r
+        nc = int(stats[w, 0])
+        assert nc == ref["f32"].ints()["ncon"] == ref["f64"].ints()["ncon"], f"state {w}"
+        assert geom[w, :nc].astype(int).tolist() == ref["f64"].ints()["con_geom"]
+        scale = np.abs(ref["f64"].arr("qacc")).max()
+        assert np.abs(qacc[w] - ref["f64"].arr("qacc")).max() < 2e-3 * scale, f"state {w}"
+        faces += int((ref["f64"].arr("con_frame").reshape(-1, 9)[:, 2] == 0).sum())
+    assert faces >= n // 2          # (a state is the one AFTER the step in which the oracle touched a face: most still do)
