@@ -105,6 +105,7 @@ class EngineSemantics:
                          0, 0, 0], dtype=np.int32)
 
     def as_dict(self):
+        self.validate()
         return {k: getattr(self, k) for k in (*self._CHOICES, "max_hull_contacts")}
 _DT = {np.dtype(np.float64): 0, np.dtype(np.int32): 1}
 

@@ -72,6 +72,10 @@ class BaseWorld(ABC):
         """The engine's compiled model of this world (cached until the world changes)."""
         from ..compiler.model import compile_world
 
+        # the cache is only as good as what it was compiled from: world.semantics is a plain mutable object, so a flag set
+        # after the first compile must not be silently ignored (ADVICE r2)
+        if self._compiled is not None and self._compiled.meta.get("semantics") != self.semantics.as_dict():
+            self._compiled = None
         if self._compiled is None:
             self._compiled = compile_world(self)
         return self._compiled

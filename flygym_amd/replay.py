@@ -93,13 +93,21 @@ class MotionSnippet:
                                 sgfilter_window_sec: float = 0.03, sgfilter_polyorder: int = 3):
         """The same table computed on the GPU (``nmf_replay_resample``: Savitzky-Golay + not-a-knot cubic spline in
         float64, one workgroup per column): float32 torch tensor ``(n_output_steps, len(output_dof_order))`` on
-        ``device``.  Only the clip (660 x 42 floats) and the filter constants cross PCIe."""
+        ``device``.  Only the clip (660 x 42 floats) and the filter constants cross PCIe.
+
+        The kernel keeps a column of the clip in LDS: clips of 6 to 1536 frames with a filter window no longer than the
+        clip.  Anything else takes the host path (:meth:`get_joint_angles`, scipy) and is copied to ``device``."""
         import torch
 
         from . import _native
 
         window = int(sgfilter_window_sec * self.data_fps)
         window += 1 - (window % 2)
+        n_frames = self.joint_angles.shape[0]
+        if not 6 <= n_frames <= 1536 or window > n_frames or window < 3:
+            host = self.get_joint_angles(output_timestep, output_dof_order, sgfilter_window_sec=sgfilter_window_sec,
+                                         sgfilter_polyorder=sgfilter_polyorder)
+            return torch.as_tensor(np.ascontiguousarray(host, dtype=np.float32), device=device)
         cols = [
             (self.legs.index(d.child.pos), self.dofs_per_leg.index((d.parent.link, d.child.link, d.axis.value)))
             for d in output_dof_order

@@ -197,3 +197,38 @@ def test_reference_utility_surface(bench_model, capsys):
     assert "PERFORMANCE" in out and "Physics" in out and "No frames" in out and "parallelized" in out.lower()
     with pytest.raises(ValueError, match="n_steps"):
         print_perf_report(1, 0, 0, 0, 1e-3)
+
+
+def test_semantics_changed_after_compile_recompile_the_world(bench_model):
+    """world.semantics is a mutable object read at compile time: a flag flipped after the first compile must reach the
+    next compile_model() instead of being shadowed by the cached model."""
+    from flygym_amd.models import make_model
+
+    fly, world, _ = make_model()
+    a = world.compile_model()
+    assert world.compile_model() is a                                   # cached while nothing changes
+    world.semantics.pyramid_R = "plain"
+    b = world.compile_model()
+    assert b is not a and int(b["sem_options"][0]) == 1 and int(a["sem_options"][0]) == 0
+    world.semantics.mesh_inertia = "convex"                              # a compile-time semantic: the inertias change
+    c = world.compile_model()
+    assert c is not b and not np.allclose(c["body_inertia"], b["body_inertia"])
+    world.semantics.pyramid_R = "nonsense"
+    with pytest.raises(ValueError):
+        world.compile_model()
+
+
+def test_replay_device_path_falls_back_for_clips_the_kernel_cannot_hold():
+    """MotionSnippet.get_joint_angles_device: clips outside the kernel's 6..1536 frames take the scipy path."""
+    torch = pytest.importorskip("torch")
+    from flygym_amd.anatomy import AxisOrder, JointPreset, Skeleton
+    from flygym_amd.replay import MotionSnippet
+
+    ms = MotionSnippet()
+    sk = Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.LEGS_ONLY)
+    order = sk.get_actuated_dofs_from_preset("legs_active_only")
+    ms.joint_angles = np.tile(ms.joint_angles, (3, 1, 1))                # 1980 frames: more than the kernel's LDS column
+    got = ms.get_joint_angles_device(1e-3, order, "cpu")
+    want = ms.get_joint_angles(1e-3, order).astype(np.float32)
+    assert tuple(got.shape) == want.shape and got.dtype == torch.float32
+    np.testing.assert_array_equal(got.numpy(), want)
