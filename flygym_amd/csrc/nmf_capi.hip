@@ -320,7 +320,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     for (int cand = 4; cand <= 5 && topo < 0 && bp && dn; ++cand) {
       const int* pat = cand == 4 ? patB : patA;
       const int nb = model->nb, lb0 = 21, want_nv = cand == 4 ? 132 : 210;
-      bool ok = nb == 69 && model->nv == want_nv && (int)dn->i.size() == nb && dn->i[0] == 6;
+      bool ok = nb == 69 && model->nv == want_nv && (int)dn->i.size() == nb && dn->i[0] == 6 && model->nu <= nmf::FlyTopoBio::kCtrl;
       int rest_v = 0;
       for (int bb = 1; ok && bb < lb0; ++bb) { rest_v += dn->i[(size_t)bb]; ok = bp->i[(size_t)bb] >= 0 && bp->i[(size_t)bb] < lb0 && bp->i[(size_t)bb] < bb; }
       ok = ok && rest_v == 60;

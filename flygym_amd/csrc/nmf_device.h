@@ -33,7 +33,9 @@ template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
 struct HybridTopo {
   static constexpr bool kStar = true;
   static constexpr bool kTerrain = false;   // see Terrain<> below
-  static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 6 + REST_V_ + NLEG_ * (DOFS + ...) + 8;
+  // controls a kernel keeps in LDS: 48 for the leg skeletons, 64 for the full-body ones (nmf_batch_create sends models
+  // with more actuators to the general-tree kernel, which holds one per dof)
+  static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 64;
   static constexpr int REST_B = REST_B_, REST_V = REST_V_;
   static constexpr int NLEG = NLEG_;
   static constexpr int NBL = sizeof...(DOFS);

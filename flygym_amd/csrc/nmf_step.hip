@@ -101,11 +101,9 @@ struct TreeLds<TP, false, true> {
 template <class TP>
 struct TreeLds<TP, true, true> {   // hybrid kernels: the same for the rest bodies only
   float fact[TP::kNFact][8];
-  float slot[TP::kNSlot][27];
-  // the rest carries no contacts while walking, so its matrix factors are the same for the smooth solve and every Newton
-  // solve of a step: cached (valid flag reset every step; the damping term they were built with)
-  int rest_fact_valid;
-  float rest_fact_hdamp;
+  // (no slot array: what a rest body hands to its parent lives only while an elimination sweep runs, in LDS that is dead
+  // inside an articulated-body solve — FlyLds::slot_at.  2160 bytes: with a 64-control cap the ALL_BIOLOGICAL kernel fits
+  // 8 flies per CU instead of 7.)
   // reduced constraint problem (physics_forward): while no rest body is in contact the rest's accelerations are
   // eliminated from the Newton loop — the root carries the rest's articulated inertia restA (symmetric 6x6) instead
   int reduced;
@@ -161,6 +159,7 @@ struct HotModel {
   int terrain_type, ng, sem_max_hull_contacts, terrain_walls;
 };
 template <class TP> struct FlyLds;
+template <class TP> struct AbaHandoff;
 template <class T> using gptr = const __attribute__((address_space(1))) T*;
 template <class T> __device__ __forceinline__ gptr<T> G(const T* p) { return (gptr<T>)p; }
 __device__ __forceinline__ V3 ld3(gptr<float> p) { return V3{p[0], p[1], p[2]}; }
@@ -188,7 +187,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap).  Rows are 11
   // floats apart where LDS allows: lane = body loops then hit 32 different banks (stride 10: bodies b and b + 16 collide)
   float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
-  float Isym[kHasIsym<TP> ? TP::NB : 1][21];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
+  float Isym[kHasIsym<TP> ? TP::NB : 1][kHasIsym<TP> ? 21 : 1];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
   static_assert(7 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
   __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
@@ -208,7 +207,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
   // star kernels: the 3x3 pyramid-coefficient matrix of every contact for its active rows (nn, n1, n2, 11, 22), written
   // with the active-row mask; the hybrid kernels have no LDS to spare and rebuild it from the mask
-  float c_m3[kHasCm3<TP> ? kMaxCon : 1][5];
+  float c_m3[kHasCm3<TP> ? kMaxCon : 1][kHasCm3<TP> ? 5 : 1];
   // per row index r of a 6x6 (staged once per launch): [0..10] KLane constants of the contact stiffness rows; [11..13]
   // the row's map into a body's 10-float inertia (byte offsets of columns 0-2 / 3-5, 2-bit signs + 1): see InertiaRowMap
   // [14..19]: offsets of the row's six entries inside a packed symmetric 6x6 (ints).  The launch-constant conveniences
@@ -223,6 +222,17 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // leg's nine in paired reads), bytes where LDS is what limits residency
   using cstart_t = std::conditional_t<kHasIsym<TP>, int, unsigned char>;
   cstart_t body_cstart[(TP::NB + 1 + 3) / 4 * 4];
+  // What rest body k (breadth-first slot) hands to its parent during an elimination sweep: articulated inertia (symmetric,
+  // 21) + bias wrench (6).  Tree kernels keep an array; the hybrid kernels (LDS-bound) put the first 12 on the contact
+  // wrenches and the others behind the leg -> root hand-off in T..W — both dead while an articulated-body solve runs.
+  __device__ __forceinline__ float* slot_at(int k) {
+    if constexpr (TP::kStar) {
+      constexpr int kInCw = 7 * kMaxCon / 27;
+      static_assert(TP::REST_B == 0 || (TP::REST_B - kInCw) * 27 * sizeof(float) + sizeof(AbaHandoff<TP>) <= sizeof(float) * TP::NB * 2 * row_width_tw<TP>(),
+                    "hand-off slots of the rest do not fit T..W");
+      return k < kInCw ? &c_w[0][0] + 27 * k : &T[0][0] + sizeof(AbaHandoff<TP>) / sizeof(float) + 27 * (k - kInCw);
+    } else return this->slot[k];
+  }
   int ncon, overflow, iters;
   int nwall;                            // contacts of this step that touch a terrain side face (frame id != 0)
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
@@ -366,8 +376,6 @@ template <class TP, bool FAST, bool UP, class F> __device__ __forceinline__ void
 template <class TP, int NUM>
 __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode& nd, const float* tau, bool withK, float hdamp,
                                                    const Frame& fr, const LaneRole& L, const int (&so)[6], const struct InertiaRowMap& IM, const GModel& m);
-template <class TP, int NUM>
-__device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L);
 template <class TP, int NUM, bool HOMOGENEOUS>
 __device__ __forceinline__ void rest_aba_expand(FlyLds<TP>& s, const RestNode& nd, float* x, const LaneRole& L);
 
@@ -844,6 +852,24 @@ __device__ __forceinline__ bool rest_reduced(const FlyLds<TP>& s) {
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) return __builtin_amdgcn_readfirstlane(s.reduced) != 0; }
   return false;
 }
+// Lane-strided loops over the dofs / bodies a stage has to visit: all of them — or, on the hybrid kernels while the Newton
+// loop runs on the reduced problem, root + legs only, compacted: 72 of ALL_BIOLOGICAL's 132 dofs are two passes of the wave
+// instead of three (the third for four dofs), its 49 of 69 bodies one pass instead of two.
+template <class TP, class F>
+__device__ __forceinline__ void for_dofs(const FlyLds<TP>& s, bool red, int lane, F&& f) {
+  if constexpr (TP::kStar) { if constexpr (TP::REST_V > 0) {
+    if (red) { for (int jj = lane; jj < TP::NV - TP::REST_V; jj += kWave) f(jj < 6 ? jj : jj + TP::REST_V); return; }
+  } }
+  for (int j = lane; j < s.nv(); j += kWave) f(j);
+}
+template <class TP, class F>
+__device__ __forceinline__ void for_bodies(const FlyLds<TP>& s, bool red, int lane, F&& f) {
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) {
+    if (red) { for (int bb = lane; bb < TP::NB - TP::REST_B; bb += kWave) f(bb < 1 ? 0 : bb + TP::REST_B); return; }
+  } }
+  for (int b = lane; b < s.nb(); b += kWave) f(b);
+}
+
 // restA * t  (the rest's articulated inertia applied to the root twist)
 template <class TP>
 __device__ __forceinline__ SV rest_inertia_mul(const FlyLds<TP>& s, SV t) {
@@ -908,10 +934,9 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_widt
     W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) {
-    if (TP::REST_V > 0 && red && j >= 6 && j < TP::LD0) continue;      // reduced problem: the rest's dofs are not in it
+  for_dofs(s, red, lane, [&](int j) {         // reduced problem: the rest's dofs are not in it
     emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
-  }
+  });
   WSYNC();
   }
 }
@@ -922,13 +947,12 @@ template <class TP, class Emit>
 __device__ __forceinline__ void mul_M(FlyLds<TP>& s, const float* x, const GModel& m, int lane, bool have_twists, Emit&& emit) {
   if (!have_twists) sweep_twists(s, x, s.T, m, lane);
   const bool red = rest_reduced(s);
-  for (int b = lane; b < s.nb(); b += kWave) {
-    if constexpr (TP::kStar) { if (TP::REST_B > 0 && red && b >= 1 && b < TP::LB0) continue; }
+  for_bodies(s, red, lane, [&](int b) {
     const SV tb = ldsv(s.T[b]);
     SV wb = inert_mul(s.Ib[b], tb);
     if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (red && b == 0) wb = wb + rest_inertia_mul(s, tb); } }
     stsv(s.W[b], wb);
-  }
+  });
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) { emit(j, v + s.arm[j] * x[j]); });
 }
@@ -1148,16 +1172,12 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   const bool red = rest_reduced(s);
   SUB_T0();
   if constexpr (TP::REST_B > 0) {
-    const bool rest_K = withK && s.body_cstart[TP::LB0] > s.body_cstart[1];     // contact stiffness on a rest body
-    const bool reuse = s.rest_fact_valid != 0 && s.rest_fact_hdamp == hdamp && !rest_K;
-    if (red) {}
-    else if (reuse) {
-      if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 3>(s, nd, tau, L); });
-      else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate_reuse<TP, 0>(s, nd, tau, L); });
-    } else {
+    // (Round 1 re-used the rest's matrix factors from the smooth solve in the Newton solves.  Since the reduced problem
+    // the Newton loop visits the rest only when one of its bodies is in contact — and then the factors change with the
+    // contact stiffness — so every visit is a full elimination and nothing but `fact` outlives a solve.)
+    if (!red) {
       if (m.rest_fast) rest_levels<TP, true, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 3>(s, nd, tau, withK, hdamp, fr, L, so, IM, m); });
       else rest_levels<TP, false, true>(s, lane, [&](const auto& nd) { rest_aba_eliminate<TP, 0>(s, nd, tau, withK, hdamp, fr, L, so, IM, m); });
-      if (lane == 0) { s.rest_fact_valid = rest_K ? 0 : 1; s.rest_fact_hdamp = hdamp; }
       WSYNC();
     }
   }
@@ -1222,14 +1242,22 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       if (red) {
 #pragma unroll
         for (int i = 0; i < 6; i++) row[i] += s.restA[so[i]];
-      } else
-      for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
-        const float* sl = s.slot[k - 1];               // hybrid: slots in breadth-first order
-        { float v[6];
+      } else {
+        // the smooth solve's factors give the reduced constraint problem its root term: the articulated inertia the rest's
+        // children of the root hand over (restA), summed here while the slots are alive
+        if (!withK && hdamp == 0.f && lane < 21) {
+          float a = 0.f;
+          for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a += s.slot_at(k - 1)[lane];
+          s.restA[lane] = a;
+        }
+        for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) {
+          const float* sl = s.slot_at(k - 1);               // hybrid: slots in breadth-first order
+          { float v[6];
 #pragma unroll
-          for (int i = 0; i < 6; i++) v[i] = sl[so[i]];
-          add6(row, v); }
-        pA += sl[21 + L.rr];
+            for (int i = 0; i < 6; i++) v[i] = sl[so[i]];
+            add6(row, v); }
+          pA += sl[21 + L.rr];
+        }
       }
     }
 #pragma unroll
@@ -1428,10 +1456,9 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     s.W[0][lane] = a0;
   }
   WSYNC();
-  for (int j = lane; j < TP::NV; j += kWave) {
-    if (TP::REST_V > 0 && red && j >= 6 && j < TP::LD0) continue;
+  for_dofs(s, red, lane, [&](int j) {
     emit(j, dot(ldsv(s.S[j]), ldsv(s.W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
-  }
+  });
   WSYNC();
   }
 }
@@ -1461,7 +1488,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // keep them: recomputing costs those 2 %)
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
-  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) { s.rest_fact_valid = 0; s.reduced = 0; } } }   // new configuration: new factors
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) s.reduced = 0; } }
   stage_kinematics(s, m, lane);
   STAGE(1);
   stage_inertia(s, m, lane);
@@ -1659,12 +1686,7 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) {
       red = s.body_cstart[TP::LB0] == s.body_cstart[1];
       red = __builtin_amdgcn_readfirstlane(red ? 1 : 0) != 0;
-      if (red) {
-        if (lane < 21) {
-          float a = 0.f;
-          for (int k = (int)s.t_cstart[0]; k < (int)s.t_cstart[0] + (int)s.t_ccount[0]; ++k) a += s.slot[k - 1][lane];
-          s.restA[lane] = a;
-        }
+      if (red) {       // (restA: left by the smooth solve, aba_solve)
         for (int j = lane; j < TP::NV; j += kWave) {
           const bool rest = j >= 6 && j < TP::LD0;
           search[j] = rest ? 0.f : s.qacc[j] - s.qacc_smooth[j];
@@ -1747,15 +1769,14 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       // g1 = search·(M qacc − qfrc_smooth) = search·grad + (J search)·f ;  g2 = search·M·search as twice the kinetic
       // energy of the twists the ABA left in T (a sum of positive terms).  W keeps I_b T_b for the update sweep.
       float g1 = 0.f, g2 = 0.f;
-      for (int j = lane; j < s.nv(); j += kWave) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; }
-      for (int b = lane; b < s.nb(); b += kWave) {
-        if constexpr (TP::kStar) { if (TP::REST_B > 0 && red && b >= 1 && b < TP::LB0) continue; }
+      for_dofs(s, red, lane, [&](int j) { const float sj = search[j]; g1 -= sj * rhs[j]; g2 += s.arm[j] * sj * sj; });
+      for_bodies(s, red, lane, [&](int b) {
         const SV tb = ldsv(s.T[b]);
         SV wb = inert_mul(s.Ib[b], tb);
         if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (red && b == 0) wb = wb + rest_inertia_mul(s, tb); } }
         stsv(s.W[b], wb);
         g2 += dot(tb, wb);
-      }
+      });
       // the rows' part of the line search's first evaluation (alpha = 0) rides the same reduction round as g1, g2: the
       // four wave sums interleave, and the search starts one dependent round later than it would otherwise
       float q1 = 0.f, q2 = 0.f;

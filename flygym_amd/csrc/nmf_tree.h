@@ -194,7 +194,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
   float pA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int c0 = (int)s.t_cstart[b], c1 = c0 + (int)s.t_ccount[b];
   for (int k = c0; k < c1; ++k) {
-    const float* sl = s.slot[(int)s.t_body[k] - TP::kSlot0];
+    const float* sl = s.slot_at((int)s.t_body[k] - TP::kSlot0);
 #pragma unroll
     for (int i = 0; i < 21; ++i) IA.v[i] += sl[i];
 #pragma unroll
@@ -242,7 +242,7 @@ __device__ __forceinline__ void tree_aba_eliminate_body(FlyLds<TP>& s, int b, co
     for (int i = 0; i < 6; ++i) pA[i] += U[i] * ku;
   }
   if (b >= TP::kSlot0) {
-    float* sl = s.slot[b - TP::kSlot0];
+    float* sl = s.slot_at(b - TP::kSlot0);
 #pragma unroll
     for (int i = 0; i < 21; ++i) sl[i] = IA.v[i];
 #pragma unroll
@@ -336,7 +336,7 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
   }
   float pA = 0.f;
   for (int k = nd.cstart - 1; k < nd.cstart - 1 + nd.ccount; ++k) {
-    const float* sl = s.slot[k];
+    const float* sl = s.slot_at(k);
     { float v[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) v[c] = sl[so[c]];
@@ -374,44 +374,11 @@ __device__ __forceinline__ void rest_aba_eliminate(FlyLds<TP>& s, const RestNode
     }
   }
   if (L.r < 6) {
-    float* sl = s.slot[nd.k - 1];
+    float* sl = s.slot_at(nd.k - 1);
 #pragma unroll
     for (int c = 0; c < 6; ++c) if (c >= L.rr) sl[so[c]] = row[c];
     sl[21 + L.rr] = pA;
   }
-}
-
-// vector part only, over factors kept from a full elimination of the same matrix
-template <class TP, int NUM>
-__device__ __forceinline__ void rest_aba_eliminate_reuse(FlyLds<TP>& s, const RestNode& nd, const float* tau, const LaneRole& L) {
-  const int num = NUM > 0 ? NUM : (int)s.t_dofnum[nd.b];
-  float sown[NUM > 0 ? NUM : 1], Uj[NUM > 0 ? NUM : 1], invD[NUM > 0 ? NUM : 1], tj[NUM > 0 ? NUM : 1];
-  if constexpr (NUM > 0) {
-#pragma unroll
-    for (int d = 0; d < NUM; ++d) {
-      const int j = nd.adr + d;
-      const float* f = s.fact[j - TP::kFact0];
-      sown[d] = L.mask * s.S[j][L.rr]; Uj[d] = f[L.rr]; invD[d] = f[7]; tj[d] = tau[j];
-    }
-  }
-  float pA = 0.f;
-  for (int k = nd.cstart - 1; k < nd.cstart - 1 + nd.ccount; ++k) pA += s.slot[k][21 + L.rr];
-  if constexpr (NUM > 0) {
-    static_for<NUM>([&](auto I) {
-      constexpr int d = NUM - 1 - decltype(I)::value;
-      const float u = tj[d] - grp8_sum(sown[d] * pA);
-      if (L.r == 0) s.fact[nd.adr + d - TP::kFact0][6] = u;
-      pA += Uj[d] * (u * invD[d]);
-    });
-  } else {
-    for (int j = nd.adr + num - 1; j >= nd.adr; --j) {
-      float* f = s.fact[j - TP::kFact0];
-      const float u = tau[j] - grp8_sum(L.mask * s.S[j][L.rr] * pA);
-      if (L.r == 0) f[6] = u;
-      pA += f[L.rr] * (u * f[7]);
-    }
-  }
-  if (L.r < 6) s.slot[nd.k - 1][21 + L.rr] = pA;
 }
 
 // back-substitution of a body given its parent's acceleration in T; HOMOGENEOUS: no force on the subtree, the dofs'
