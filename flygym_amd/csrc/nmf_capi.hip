@@ -93,11 +93,13 @@ struct nmf_batch {
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
-  // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = costliest (default) | inorder | none
-  // (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
-  // faster, the other re-tried every 32nd launch — with chunked launches costliest-first wins everywhere: 20-step CPG
-  // launches 43.1 vs 42.5 M env-steps/s, replay 45.9 vs 45.0 M)
-  int order_policy = 1;          // 1 costliest first (default), 0 in order, 2 none, -1 the measured policy of rounds 1-2
+  // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = auto (default) | costliest | inorder |
+  // none (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
+  // faster, the other re-tried every 32nd launch).  auto = costliest first for launches of up to 64 steps — the cost of the
+  // previous launch predicts this one's (20-step CPG launches 43.1 vs 42.5 M env-steps/s, replay 45.9 vs 45.0 M; 50-step
+  // 44.7 vs 44.5 M) — and the measured policy for longer ones, whose costs are a third of a gait cycle stale (250-step
+  // launches: 43.7 M costliest first, 45.6 M measured policy)
+  int order_policy = 3;          // 3 auto (default), 1 costliest first, 0 in order, 2 none, -1 the measured policy of rounds 1-2
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
   double chunk_div = 2.0;
 };
@@ -260,10 +262,10 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   // more worlds than resident waves: the launch runs in rounds; the measured policy picks the world order (nmf_order_kernel)
   b->st.order = nullptr; b->st.sched = nullptr;
   if (oversub && b->order_buf && b->sched_buf && b->order_policy != 2) {
-    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps,
-                       b->order_policy);
+    const int policy = b->order_policy == 3 ? (n_steps <= 64 ? 1 : -1) : b->order_policy;
+    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps, policy);
     b->st.order = b->order_buf;
-    if (b->order_policy < 0) b->st.sched = b->sched_buf;
+    if (policy < 0) b->st.sched = b->sched_buf;
   }
   const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
@@ -489,7 +491,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     if (const char* e = getenv("NMF_SCHED")) { if (std::string(e) == "plain") b->chunking = false; }
     if (const char* e = getenv("NMF_ORDER")) {
       const std::string v(e);
-      b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 1;
+      b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 3;
     }
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));

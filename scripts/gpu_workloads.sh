@@ -17,7 +17,9 @@ timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 --worlds-per-gpu 128 2>/
 timeout 300 $B --joint-preset legs_active_only 2>/dev/null | line "legs_active_only"
 timeout 300 $B --joint-preset all_biological 2>/dev/null | line "all_biological"
 timeout 300 $B --steps-per-launch 250 2>/dev/null | line "cpg 250-step launches"
-timeout 300 python scripts/bench_vision.py 2>/dev/null | tail -1 | cut -c1-400
-timeout 300 python scripts/bench_vision.py --render 2>/dev/null | tail -1 | cut -c1-400
+timeout 300 $B --steps 20 --warmup 5 2>/dev/null | line "cpg 20-step launches (driver args)"
+timeout 300 $B --workload replay --steps 20 --warmup 5 2>/dev/null | line "replay 20-step launches"
+timeout 300 $B --vision resample --steps 200 2>/dev/null | line "config 3, vision resample"
+timeout 300 $B --vision render --steps 200 2>/dev/null | line "config 3, vision render"
 } > gpurun_out/workloads.log 2>&1
 cat gpurun_out/workloads.log
