@@ -34,7 +34,7 @@ sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 sim.step(500); torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 28)()
 L.nmf_debug_stage_cycles(buf, 28, 1)
-steps = 500
+steps = next((int(a.split('=')[1]) for a in sys.argv if a.startswith('--steps=')), 500)
 sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
 L.nmf_debug_stage_cycles(buf, 28, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
