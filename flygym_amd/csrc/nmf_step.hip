@@ -35,7 +35,7 @@ constexpr float kNoiseFactor = 8.f;
 // Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
 // -DNMF_STAGE_PROFILE into a separate diagnostic library; the product build has no trace of it.
 #ifdef NMF_STAGE_PROFILE
-#define NMF_NSTAGE 28
+#define NMF_NSTAGE 36
 __device__ unsigned long long g_stage_cycles[NMF_NSTAGE];
 struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_INIT() __shared__ unsigned long long stage_acc_[NMF_NSTAGE]; StageClock sc_; sc_.acc = stage_acc_; \
@@ -48,7 +48,11 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define SUB_T0() unsigned long long sub_t_ = clock64()
 #define SUB(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sub_t_; sub_t_ = clock64(); } } while (0)
 #define SUB_COUNT(k, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stage_cycles[k] += (unsigned long long)(n); } while (0)
+#define SUBH_T0() unsigned long long subh_t_ = clock64()
+#define SUBH(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - subh_t_; subh_t_ = clock64(); } } while (0)
 #else
+#define SUBH_T0()
+#define SUBH(k)
 #define SUB_T0()
 #define SUB(k)
 #define SUB_COUNT(k, n)
@@ -524,6 +528,7 @@ __device__ __forceinline__ float terrain_height(int terrain_type, const float* p
 // Bounds (x_lo, x_hi, y_lo, y_hi) of a constant-height cell; +-kFar where the lattice does not divide that axis.
 constexpr float kFar = 1e30f;
 constexpr float kProbeEps = 1e-4f;
+constexpr float kOneCell = 0.02f;     // clearance [mm] of a footprint from its cell's boundary for the one-cell paths of the collision stage
 // Height and bounds of the cell that holds (x, y) in one go (the same expressions as terrain_height and the oracle's
 // cell_bounds: the lattice indices are shared)
 __device__ __forceinline__ float terrain_cell_kind(int kind, float p0, float p1, float p2, float x, float y, float* b) {
@@ -567,14 +572,22 @@ __device__ __forceinline__ void terrain_probe(int terrain_type, const float* p, 
   if (!walls) return;
   const float delta[4] = {b[1] - x, x - b[0], b[3] - y, y - b[2]};
   if (zb >= h0 && fminf(fminf(delta[0], delta[1]), fminf(delta[2], delta[3])) - rho > reach) return;
+  // The neighbour across boundary e matters only if its face is within reach of the probe, or — for a probe inside its
+  // own cell's box — if that boundary is nearer than the way out through the top: the others are never looked up (a
+  // lattice evaluation each; a hull vertex next to one edge of its cell needs one of the four).  A face further than
+  // `reach` is reported as no face at all (dwall = kFar): no caller uses a larger distance.
+  const float pen0 = h0 - zb;
   float he[4];
-  he[0] = b[1] < kFar ? terrain_height(terrain_type, p, b[1] + kProbeEps, y) : h0;
-  he[1] = b[0] > -kFar ? terrain_height(terrain_type, p, b[0] - kProbeEps, y) : h0;
-  he[2] = b[3] < kFar ? terrain_height(terrain_type, p, x, b[3] + kProbeEps) : h0;
-  he[3] = b[2] > -kFar ? terrain_height(terrain_type, p, x, b[2] - kProbeEps) : h0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    he[e] = h0;
+    if (delta[e] < kFar && (delta[e] - rho <= reach || (zb < h0 && delta[e] + rho < pen0)))
+      he[e] = e == 0 ? terrain_height(terrain_type, p, b[1] + kProbeEps, y) : e == 1 ? terrain_height(terrain_type, p, b[0] - kProbeEps, y)
+            : e == 2 ? terrain_height(terrain_type, p, x, b[3] + kProbeEps) : terrain_height(terrain_type, p, x, b[2] - kProbeEps);
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e)          // side faces that look at the probe (codes 2, 1, 4, 3: the face's normal is -e)
-    if (delta[e] < kFar && he[e] > zb && delta[e] - rho < dwall) { dwall = delta[e] - rho; wall = (e ^ 1) + 1; }
+    if (delta[e] - rho <= reach && he[e] > zb && delta[e] - rho < dwall) { dwall = delta[e] - rho; wall = (e ^ 1) + 1; }
   if (zb >= h0) return;
   float pen = h0 - zb; int code = 0;   // inside its own cell's box: the ways out (codes 1..4: the normal is +e)
 #pragma unroll
@@ -604,6 +617,14 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   static_assert(kSlotInTW || 3 * (TP::NB - 1) + 2 * kWave <= 7 * kMaxCon, "slot table (128 geoms) does not fit");
   int* geom_slot0 = kSlotInTW ? reinterpret_cast<int*>(&s.T[0][0]) + sizeof(CollisionScratch) / sizeof(int)
                               : reinterpret_cast<int*>(&s.c_w[0][0]) + 3 * (TP::NB - 1);
+  // terrains: the vertices of the hull being scanned that lie within the margin (index, distance), in index order — what
+  // is left of T..W behind the scratch (and the slot table) holds kCand of them
+  constexpr int kTwUsed = (int)sizeof(CollisionScratch) + (kSlotInTW ? 2 * kWave * (int)sizeof(int) : 0);
+  constexpr int kCandRoom = ((int)sizeof(float) * TP::NB * 12 - kTwUsed) / 8;
+  constexpr int kCand = kCandRoom > kWave ? kWave : kCandRoom;
+  constexpr bool kListed = ROUGH && kCand >= 8;
+  int* cand_idx = reinterpret_cast<int*>(&s.T[0][0]) + kTwUsed / 4;
+  float* cand_d = reinterpret_cast<float*>(cand_idx + (kCand > 0 ? kCand : 0));
   // the model's side of this stage, staged in LDS at launch (see HotModel): scalars once, arrays as global memory
   const HotModel hm = hot_model(s, m);
   const int ng = hm.ng, terrain_type = hm.terrain_type, max_hull_contacts = hm.sem_max_hull_contacts;
@@ -631,6 +652,10 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   // the two face contacts and the frame ids of all four (3 bits each) live here
   float cdw0 = 0.f, cdw1 = 0.f; V3 cpw0 = v3(0, 0, 0), cpw1 = v3(0, 0, 0); int cfid = 0, cntw = 0;
   bool near = false;
+  // terrains: g_ttop = the highest cell top under the geom's footprint (bounding sphere + margin); one_cell: the footprint
+  // lies inside ONE cell, further than kOneCell from its boundary — no vertex of it can meet a side face, and all of
+  // them see the same top, g_ttop
+  bool one_cell = false; float g_ttop = 0.f;
   if (gi < ng) {
     g_body = geom_body[gi]; g_type = geom_type[gi]; g_margin = pair_margin[gi];
     g_hadr = geom_hulladr[gi]; g_hnum = geom_hullnum[gi];
@@ -645,14 +670,24 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     // 3 x 3 sample of the height map at the centre +- radius is conservative (every cell is wider than a geom's radius).
     // Against the global maximum every leg segment dangling in a 2 mm gap passed the cull: 21 hull scans per step on the
     // gapped world instead of 4.
+    // The cell under the centre comes first: most footprints lie inside it (cells are 1 mm and more, a leg segment's
+    // radius 0.1-0.3 mm) and need neither the other eight samples nor, later, a terrain probe per hull vertex.
     float ttop = terrain_top;
     if (rough) {
-      ttop = -kFar;
+      // (the footprint is widened by the margin: a face within the margin of a vertex belongs to a cell it touches)
+      const float cx = cw.x + xp.x, cy = cw.y + xp.y, fr = bs_r + g_margin;
+      float cb[4];
+      ttop = terrain_cell(terrain_type, tpar, cx, cy, cb);
+      const float clear = fminf(fminf(cb[1] - cx, cx - cb[0]), fminf(cb[3] - cy, cy - cb[2])) - fr;
+      one_cell = clear > kOneCell;
+      if (!(clear > 0.f)) {
 #pragma unroll
-      for (int a = -1; a <= 1; ++a)
+        for (int a = -1; a <= 1; ++a)
 #pragma unroll
-        for (int bb = -1; bb <= 1; ++bb)
-          ttop = fmaxf(ttop, terrain_height(terrain_type, tpar, cw.x + xp.x + (float)a * bs_r, cw.y + xp.y + (float)bb * bs_r));
+          for (int bb = -1; bb <= 1; ++bb)
+            if (a != 0 || bb != 0) ttop = fmaxf(ttop, terrain_height(terrain_type, tpar, cx + (float)a * fr, cy + (float)bb * fr));
+      }
+      g_ttop = ttop;
     }
     near = dc - bs_r - ttop <= g_margin;
     const V3 p0 = mat_vec(R, l0) + xp, p1 = mat_vec(R, l1) + xp;
@@ -660,12 +695,23 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     float d0 = z0 - rad, d1 = z1 - rad;
     // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's
     // reach but above its own thickness needs no vertex scan
-    if (g_type == GEOM_HULL) near = near && fminf(d0, d1) - ttop <= g_margin;
+    // (capsules: its end spheres; over a terrain nothing above the highest top under the footprint needs a probe)
+    if (g_type == GEOM_HULL) {
+      // the cylinder's lowest point: the lower end disc's rim, rad * sin(axis, normal) below its centre (a steep tibia or
+      // femur stays clear of the ground by far more than its end's height minus its radius says)
+      const V3 ax = p1 - p0;
+      const float ca = dot(n, ax);
+      const float sn = sqrtf(fmaxf(0.f, 1.f - ca * ca / fmaxf(dot(ax, ax), 1e-12f)) + 4e-6f);
+      near = near && fminf(z0, z1) - rad * fminf(sn, 1.f) - ttop <= g_margin;
+    } else if (rough) near = near && fminf(d0, d1) - ttop <= g_margin;
     if (near && g_type == GEOM_CAPSULE) {
       float dw0 = kFar, dw1 = kFar; int w0 = 0, w1 = 0;
       if (rough) {
-        terrain_probe(terrain_type, tpar, walls, p0.x, p0.y, z0, rad, g_margin, d0, dw0, w0);
-        terrain_probe(terrain_type, tpar, walls, p1.x, p1.y, z1, rad, g_margin, d1, dw1, w1);
+        if (one_cell && fminf(d0, d1) - g_ttop >= -kOneCell) { d0 -= g_ttop; d1 -= g_ttop; }      // what the probes would return
+        else {
+          terrain_probe(terrain_type, tpar, walls, p0.x, p0.y, z0, rad, g_margin, d0, dw0, w0);
+          terrain_probe(terrain_type, tpar, walls, p1.x, p1.y, z1, rad, g_margin, d1, dw1, w1);
+        }
       }
       const V3 q0 = ((p0 - rad * n) - (0.5f * d0) * n) - o, q1 = ((p1 - rad * n) - (0.5f * d1) * n) - o;
       if (d0 <= g_margin) { cd0 = d0; cp0 = q0; cnt = 1; }
@@ -685,8 +731,10 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
   // few patch candidates over through LDS — same rate on flat ground, where the tarsal capsules make the contacts, and
   // 3-8 % slower over relief: six slots per lane whatever the hull's size, and 40 more callee-saved registers)
   unsigned long long hmask = __ballot(near && g_type == GEOM_HULL);
+  const unsigned long long one_mask = __ballot(one_cell);
   SUB_COUNT(24, __popcll(hmask));
   while (hmask) {
+    SUBH_T0();
     const int g = __ffsll((long long)hmask) - 1;
     hmask &= hmask - 1;
     const int b = __builtin_amdgcn_readlane(g_body, g);
@@ -699,17 +747,36 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     const float c0 = dot(n, xp) - pd;
     // distance of a hull vertex to the ground under it (flat ground: the plane distance; terrains: the top of its cell, or
     // kFar when a side face owns the vertex — terrain_probe)
+    // A hull inside one cell (above): every vertex is further than kOneCell from the cell's boundary, so terrain_probe
+    // would return (height over the plane) - (the cell's top) and no face for each of them — as long as none is deeper
+    // than kOneCell inside the box (then a way out sideways could be nearer than the top: checked after the first scan,
+    // which is repeated with the probe if so).  Same values, without a probe per vertex.  Any other hull: a vertex more
+    // than the margin above the highest top under the hull's footprint touches neither a top nor a face (a face looks
+    // at it only from a higher cell) — it needs no probe either, and its height over that top, a lower bound of its
+    // distance, keeps it out of every selection.
     float pdw = kFar; int pw_code = 0;          // side face of the vertex probed last
+    bool one = rough && ((one_mask >> g) & 1ull);
+    const float h_top = rough ? readlane_f(g_ttop, g) : 0.f;
     auto vdist = [&](V3 v) {
       float di = dot(nb, v) + c0;
-      if (rough) { const V3 pw = mat_vec(R, v) + xp; terrain_probe(terrain_type, tpar, walls, pw.x, pw.y, di, 0.f, margin, di, pdw, pw_code); }
+      if (rough) {
+        pw_code = 0;
+        if (one || di - h_top > margin) di = di - h_top;
+        else { const V3 pw = mat_vec(R, v) + xp; terrain_probe(terrain_type, tpar, walls, pw.x, pw.y, di, 0.f, margin, di, pdw, pw_code); }
+      }
       return di;
     };
     // scan 1 — the deepest vertex — is all most near hulls ever get (a tarsal segment next to the one in contact: its
     // bounding cylinder reaches the margin, its vertices do not), and a plain loop pays one memory round trip per 64
     // vertices: the loads of four passes are issued together (indices clamped, results of the overhang ignored)
+    SUBH(28);
     float best = INFINITY; int bi = 0x7fffffff;
     float bestw = INFINITY; int biw = 0x7fffffff;        // the vertex nearest to (deepest in) a side face: index * 8 + face code
+    // (terrains: the vertices within the margin are compacted into a list on the way, in index order — the patch scans
+    // then run over that list, lane = candidate)
+    int ncand = 0;
+    for (;;) {
+    best = INFINITY; bi = 0x7fffffff; ncand = 0;
     for (int base = lane; base < nvv + lane; base += 4 * kWave) {
       V3 hv[4];
 #pragma unroll
@@ -717,25 +784,75 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = base + k * kWave;
+        bool c = false; float di = 0.f;
         if (i < nvv) {
-          const float di = vdist(hv[k]);
+          di = vdist(hv[k]);
           if (di < best) { best = di; bi = i; }
           if (rough && pw_code && pdw < bestw) { bestw = pdw; biw = i * 8 + pw_code; }
+          c = di <= margin;
+        }
+        if constexpr (kListed) {
+          const unsigned long long cm = __ballot(c);
+          const int pos = ncand + __popcll(cm & ((1ull << lane) - 1ull));
+          if (c && pos < kCand) { cand_idx[pos] = i; cand_d[pos] = di; }
+          ncand += __popcll(cm);
         }
       }
     }
     wave_argmin(best, bi);
+    if (rough && one && !(best >= -kOneCell)) { one = false; continue; }
+    break;
+    }
     const float dmin = best; const int ia = bi;
     bool face = false;
     if (rough && walls) { wave_argmin(bestw, biw); face = bestw <= margin; }
+    SUBH(29); SUB_COUNT(32, one ? 1 : 0); SUB_COUNT(33, nvv);
     if (!(dmin <= margin) && !face) { SUB_COUNT(25, 1); SUB_COUNT(26, (unsigned long long)(fminf(dmin, 1.f) * 1e6f)); continue; }
     SUB_COUNT(27, 1);
     int nsel = 0;
     int s1 = -1, s2 = -1, s3 = -1;
+    [[maybe_unused]] int listed_dbg = 0;
     if (dmin <= margin) {
     nsel = 1;
     const float thr = fminf(dmin + hull_skin, margin);
     const V3 va = ld3(V + 3 * ia);
+    bool listed = false;
+    if constexpr (kListed) listed = ncand <= kCand;
+    listed_dbg = listed ? 1 : 0;
+    if (listed) {
+      // terrains: the patch scans run over the listed vertices, lane = candidate — the same selections (same expressions,
+      // lowest index among ties) without another pass over the hull's vertices, i.e. without three memory round trips
+      // per scan and a terrain probe per vertex
+      if constexpr (kListed) {
+        WSYNC();
+        const bool have = lane < ncand;
+        const int ci = have ? cand_idx[lane] : 0;
+        const bool ok = have && !(cand_d[have ? lane : 0] > thr);
+        const V3 vi = ld3(V + 3 * ci);
+        auto pick = [&](int idx) {      // coordinates of candidate vertex idx, from the lane that holds it
+          const int wl = __ffsll((long long)__ballot(ok && ci == idx)) - 1;
+          return v3(readlane_f(vi.x, wl), readlane_f(vi.y, wl), readlane_f(vi.z, wl));
+        };
+        { const V3 e = vi - va; best = ok ? dot(e, e) : -INFINITY; bi = ok ? ci : 0x7fffffff; }
+        wave_argmax(best, bi);
+        if (best > 1e-10f) {
+          s1 = bi; nsel = 2;
+          const V3 ab = pick(bi) - va;
+          const float lab2 = dot(ab, ab);
+          { const V3 cr = cross(vi - va, ab); best = ok ? dot(cr, cr) : -INFINITY; bi = ok ? ci : 0x7fffffff; }
+          wave_argmax(best, bi);
+          if (best > 1e-10f * lab2) {
+            s2 = bi; nsel = 3;
+            const float side = dot(cross(pick(bi) - va, ab), nb);
+            const float sg = side > 0.f ? -1.f : 1.f;
+            best = ok ? sg * dot(cross(vi - va, ab), nb) : -INFINITY; bi = ok ? ci : 0x7fffffff;
+            wave_argmax(best, bi);
+            if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
+          }
+        }
+        WSYNC();
+      }
+    } else {
     // b: farthest candidate from a
     best = -INFINITY; bi = 0x7fffffff;
     for (int i = lane; i < nvv; i += kWave) {
@@ -775,8 +892,10 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
         if (best > sqrtf(1e-10f * lab2)) { s3 = bi; nsel = 4; }
       }
     }
+    }
     nsel = nsel < max_hull_contacts ? nsel : max_hull_contacts;
     }   // a vertex within the margin of the top of its cell
+    SUBH(30); SUB_COUNT(34, listed_dbg);
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
@@ -797,6 +916,7 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     nsel += face ? 1 : 0;
     if (lane == g) cnt = nsel;
     nh += nsel;
+    SUBH(31);
   }
   SUB(22);
   // ---- phase 3: contact slots in geom order.  cnt <= 4, so an exclusive prefix over lanes is three ballots.

@@ -32,16 +32,17 @@ table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_wor
 ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
 sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 sim.step(500); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 28)()
-L.nmf_debug_stage_cycles(buf, 28, 1)
+buf = (ctypes.c_ulonglong * 36)()
+L.nmf_debug_stage_cycles(buf, 36, 1)
 steps = next((int(a.split('=')[1]) for a in sys.argv if a.startswith('--steps=')), 500)
 sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
-L.nmf_debug_stage_cycles(buf, 28, 1)
+L.nmf_debug_stage_cycles(buf, 36, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
          "ABA smooth", "solver init + first grad", "newton: test/exit", "newton: ABA(H)", "newton: jv, g1, g2", "newton: linesearch",
          "newton: move (merged sweep)", "final forces", "integrate (ABA Euler)", "write outputs", "sensors",
          "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down",
-         "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step", "(collision) scans without a contact per step", "(collision) their summed dmin [nm]", "(collision) scans with contacts per step"]
+         "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step", "(collision) scans without a contact per step", "(collision) their summed dmin [nm]", "(collision) scans with contacts per step",
+         "(hull) setup", "(hull) first scan + argmin", "(hull) patch scans", "(hull) contact output", "(hull) one-cell hulls per step", "(hull) vertices scanned per step", "(hull) patch scans over the candidate list per step", "-"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
 tot = cyc[:18].sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
