@@ -29,28 +29,56 @@ def torch_mod():
     return torch
 
 
+def _fly(skeleton):
+    """A fly with the leg actuators and adhesion of the benchmark model on ``skeleton``: a JointPreset name, or "custom"
+    (ALL_BIOLOGICAL without wings, halteres and abdomen joints: 60 bodies, 105 dofs — the general-tree kernel)."""
+    import flygym_amd.compose as C
+    from flygym_amd import anatomy as A
+
+    fly = C.Fly(name="t")
+    if skeleton == "custom":
+        bio = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL)
+        keep = [j for j in bio.anatomical_joints if not any(k in j.child.name for k in ("wing", "haltere", "abdomen"))]
+        sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, anatomical_joints=keep)
+    else:
+        sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=getattr(A.JointPreset, skeleton))
+    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    legs = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_actuators(legs.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
+                      neutral_input=C.KinematicPosePreset.NEUTRAL)
+    fly.add_leg_adhesion()
+    return fly
+
+
 def _model(kind):
     """(fly, world) of the kernel instantiation under test."""
     import flygym_amd.compose as C
-    from flygym_amd import anatomy as A, make_model
+    from flygym_amd import make_model
     from flygym_amd.utils.math import Rotation3D
 
     if kind in ("legs_only", "legs_active_only", "all_biological"):
         fly, world, _ = make_model(joints_preset=kind)
         return fly, world
-    assert kind == "tethered"
-    fly = C.Fly(name="t")
-    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
-    fly.add_joints(sk, neutral_pose=C.KinematicPosePreset.NEUTRAL)
-    fly.add_actuators(sk.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0,
-                      neutral_input=C.KinematicPosePreset.NEUTRAL)
-    fly.add_leg_adhesion()
-    world = C.TetheredWorld()
-    world.add_fly(fly, (0, 0, 1.5), Rotation3D("quat", (1, 0, 0, 0)))
+    upright = Rotation3D("quat", (1, 0, 0, 0))
+    if kind == "tethered":
+        fly, world = _fly("LEGS_ONLY"), C.TetheredWorld()
+        world.add_fly(fly, (0, 0, 1.5), upright)
+        return fly, world
+    skeleton, world_cls = {"all_possible": ("ALL_POSSIBLE", "FlatGroundWorld"), "custom_tree": ("custom", "FlatGroundWorld"),
+                           "legs_only_on_blocks": ("LEGS_ONLY", "BlocksTerrainWorld"),
+                           "all_biological_on_mixed": ("ALL_BIOLOGICAL", "MixedTerrainWorld")}[kind]
+    fly, world = _fly(skeleton), getattr(C, world_cls)()
+    world.add_fly(fly, (0.3, 0.2, 0.8), upright)
     return fly, world
 
 
-@pytest.mark.parametrize("kind", ["legs_only", "legs_active_only", "all_biological", "tethered"])
+SCHEDULE_KINDS = ["legs_only", "legs_active_only", "all_biological", "tethered",
+                  # HybridTopo<20,60,6,3,3,...> (6 flies per CU), TreeTopoT<72,144> (5), and the terrain instantiations
+                  # Terrain<LEGS_ONLY> / Terrain<ALL_BIOLOGICAL> with lateral contacts against block faces
+                  "all_possible", "custom_tree", "legs_only_on_blocks", "all_biological_on_mixed"]
+
+
+@pytest.mark.parametrize("kind", SCHEDULE_KINDS)
 def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
     """More worlds than resident waves: a launch is cut into (chunk, world) items pulled by persistent workgroups, and a
     world's state travels from one chunk's workgroup to the next's as data-tagged 8-byte granules (nmf_step_kernel).
@@ -65,7 +93,7 @@ def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
     fly, world = _model(kind)
     cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
     table = cpg.targets(N, 1250, device="cuda:0")
-    n50 = 47 if kind == "legs_only" else 12
+    n50 = 47 if kind == "legs_only" else 12 if kind in ("legs_active_only", "all_biological", "tethered") else 6
 
     def run(env, graphed=False):
         for k in ("NMF_SCHED", "NMF_ORDER", "NMF_MAX_CHUNKS"):
@@ -114,6 +142,8 @@ def test_launch_schedules_are_bitwise_identical(torch_mod, kind, monkeypatch):
     else:
         assert float(plain["stats_sum"][:, 1].float().mean()) > 1000          # contact-rich walking
         assert len(torch.unique(plain["qpos"][:, 0])) > 1000                  # the worlds really differ (phase offsets)
+    if "_on_" in kind:                                                        # lateral contacts happened (frame ids 1..4)
+        assert int(plain["stats_sum"][:, 3].max()) == 0                       # and the 48-contact cap was never hit
 
 
 def test_all_biological_batch_follows_the_oracle(torch_mod, oracle_lib):
@@ -388,3 +418,61 @@ def test_terrain_side_faces_on_the_kernel(torch_mod, oracle_lib):
         assert np.abs(qacc[w] - ref["f64"].arr("qacc")).max() < 2e-3 * scale, f"state {w}"
         faces += int((ref["f64"].arr("con_frame").reshape(-1, 9)[:, 2] == 0).sum())
     assert faces >= n // 2          # (a state is the one AFTER the step in which the oracle touched a face: most still do)
+
+
+@pytest.mark.parametrize("skeleton,world_cls", [("ALL_BIOLOGICAL", "BlocksTerrainWorld"), ("custom", "GappedTerrainWorld"),
+                                                ("LEGS_ACTIVE_ONLY", "MixedTerrainWorld")])
+def test_terrain_kernels_of_the_other_skeletons(torch_mod, oracle_lib, skeleton, world_cls):
+    """``Terrain<TP>`` is instantiated for every topology; tests/test_hip_parity.py walks the LEGS_ONLY one.  Here the
+    hybrid kernel (ALL_BIOLOGICAL), the general-tree kernel (custom skeleton) and the 48-dof star kernel drop onto a box
+    terrain and walk across it against the float64 oracle in re-synchronised segments with every miss classified
+    (tests/resync.py), and one step from each contact-rich synchronisation point is compared contact list by contact list."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+    from resync import Resync
+
+    fly = _fly(skeleton)
+    world = getattr(C, world_cls)()
+    world.add_fly(fly, (0.3, 0.2, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    n = 3
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    blob = sim.model.to_blob()
+    o, o32 = oracle_lib.Oracle(blob, "f64"), oracle_lib.Oracle(blob, "f32")
+    nu = sim.model.nu
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    for orc in (o, o32):
+        orc.ctrl[nu - 6:] = 1.0
+    order = fly.get_actuated_jointdofs_order(C.ActuatorType.POSITION)
+    table = TripodCPG(order, 1e-4).targets(1, 2500)
+    tdev = torch.as_tensor(np.repeat(table, n, axis=0), device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    ids_np = ids.cpu().numpy()
+    rs = Resync(sim, torch, oracle_lib, o, o32, tol=2e-5)
+    exact = 0
+    for k in range(20):                                    # the drop onto the terrain and settling
+        rs.segment(20, lambda i: sim.step(1), lambda orc, i: orc.step(1), label=f"drop {k}")
+    for k in range(10):                                    # CPG walking across it
+        rs.segment(20, lambda i, k=k: sim.step_replay(tdev, ids, 20 * k + i, 1),
+                   lambda orc, i, k=k: orc.step_replay(table[0], ids_np, 20 * k + i, 1), label=f"walk {k}")
+        # one step from the synchronisation point (the engine holds the float64 oracle's state rounded to float32)
+        r = oracle_lib.Oracle(blob, "f32")
+        for name in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+            r.arr(name)[:] = o.arr(name)
+            sim.field(name)[:] = torch.as_tensor(np.asarray(o.arr(name)), dtype=torch.float32, device=sim.device)
+        sim.step_replay(tdev, ids, 20 * (k + 1), 1); r.step_replay(table[0], ids_np, 20 * (k + 1), 1)
+        nc = int(sim.field("stats")[0, 0].item())
+        if nc == r.ints()["ncon"] and sim.field("contact_geom")[0, :nc].cpu().numpy().astype(int).tolist() == r.ints()["con_geom"]:
+            exact += 1
+            qa, ref = sim.field("qacc")[0].cpu().numpy(), r.arr("qacc")
+            assert np.abs(qa - ref).max() < 2e-3 * max(np.abs(ref).max(), 1e4), f"{skeleton} on {world_cls}, tick {k}"
+        for name in ("qpos", "qvel", "ctrl", "qacc_warmstart"):      # back to the synchronised state for the next segment
+            sim.field(name)[:] = torch.as_tensor(np.asarray(o.arr(name)), dtype=torch.float32, device=sim.device)
+    kinds = rs.summary()
+    assert not rs.violations, f"{skeleton} on {world_cls}: {kinds}\n" + "\n".join(rs.violations)
+    assert kinds["rounding"] >= 0.8 * len(rs.records), f"{kinds}"
+    assert exact >= 8, f"contact lists equal to the float32 oracle's in only {exact} of 10 single steps"
+    assert max(r["ncon_end"] for r in rs.records) >= 3 and np.isfinite(sim.field("qpos").cpu().numpy()).all()
+    assert torch.equal(sim.field("qpos")[0], sim.field("qpos")[n - 1])
