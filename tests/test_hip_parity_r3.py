@@ -476,3 +476,47 @@ def test_terrain_kernels_of_the_other_skeletons(torch_mod, oracle_lib, skeleton,
     assert exact >= 8, f"contact lists equal to the float32 oracle's in only {exact} of 10 single steps"
     assert max(r["ncon_end"] for r in rs.records) >= 3 and np.isfinite(sim.field("qpos").cpu().numpy()).all()
     assert torch.equal(sim.field("qpos")[0], sim.field("qpos")[n - 1])
+
+
+def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
+    """tests/test_oracle_closed_form_joints.py on the HIP kernel: a hinge with spring, damper and a (clamped) position servo
+    follows the recurrence of MuJoCo's documented actuator / passive / implicit-damping Euler model step for step, and a
+    body on the tether weld the documented impedance mix a = (1 - d) a0 + d aref (general-tree kernel, WELD instantiation)."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from tiny_models import TinyWorld, hinge_on_heavy_base, welded_body
+    import test_oracle_closed_form_joints as cj
+
+    for case, c in cj.HINGE_CASES.items():
+        par = dict(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armature=1e-6, damping=0.0, stiffness=0.0, springref=0.0, kp=0.0,
+                   kv=0.0, forcerange=None, q0=0.0)
+        par.update(c["par"])
+        sim = HIPSimulation(TinyWorld(hinge_on_heavy_base(**par)), n_worlds=2, device=0)
+        n = 1500
+        inertia = par["inertia_yy"] + par["mass"] * float(np.dot(par["com"], par["com"]))
+        qs, vs, taus = cj.hinge_recurrence(n, par["q0"], 0.0, c["ctrl"], inertia, par["armature"], par["damping"], par["stiffness"],
+                                           par["springref"], par["kp"], par["kv"], par["forcerange"])
+        ctrl = torch.as_tensor(np.array([c["ctrl"](k) for k in range(n)], dtype=np.float32), device=sim.device)
+        got = torch.zeros((n, 3), device=sim.device)
+        for k in range(n):
+            sim.field("ctrl")[:, 0] = ctrl[k]
+            sim.step(1)
+            got[k, 0], got[k, 1], got[k, 2] = sim.field("qpos")[0, 7], sim.field("qvel")[0, 6], sim.field("actuator_force")[0, 0]
+        got = got.cpu().numpy().astype(np.float64)
+        assert np.abs(got[:, 0] - qs).max() < 2e-3 * np.abs(qs).max(), case
+        assert np.abs(got[:, 1] - vs).max() < 2e-3 * np.abs(vs).max(), case
+        assert np.abs(got[:, 2] - taus).max() < 2e-3 * max(np.abs(taus).max(), 1e-12), case
+        assert float((sim.field("qpos")[0, :3] - torch.tensor([0.0, 0.0, 100.0], device=sim.device)).abs().max()) < 1e-5
+
+    off = 2e-5
+    sim = HIPSimulation(TinyWorld(welded_body(offset=(0.0, 0.0, off), **cj.WELD)), n_worlds=2, device=0)
+    n = 400
+    want = cj.weld_recurrence(n, off, 0.0, cj.G)
+    got = torch.zeros(n, device=sim.device)
+    for k in range(n):
+        sim.step(1)
+        got[k] = sim.field("qpos")[0, 2]
+    got = got.cpu().numpy().astype(np.float64) - 100.0
+    assert np.abs(got - want).max() < 2e-5            # float32: the position 100 + r carries 7.6e-6 per bit
+    assert float(sim.field("qpos")[0, :2].abs().max()) < 1e-6 and float(sim.field("qpos")[0, 4:7].abs().max()) < 1e-6
+    assert int(sim.field("stats")[0, 0].item()) == 0

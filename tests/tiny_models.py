@@ -98,3 +98,46 @@ class TinyWorld:
 
     def compile_model(self):
         return self._model
+
+
+def hinge_on_heavy_base(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armature=1e-6, damping=2e-5, stiffness=0.0, springref=0.0,
+                        kp=0.0, kv=0.0, forcerange=None, q0=0.0, timestep=1e-4) -> CompiledModel:
+    """A link on a hinge (axis y through the base's origin) carried by a free base 1e9 times heavier, no gravity, no
+    contact (the base's only geom floats 100 mm over the plane): the base stays put to 1e-9, so the hinge obeys the
+    one-dof equation  (I + armature) qdd = tau_act - stiffness (q - springref) - damping qd  with
+    I = inertia_yy + mass |com|^2 (com perpendicular to the axis).  One position actuator on the hinge: force =
+    kp ctrl - kp q - kv qd, clamped to ``forcerange`` when given."""
+    base_mass = 1e9 * mass
+    m = sphere_on_plane(mass=base_mass, radius=0.1, gravity=(0.0, 0.0, 0.0), timestep=timestep, start_height=100.0)
+    f, i = (lambda *a: np.asarray(a, dtype=np.float64)), (lambda *a: np.asarray(a, dtype=np.int32))
+    big = 1e9 * (inertia_yy + mass * float(np.dot(com, com)))
+    limited = 1 if forcerange is not None else 0
+    lo, hi = forcerange if forcerange is not None else (0.0, 0.0)
+    m.update(
+        body_parent=i(-1, 0), body_dofadr=i(0, 6), body_dofnum=i(6, 1), body_pos=f([0, 0, 0], [0, 0, 0]),
+        body_quat=f([1, 0, 0, 0], [1, 0, 0, 0]), body_mass=f(base_mass, mass), body_ipos=f([0, 0, 0], list(com)),
+        body_inertia=f([big, big, big, 0, 0, 0], [inertia_yy, inertia_yy, inertia_yy, 0, 0, 0]),
+        dof_body=i(0, 0, 0, 0, 0, 0, 1), dof_parent=i(-1, 0, 1, 2, 3, 4, 5), dof_axis=f(*([[0, 0, 0]] * 6), [0, 1, 0]),
+        dof_armature=f(0, 0, 0, 0, 0, 0, armature), dof_damping=f(0, 0, 0, 0, 0, 0, damping),
+        dof_stiffness=f(0, 0, 0, 0, 0, 0, stiffness), dof_springref=f(0, 0, 0, 0, 0, 0, springref),
+        seg_body=i(0, 1), seg_pos=f([0, 0, 0], [0, 0, 0]), seg_quat=f([1, 0, 0, 0], [1, 0, 0, 0]),
+        seg_invweight0=f([1.0 / base_mass, 1.0 / big], [1.0 / mass, 1.0 / inertia_yy]),
+        act_type=i(0), act_trn=i(6), act_limited=i([limited, 0]), act_geom=i(-1), act_gain=f(kp), act_bias=f([-kp, -kv]),
+        act_forcerange=f([lo, hi]), act_ctrlrange=f([0.0, 0.0]), key_ctrl=f(0.0),
+        key_qpos=f(0, 0, 100.0, 1, 0, 0, 0, q0), qpos0=f(0, 0, 100.0, 1, 0, 0, 0, q0),
+        stat_meaninertia=f(mass),
+    )
+    return m
+
+
+def welded_body(mass=1e-3, solref=(2e-4, 1.0), solimp=(0.98, 0.99, 1e-5, 0.5, 3.0), gravity=(0.0, 0.0, -9810.0), offset=(0.0, 0.0, 0.0),
+                timestep=1e-4) -> CompiledModel:
+    """One free body held by the tether weld (TetheredWorld's six bilateral rows, with the reference's weld parameters by
+    default) to the pose (0, 0, 100) / identity, started ``offset`` away from it; no contact."""
+    m = sphere_on_plane(mass=mass, radius=0.1, gravity=gravity, timestep=timestep, start_height=100.0)
+    f, i = (lambda *a: np.asarray(a, dtype=np.float64)), (lambda *a: np.asarray(a, dtype=np.int32))
+    start = np.array([0.0, 0.0, 100.0]) + np.asarray(offset, dtype=np.float64)
+    big = 1e9 * mass
+    m.update(weld_active=i(1), weld_params=f(0.0, 0.0, 100.0, 1, 0, 0, 0, *solref, *solimp, 1.0 / mass, 1.0 / big),
+             key_qpos=f(*start, 1, 0, 0, 0), qpos0=f(*start, 1, 0, 0, 0))
+    return m
