@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--vision-every", type=int, default=20, help="physics steps per vision tick (20 = 500 Hz)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not re-run the workload under rocprofv3 --pmc after the timed region (N = 1): roofline.traffic / "
+                         ".issue then come from the committed passes under profiles/ and say so")
     ap.add_argument("--cpu-steps", type=int, default=200000)
     return ap.parse_args(argv)
 
@@ -213,6 +216,72 @@ def traffic_model(n_local, spl, args):
     if (rec.get("worlds_per_gpu"), rec.get("steps_per_launch")) == (n_local, spl):
         return rec["traffic_bytes_per_launch"], issue
     return None, issue
+
+
+LIVE_PASSES = (
+    ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+    ("sq1", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"]),
+    ("sq2", ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]),
+)
+
+
+def live_counters(spl, kernel, launches=6, budget_s=240.0, passes=None):
+    """HBM traffic and SQ issue counters of THIS command measured by THIS run (N = 1): after the timed region, rank 0
+    re-runs the same workload for a few launches under `rocprofv3 --kernel-trace --pmc ...` — FETCH_SIZE, WRITE_SIZE and
+    two SQ groups, each in its own pass as MI355X_MICROARCH.md prescribes — and reads the counter CSVs (mean over the
+    last launches of `kernel`).  Returns {counter: value per launch} or None when rocprofv3 is missing or a pass fails;
+    the caller then falls back to the committed passes of the builder (profiles/hbm_traffic.json) and says so."""
+    import csv
+    import shutil
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "already running under a profiler"
+    drop = {"--steps": 1, "--warmup": 1, "--repeats": 1, "--gpus": 1, "--steps-per-launch": 1, "--cpu-steps": 1, "--no-cpu-baseline": 0}
+    argv, skip = [], 0
+    for a in sys.argv[1:]:
+        if skip:
+            skip -= 1
+            continue
+        key = a.split("=", 1)[0]
+        if key in drop:
+            skip = drop[key] if "=" not in a else 0
+            continue
+        argv.append(a)
+    inner = [sys.executable, str(Path(__file__).resolve()), *argv, "--no-cpu-baseline", "--no-live-counters", "--steps-per-launch", str(spl),
+             "--steps", str(spl * launches), "--warmup", "0", "--repeats", "1"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    acc = {}
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="nmf_live_") as tmp:
+        for tag, ctrs in (passes or LIVE_PASSES):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "time budget of the live counter passes used up"
+            cmd = [rocprof, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", f"{tmp}/{tag}", "-o", "live", "--", *inner]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 pass {tag} timed out"
+            files = sorted(Path(tmp, tag).rglob("*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 pass {tag} failed (rc {r.returncode})"
+            by_disp = {}
+            for row in csv.DictReader(open(files[0])):
+                if kernel in row["Kernel_Name"]:
+                    by_disp.setdefault(int(row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
+            disp = [by_disp[k] for k in sorted(by_disp)][-max(1, launches - 2):]      # the inner run's timed launches
+            if not disp:
+                return None, f"no dispatch of {kernel} in pass {tag}"
+            for c in ctrs:
+                vals = [d[c] for d in disp if c in d]
+                if not vals:
+                    return None, f"counter {c} missing in pass {tag}"
+                acc[c] = float(np.mean(vals))
+    return acc, f"measured by this run: rocprofv3 --kernel-trace --pmc passes ({', '.join(t for t, _ in (passes or LIVE_PASSES))}) over {launches} launches of the same workload, {time.perf_counter() - t0:.0f} s"
 
 
 def idle_rank(args, torch, dist, device, total_worlds, shard_sizes, rank, world_size, n_ticks):
@@ -455,6 +524,26 @@ def main():
         assert args.joint_preset != "legs_only" or bytes_per_env_step == BYTES_PER_ENV_STEP
         achieved = bytes_per_env_step * n_local * spl / (ms * 1e-3) / 1e9
         traffic, issue = traffic_model(n_local, spl, args)
+        traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder, fitted per world and per step)" if traffic is not None else None
+        issue_source = "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_* passes of this command run by the builder)" if issue else None
+        live, live_note = None, ("off (--no-live-counters)" if args.no_live_counters else "N > 1: committed passes" if world_size > 1
+                                 else "vision run: the live passes go to the retina kernel (`roofline`), this block uses the committed ones")
+        if not args.no_live_counters and world_size == 1 and see is None:
+            live, live_note = live_counters(spl, "nmf_step_kernel")
+        if live:
+            # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KiB; FETCH_SIZE under-reports wide reads by 2x on
+            # gfx950 (dword-wide state loads here, so x2 is the upper bound); quad-cycle SQ counters
+            traffic = 1024.0 * (2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"])
+            traffic_source = issue_source = live_note
+            env_steps = float(n_local * spl)
+            base = issue or {}
+            issue = {"valu_insts_per_env_step": live["SQ_INSTS_VALU"] / env_steps, "salu_insts_per_env_step": live["SQ_INSTS_SALU"] / env_steps,
+                     "lds_insts_per_env_step": live["SQ_INSTS_LDS"] / env_steps, "wave_cycles_per_env_step": 4.0 * live["SQ_WAVE_CYCLES"] / env_steps,
+                     "valu_active_per_wave": live["SQ_ACTIVE_INST_VALU"] / live["SQ_WAVE_CYCLES"], "wait_any_per_wave": live["SQ_WAIT_ANY"] / live["SQ_WAVE_CYCLES"],
+                     # pipe cycles per wave64 VALU instruction: the microbenchmark's figure (profiles/valu_issue_microbench.json)
+                     "valu_cycles_per_inst": base.get("valu_cycles_per_inst", 1.66),
+                     "active_lane_fraction": live["SQ_THREAD_CYCLES_VALU"] / (64.0 * live["SQ_ACTIVE_INST_VALU"]) if live["SQ_ACTIVE_INST_VALU"] else None,
+                     "lds_bank_conflict_fraction": live["SQ_LDS_BANK_CONFLICT"] / live["SQ_LDS_IDX_ACTIVE"] if live["SQ_LDS_IDX_ACTIVE"] else None}
         flops = algorithmic_flops(sim.model.nv, sim.model.nb, mean_contacts, mean_iters)
         kernel_rate = n_local * spl / (ms * 1e-3)           # env-steps/s of the kernel alone on this GPU
         compute = {
@@ -502,10 +591,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                # traffic / issue are NOT measured by this run: they are the rocprofv3 --pmc passes of the same command,
-                # committed under profiles/ and scaled to this launch length
-                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, fitted per world and per step)" if traffic is not None else None,
-                "issue_source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_* passes of this command)" if issue else None,
+                # traffic / issue: at N = 1 measured by THIS run (live_counters: the workload re-run under rocprofv3 --pmc after
+                # the timed region); otherwise the committed passes of the same command under profiles/, scaled to this
+                # launch length — `counters` / `*_source` say which
+                "traffic_source": traffic_source, "issue_source": issue_source,
+                "counters": "live" if live else "replayed", "counters_note": live_note,
                 "kernel": {"legs_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1,1,1,1,1>, false>",
                            "legs_active_only": "nmf_step_kernel<HybridTopo<0,0,6,3,2,1,1>, false>",
                            "all_biological": "nmf_step_kernel<HybridTopo<20,60,6,3,2,1,1,1,1,1,1>, false>",
@@ -533,11 +623,17 @@ def main():
             if vfile.exists() and args.vision == "resample":
                 rec = json.loads(vfile.read_text())
                 vt = rec.get("traffic_bytes_per_eye_frame", 0) * 2 * n_local or None
+            vt_source = "profiles/vision_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder)" if vt else None
+            vlive = None
+            if not args.no_live_counters and world_size == 1 and args.vision == "resample":
+                vlive, vnote = live_counters(spl, "nmf_retina_stream_kernel", passes=LIVE_PASSES[:2])
+                if vlive:      # wide coalesced 16-byte reads: the x2 of the guide's gfx950 correction applies in full
+                    vt, vt_source = 1024.0 * (2.0 * vlive["FETCH_SIZE"] + vlive["WRITE_SIZE"]), vnote
             ach = per_launch / (vis_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm" if args.vision == "resample" else "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": vt,
-                "traffic_source": "profiles/vision_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if vt else None,
+                "traffic_source": vt_source, "counters": "live" if vlive else "replayed",
                 "kernel": "nmf_retina_stream_kernel" if args.vision == "resample" else "nmf_eye_kernel",
                 "kernel_ms_per_launch": vis_ms, "eye_frames_per_launch": 2 * n_local,
                 "algorithmic_bytes_per_eye_frame": {"in": frame_bytes, "out": out_bytes},

@@ -2,7 +2,7 @@
 # quick kernel A/B on the GPU box: bench lines for the in-tree library (and any NMF_HIP_LIB variants passed as args)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

@@ -8,6 +8,6 @@ for so in variants/*.so; do
   python -m pytest tests -x -q -m gpu 2>&1 | tail -1
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
   for p in legs_only legs_only; do
-  python bench.py --no-cpu-baseline --steps 1000 --joint-preset $p 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$p value %.4e  ms/launch %.3f  iters %.2f contacts %.2f' % (d['value'], d['roofline']['kernel_ms_per_launch'], d['config']['mean_newton_iters'], d['config']['mean_contacts']))"
+  python bench.py --no-cpu-baseline --no-live-counters --steps 1000 --joint-preset $p 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$p value %.4e  ms/launch %.3f  iters %.2f contacts %.2f' % (d['value'], d['roofline']['kernel_ms_per_launch'], d['config']['mean_newton_iters'], d['config']['mean_contacts']))"
   done
 done

@@ -2,7 +2,7 @@
 # A/B on the GPU box for libs build/libnmf_<name>.so: ALL_BIOLOGICAL bench lines + its parity tests
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --joint-preset all_biological"
+B="python bench.py --no-cpu-baseline --no-live-counters --joint-preset all_biological"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

@@ -2,7 +2,7 @@
 # A/B on the GPU box: driver-args bench lines for "<lib>[:ENV=VAL,...]" specs; libs are build/libnmf_<lib>.so
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

@@ -2,7 +2,7 @@
 # kernel A/B on the GPU box: bench lines (driver args, default, replay) for the libraries build/libnmf_<name>.so given as args
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

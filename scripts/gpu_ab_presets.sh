@@ -2,7 +2,7 @@
 # A/B on the GPU box for libs build/libnmf_<name>.so: LEGS_ONLY (driver args, default) and ALL_BIOLOGICAL (default) bench lines
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

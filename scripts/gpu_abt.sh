@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 T=$1; shift
 for lib in "$@"; do
   export NMF_HIP_LIB=$PWD/build/libnmf_$lib.so
-  timeout 300 python bench.py --no-cpu-baseline --terrain $T 2>/dev/null | grep '^{"metric"' | python -c "
+  timeout 300 python bench.py --no-cpu-baseline --no-live-counters --terrain $T 2>/dev/null | grep '^{"metric"' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); c = d['config']
 print('$lib', '$T', round(d['value'] / 1e6, 2), 'M', 'ms/launch', round(d['roofline']['kernel_ms_per_launch'], 3), 'contacts', round(c['mean_contacts'], 2), 'iters', round(c['mean_newton_iters'], 2), 'valid', d.get('valid'))"

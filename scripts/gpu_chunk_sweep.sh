@@ -2,7 +2,7 @@
 # chunk-plan sweep for short launches (the driver's --steps 20) and the default 50
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-run() { timeout 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric"' | python -c "
+run() { timeout 200 python bench.py --no-cpu-baseline --no-live-counters "$@" 2>/dev/null | grep '^{"metric"' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print(round(d['value'] / 1e6, 2), 'M', round(d['roofline']['kernel_ms_per_launch'], 3), 'ms')"; }
 {

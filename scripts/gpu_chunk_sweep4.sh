@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export NMF_HIP_LIB=$PWD/build/libnmf_$1.so
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 val() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin: print(round(json.loads(l)['value'] / 1e6, 2))"; }

@@ -8,6 +8,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export NMF_BENCH_FORCE_DIST=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 500 $* > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-counters --steps 500 $* > "$OUT/bench_trace.log" 2>&1
 grep -h '"metric"' "$OUT"/bench_trace.log | cut -c1-200
 tail -3 "$OUT"/bench_trace.log | cut -c1-200

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 ( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) > gpurun_out/pytest.log
 bash scripts/gpu_ab.sh > /dev/null 2>&1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_quick; rm -rf $OUT; mkdir -p $OUT
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT -o q -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT -o q -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-counters > $OUT/bench.log 2>&1 )
 python - <<'P'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/prof_quick/**/*counter_collection.csv", recursive=True)[0]

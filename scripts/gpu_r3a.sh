@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -q --deselect tests/test_hip_parity_r3.py 2>&1 | tail -30 ) > gpurun_out/pytest_old.log
 ( timeout 1500 python -m pytest tests/test_hip_parity_r3.py -m gpu -q 2>&1 | tail -60 ) > gpurun_out/pytest_r3.log
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > gpurun_out/smoke.log
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

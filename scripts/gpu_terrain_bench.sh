@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 ( timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_parity_r2.py tests/test_hip_parity_r3.py tests/test_sensors.py -m gpu -q -k "terrain or config4 or config5 or side_faces or sees_the" 2>&1 | tail -6 ) > gpurun_out/pytest_terrain.log
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

@@ -2,7 +2,7 @@
 # the workload table of DESIGN.md §3: batch-size sweep under the reference protocol + the other configurations
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-live-counters"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:

@@ -10,7 +10,7 @@ TAG=${1:-r2}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-counters $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- $BENCH > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$TAG" -- $BENCH > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$TAG" -- $BENCH > "$OUT/bench_write.log" 2>&1

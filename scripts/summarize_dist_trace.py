@@ -12,7 +12,7 @@ b = next(json.loads(l) for l in (src / "bench_trace.log").read_text().splitlines
 steps = [i for i, r in enumerate(rows) if "nmf_step_kernel" in r["Kernel_Name"]]
 n_timed = b["steps"] // b["config"]["steps_per_launch"] * int(b["config"].get("repeats", 1))
 ticks = steps[-n_timed - 1:-1]                       # timed-region launches that have a successor in the trace
-out = [f"# rocprofv3 kernel trace `{tag}` — `NMF_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps {b['steps']}` on 1x MI355X\n",
+out = [f"# rocprofv3 kernel trace `{tag}` — `NMF_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-live-counters --steps {b['steps']}` on 1x MI355X\n",
        f"The bench's multi-GPU code path on ONE rank (process group on RCCL, per control tick: stepping launch, observation pack, "
        f"asynchronous all-gather on RCCL's stream, double-buffered): {b['value']:.4e} env-steps/s, rccl_ranks {b['config']['rccl_ranks']}.\n",
        "## One control tick in dispatch order (us from the start of its stepping kernel; mean over the timed ticks)\n",

@@ -27,7 +27,7 @@ def bench_line(log):
     return None
 
 
-out = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline` on 1x MI355X\n"]
+out = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-live-counters` on 1x MI355X\n"]
 b = bench_line("bench_trace.log")
 n_launch = b["steps"] // b["config"]["steps_per_launch"] * int(b["config"].get("repeats", 1))
 out.append(f"bench line under the tracer: value {b['value']:.4e} env-steps/s, kernel_ms_per_launch "

@@ -22,7 +22,7 @@ def bench_line(log):
 b = bench_line("bench_trace.log")
 r, v = b["roofline"], b["config"]["vision"]
 n_frames = r["eye_frames_per_launch"]
-out = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --vision resample --steps 200` on 1x MI355X (BASELINE config 3)\n",
+out = [f"# rocprofv3 summary `{tag}` — `python bench.py --no-cpu-baseline --no-live-counters --vision resample --steps 200` on 1x MI355X (BASELINE config 3)\n",
        f"bench line under the tracer: {b['value']:.4e} env-steps/s combined (physics {v['physics_kernel_ms_per_tick']:.3f} ms + retina "
        f"{v['kernel_ms_per_tick']:.3f} ms per {v['every_steps']}-step tick); `{r['kernel']}`: {r['kernel_ms_per_launch']:.3f} ms per {n_frames} eye frames "
        f"= {r['achieved']:.0f} GB/s algorithmic = **{100 * r['frac']:.1f} % of 8 TB/s** (HIP events on the launch stream)\n"]
