@@ -99,6 +99,8 @@ struct nmf_batch {
   // previous launch predicts this one's (20-step CPG launches 43.1 vs 42.5 M env-steps/s, replay 45.9 vs 45.0 M; 50-step
   // 44.7 vs 44.5 M) — and the measured policy for longer ones, whose costs are a third of a gait cycle stale (250-step
   // launches: 43.7 M costliest first, 45.6 M measured policy)
+  int order_every = 1, order_age = 0;      // costliest-first order: recomputed every order_every-th launch (NMF_ORDER_EVERY)
+  bool order_valid = false;
   int order_policy = 3;          // 3 auto (default), 1 costliest first, 0 in order, 2 none, -1 the measured policy of rounds 1-2
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
   double chunk_div = 2.0;
@@ -263,7 +265,10 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   b->st.order = nullptr; b->st.sched = nullptr;
   if (oversub && b->order_buf && b->sched_buf && b->order_policy != 2) {
     const int policy = b->order_policy == 3 ? (n_steps <= 64 ? 1 : -1) : b->order_policy;
-    hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps, policy);
+    if (!(policy == 1 && b->order_valid && ++b->order_age < b->order_every)) {
+      hipLaunchKernelGGL(nmf::nmf_order_kernel, dim3(1), dim3(1024), 0, stream, b->st.cost, b->n_worlds, b->order_buf, b->sched_buf, n_steps, policy);
+      b->order_age = 0; b->order_valid = true;
+    }
     b->st.order = b->order_buf;
     if (policy < 0) b->st.sched = b->sched_buf;
   }
@@ -493,6 +498,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       const std::string v(e);
       b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 3;
     }
+    if (const char* e = getenv("NMF_ORDER_EVERY")) b->order_every = std::max(1, atoi(e));
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));

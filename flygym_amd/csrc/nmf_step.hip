@@ -449,6 +449,31 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const GModel& m, in
     float R0 = s.xmat()[0][3 * r3], R1 = s.xmat()[0][3 * r3 + 1], R2 = s.xmat()[0][3 * r3 + 2];
     float p = s.xpos()[0][r3];
     const int b0 = TP::LB0 + L.lg * TP::NBL;
+#ifndef NMF_KIN_NO_PREFETCH
+    // the relative transform of level l + 1 is requested before level l's results are stored: its LDS round trip runs
+    // under the stores (the compiler keeps the loads behind them otherwise — it cannot tell the two regions apart)
+    float Mn[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mn[k] = relm[b0][k];
+    static_for<TP::NBL>([&](auto I) {
+      constexpr int l = decltype(I)::value;
+      float M[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) M[k] = Mn[k];
+      p += R0 * M[9] + R1 * M[10] + R2 * M[11];
+      const float n0 = R0 * M[0] + R1 * M[3] + R2 * M[6];
+      const float n1 = R0 * M[1] + R1 * M[4] + R2 * M[7];
+      const float n2 = R0 * M[2] + R1 * M[5] + R2 * M[8];
+      R0 = n0; R1 = n1; R2 = n2;
+      if constexpr (l + 1 < TP::NBL) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Mn[k] = relm[b0 + l + 1][k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      s.xmat()[b0 + l][3 * r3] = R0; s.xmat()[b0 + l][3 * r3 + 1] = R1; s.xmat()[b0 + l][3 * r3 + 2] = R2;
+      s.xpos()[b0 + l][r3] = p;
+    });
+#else
     static_for<TP::NBL>([&](auto I) {
       constexpr int l = decltype(I)::value;
       const float* M = relm[b0 + l];
@@ -460,6 +485,7 @@ __device__ __noinline__ void stage_kinematics(FlyLds<TP>& s, const GModel& m, in
       s.xmat()[b0 + l][3 * r3] = R0; s.xmat()[b0 + l][3 * r3 + 1] = R1; s.xmat()[b0 + l][3 * r3 + 2] = R2;
       s.xpos()[b0 + l][r3] = p;
     });
+#endif
   }
   WSYNC();
   for (int j = lane; j < s.nv(); j += kWave) {
@@ -2489,7 +2515,21 @@ __global__ void __launch_bounds__(1024) nmf_order_kernel(const float* __restrict
   const float l = __uint_as_float(lo); const float scale = 255.0f / fmaxf(__uint_as_float(hi) - l, 1.0f);
   for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[(int)((cost[i] - l) * scale)], 1u);
   __syncthreads();
-  if (threadIdx.x == 0) { unsigned int run = 0u; for (int b = 255; b >= 0; --b) { base[b] = run; run += hist[b]; } }
+  // exclusive prefix from the top bin: base[b] = sum of hist over bins above b (a wave-parallel scan, 8 doubling steps —
+  // the serial loop over 256 bins was half of this kernel's 9 us)
+  if (threadIdx.x < 256) base[threadIdx.x] = hist[255 - threadIdx.x];        // reversed: inclusive scan from the top
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    unsigned int v = 0u;
+    if (threadIdx.x < 256 && (int)threadIdx.x >= off) v = base[threadIdx.x - off];
+    __syncthreads();
+    if (threadIdx.x < 256) base[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned int excl = 0u;
+  if (threadIdx.x < 256) excl = base[255 - threadIdx.x] - hist[threadIdx.x];   // bins above threadIdx.x
+  __syncthreads();
+  if (threadIdx.x < 256) base[threadIdx.x] = excl;
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&base[(int)((cost[i] - l) * scale)], 1u)] = i;
 }
