@@ -66,9 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --worlds-per-gpu on every GPU; strong: --worlds-per-gpu worlds in TOTAL, sharded over the GPUs")
     ap.add_argument("--shard-policy", choices=["spread", "fill"], default="spread",
-                    help="--scaling strong only.  spread: every GPU gets a share (highest aggregate rate: a step takes 72 us for "
-                         "128 worlds and 87 us for 2048); fill: use only ceil(total / resident worlds per GPU) GPUs — the same "
-                         "rate to within ~15 %% from far fewer GPUs; the other ranks idle (flygym_amd.sharding.shard_plan)")
+                    help="--scaling strong only.  spread: every GPU gets a share (highest aggregate rate: a step takes 61 us for "
+                         "128 worlds and 72 us for 2048); fill: use only ceil(total / resident worlds per GPU) GPUs — the same "
+                         "rate to within ~10 %% from far fewer GPUs; the other ranks idle (flygym_amd.sharding.shard_plan)")
     ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="physics steps fused into one kernel launch (= one control tick)")
     ap.add_argument("--workload", choices=["cpg", "replay"], default="cpg",
@@ -357,7 +357,7 @@ def main():
     shard_note = None
     if max(shard_sizes) < resident and world_size > 1:
         # a launch below residency is pure latency: a step takes as long for 128 worlds as for 2048 (measured on BASELINE
-        # config 5's workload: 72.1 us at 128 worlds per GPU, 78.8 at 512, 82.2 at 1024, 86.9 at 2048: scripts/gpu_config5_sweep.sh), so this job cannot scale with the GPU count
+        # config 5's workload: 61.2 us at 128 worlds per GPU, 66.2 at 512, 67.6 at 1024, 72.3 at 2048: scripts/gpu_config5_sweep.sh), so this job cannot scale with the GPU count
         shard_note = (f"{max(shard_sizes)} worlds per GPU are below the {resident} one MI355X steps at once: the step time no longer "
                       f"falls with the shard size, so {active_gpus} GPUs deliver about what {max(1, -(-total_worlds // resident))} would "
                       "(--shard-policy fill uses only those)")

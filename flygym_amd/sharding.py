@@ -33,8 +33,8 @@ def shard_plan(total_worlds: int, world_size: int, resident: int = 2048, policy:
     A launch with fewer worlds than a GPU holds at once is pure latency: a step takes as long for 128 worlds as for 2048
     (one wave per world, ~50-85 us per step whatever the count), so spreading a small batch over more GPUs buys little
     and adds the observation exchange.  BASELINE config 5 is the case in point: 1024 flies on 8 GPUs = 128 per GPU ->
-    measured 1.77 M env-steps/s per GPU = 14.1 M on eight, where ONE GPU steps all 1024 at 12.4 M (same workload,
-    scripts/gpu_config5_sweep.sh): seven more GPUs for +14 %.
+    measured 2.08 M env-steps/s per GPU = 16.7 M on eight, where ONE GPU steps all 1024 at 15.1 M (same workload,
+    scripts/gpu_config5_sweep.sh): seven more GPUs for +10 %.
 
     ``policy="fill"`` (default): use ``min(world_size, ceil(total / resident))`` ranks — fill a GPU to its residency
     before taking the next — and split the worlds evenly over those; the remaining ranks get 0 worlds (they stay in the
