@@ -449,6 +449,10 @@ def compile_world(world) -> CompiledModel:
             if a["kind"] == "position":
                 act_gain.append(kp)
                 act_bias.append([-kp, -kv])
+            elif a["kind"] == "velocity":       # MuJoCo's velocity servo: kv (ctrl - qd); kv defaults to 1
+                kv = a.get("kv", 1.0)
+                act_gain.append(kv)
+                act_bias.append([0.0, -kv])
             else:
                 act_gain.append(a.get("gear", 1.0))
                 act_bias.append([0.0, 0.0])

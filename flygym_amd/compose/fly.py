@@ -48,7 +48,10 @@ class ActuatorType(Enum):
     ADHESION = "adhesion"
 
 
-_SUPPORTED_ACTUATORS = (ActuatorType.POSITION, ActuatorType.MOTOR)
+# Stateless affine actuators: force = gain ctrl + bias_q q + bias_v qd (MuJoCo's position: gain kp, bias (-kp, -kv);
+# velocity: gain kv, bias (0, -kv); motor: gain gear).  The stateful types (intvelocity, cylinder, muscle: an activation
+# state per actuator) and damper (gain proportional to the joint velocity) are refused loudly.
+_SUPPORTED_ACTUATORS = (ActuatorType.POSITION, ActuatorType.MOTOR, ActuatorType.VELOCITY)
 
 
 class Fly:

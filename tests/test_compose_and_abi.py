@@ -85,6 +85,42 @@ def test_compose_errors_and_variants():
         world.add_fly(fly, (0, 0, 1), Rotation3D("quat", (1, 0, 0, 0)))
 
 
+def test_actuator_types(oracle_lib):
+    """Reference ``ActuatorType`` (compose/fly.py:65-77): the stateless affine servos are compiled — position (gain kp, bias
+    (-kp, -kv)), velocity (gain kv, bias (0, -kv)), motor — next to adhesion; the stateful ones and damper are refused loudly.
+    A velocity-actuated leg joint in the oracle reports kv (ctrl - qd), clamped to the force range."""
+    from flygym_amd.compose import ActuatorType
+
+    fly = Fly(name="v")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=KinematicPosePreset.NEUTRAL)
+    dofs = sk.get_actuated_dofs_from_preset("legs_active_only")
+    fly.add_actuators(dofs, ActuatorType.POSITION, kp=50.0, kv=0.5, neutral_input=KinematicPosePreset.NEUTRAL)
+    fly.add_actuators(dofs[:3], "velocity", kv=2.0, forcerange=(-4.0, 4.0))
+    fly.add_actuators(dofs[3:5], ActuatorType.MOTOR)
+    for ty in (ActuatorType.INTVELOCITY, ActuatorType.DAMPER, ActuatorType.CYLINDER, ActuatorType.MUSCLE):
+        with pytest.raises(NotImplementedError):
+            fly.add_actuators(dofs[:1], ty)
+    world = FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    m = world.compile_model()
+    n = len(dofs)
+    assert m.nu == n + 5
+    np.testing.assert_array_equal(m["act_gain"][:n], 50.0)
+    np.testing.assert_array_equal(m["act_bias"][:n], np.tile([-50.0, -0.5], (n, 1)))
+    np.testing.assert_array_equal(m["act_gain"][n:n + 3], 2.0)
+    np.testing.assert_array_equal(m["act_bias"][n:n + 3], np.tile([0.0, -2.0], (3, 1)))
+    np.testing.assert_array_equal(m["act_gain"][n + 3:], 1.0)
+    np.testing.assert_array_equal(m["act_bias"][n + 3:], 0.0)
+    assert [d.name for d in fly.get_actuated_jointdofs_order(ActuatorType.VELOCITY)] == [d.name for d in dofs[:3]]
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.ctrl[n:n + 3] = [1.0, -0.5, 10.0]
+    o.qvel[6 + np.array(m["act_trn"][n:n + 3]) - 6] = [0.25, 0.0, 0.0]
+    qd = o.qvel[np.array(m["act_trn"][n:n + 3])].copy()
+    o.forward()
+    np.testing.assert_allclose(o.arr("actuator_force")[n:n + 3], np.clip(2.0 * (np.array([1.0, -0.5, 10.0]) - qd), -4.0, 4.0), rtol=1e-12)
+
+
 def test_abi_exports_every_declared_symbol():
     _native.build()
     lib = ctypes.CDLL(str(_native.LIB_PATH))

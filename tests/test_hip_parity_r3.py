@@ -489,13 +489,13 @@ def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
 
     for case, c in cj.HINGE_CASES.items():
         par = dict(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armature=1e-6, damping=0.0, stiffness=0.0, springref=0.0, kp=0.0,
-                   kv=0.0, forcerange=None, q0=0.0)
+                   kv=0.0, forcerange=None, q0=0.0, servo="position")
         par.update(c["par"])
         sim = HIPSimulation(TinyWorld(hinge_on_heavy_base(**par)), n_worlds=2, device=0)
         n = 1500
         inertia = par["inertia_yy"] + par["mass"] * float(np.dot(par["com"], par["com"]))
         qs, vs, taus = cj.hinge_recurrence(n, par["q0"], 0.0, c["ctrl"], inertia, par["armature"], par["damping"], par["stiffness"],
-                                           par["springref"], par["kp"], par["kv"], par["forcerange"])
+                                           par["springref"], par["kp"], par["kv"], par["forcerange"], par["servo"])
         ctrl = torch.as_tensor(np.array([c["ctrl"](k) for k in range(n)], dtype=np.float32), device=sim.device)
         got = torch.zeros((n, 3), device=sim.device)
         for k in range(n):

@@ -101,12 +101,13 @@ class TinyWorld:
 
 
 def hinge_on_heavy_base(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armature=1e-6, damping=2e-5, stiffness=0.0, springref=0.0,
-                        kp=0.0, kv=0.0, forcerange=None, q0=0.0, timestep=1e-4) -> CompiledModel:
+                        kp=0.0, kv=0.0, forcerange=None, q0=0.0, timestep=1e-4, servo="position") -> CompiledModel:
     """A link on a hinge (axis y through the base's origin) carried by a free base 1e9 times heavier, no gravity, no
     contact (the base's only geom floats 100 mm over the plane): the base stays put to 1e-9, so the hinge obeys the
     one-dof equation  (I + armature) qdd = tau_act - stiffness (q - springref) - damping qd  with
     I = inertia_yy + mass |com|^2 (com perpendicular to the axis).  One position actuator on the hinge: force =
-    kp ctrl - kp q - kv qd, clamped to ``forcerange`` when given."""
+    kp ctrl - kp q - kv qd, clamped to ``forcerange`` when given (``servo="velocity"``: MuJoCo's velocity servo,
+    force = kv (ctrl - qd))."""
     base_mass = 1e9 * mass
     m = sphere_on_plane(mass=base_mass, radius=0.1, gravity=(0.0, 0.0, 0.0), timestep=timestep, start_height=100.0)
     f, i = (lambda *a: np.asarray(a, dtype=np.float64)), (lambda *a: np.asarray(a, dtype=np.int32))
@@ -122,7 +123,7 @@ def hinge_on_heavy_base(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armatur
         dof_stiffness=f(0, 0, 0, 0, 0, 0, stiffness), dof_springref=f(0, 0, 0, 0, 0, 0, springref),
         seg_body=i(0, 1), seg_pos=f([0, 0, 0], [0, 0, 0]), seg_quat=f([1, 0, 0, 0], [1, 0, 0, 0]),
         seg_invweight0=f([1.0 / base_mass, 1.0 / big], [1.0 / mass, 1.0 / inertia_yy]),
-        act_type=i(0), act_trn=i(6), act_limited=i([limited, 0]), act_geom=i(-1), act_gain=f(kp), act_bias=f([-kp, -kv]),
+        act_type=i(0), act_trn=i(6), act_limited=i([limited, 0]), act_geom=i(-1), act_gain=f(kp if servo == "position" else kv), act_bias=f([-kp, -kv] if servo == "position" else [0.0, -kv]),
         act_forcerange=f([lo, hi]), act_ctrlrange=f([0.0, 0.0]), key_ctrl=f(0.0),
         key_qpos=f(0, 0, 100.0, 1, 0, 0, 0, q0), qpos0=f(0, 0, 100.0, 1, 0, 0, 0, q0),
         stat_meaninertia=f(mass),
