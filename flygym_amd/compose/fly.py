@@ -139,6 +139,10 @@ class Fly:
         return {seg: {"name": seg.name} for seg in self._bodysegs}
 
     @property
+    def bodyseg_to_mjcfgeom(self) -> dict:
+        return {seg: {"name": seg.name, "mesh": self.mesh_type.value} for seg in self._bodysegs}
+
+    @property
     def jointdof_to_mjcfjoint(self) -> dict:
         return self.joint_params
 

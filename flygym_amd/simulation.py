@@ -156,11 +156,17 @@ class HIPSimulation:
         return dst
 
     def _to_device(self, x, n_cols: int, what: str):
+        """(n_worlds, n_cols) float32 on the device.  As on the reference's GPU class — whose scatter kernel reads the
+        leading ``n_cols`` columns of whatever it is given (warp/simulation.py:236-258; its own tests pass one column per
+        joint dof for 42 actuators, tests/warp/test_simulation.py:254-268) — a wider array is accepted and its leading
+        columns are used; a narrower one, or a wrong number of worlds, is an error here (there: an out-of-bounds read)."""
         t = self._torch
         if not isinstance(x, t.Tensor):
             x = t.as_tensor(np.asarray(x, dtype=np.float32))
-        if x.ndim != 2 or x.shape[0] != self.n_worlds or x.shape[1] != n_cols:
+        if x.ndim != 2 or x.shape[0] != self.n_worlds or x.shape[1] < n_cols:
             raise ValueError(f"Expected {what} of shape ({self.n_worlds}, {n_cols}), but got {tuple(x.shape)}")
+        if x.shape[1] > n_cols:
+            x = x[:, :n_cols]
         return x.to(device=self.device, dtype=t.float32).contiguous()
 
     # ---- reference surface ---------------------------------------------------------------
@@ -308,7 +314,7 @@ class HIPSimulation:
     def set_actuator_inputs(self, fly_name: str, actuator_type, inputs) -> None:
         ids = self._ids_by_fly[fly_name]["actuators"][ActuatorType(actuator_type)]
         n = int(ids.numel())
-        if len(inputs.shape) == 2 and inputs.shape[1] != n:
+        if len(inputs.shape) == 2 and inputs.shape[1] < n:
             raise ValueError(
                 f"Expected {n} inputs for actuator type '{ActuatorType(actuator_type).name}', but got {inputs.shape[1]}"
             )
@@ -319,7 +325,7 @@ class HIPSimulation:
     def set_leg_adhesion_states(self, fly_name: str, leg_to_adhesion_state) -> None:
         ids = self._ids_by_fly[fly_name]["adhesion"]
         n = int(ids.numel())
-        if len(leg_to_adhesion_state.shape) == 2 and leg_to_adhesion_state.shape[1] != n:
+        if len(leg_to_adhesion_state.shape) == 2 and leg_to_adhesion_state.shape[1] < n:
             raise ValueError(
                 f"Unexpected number of adhesion states: expected {n}, got {leg_to_adhesion_state.shape[1]}"
             )

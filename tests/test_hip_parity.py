@@ -144,9 +144,17 @@ def test_control_inputs_and_getters(torch_mod, sim8):
     sim.set_leg_adhesion_states(fly.name, torch.full((8, 6), 3.0, device=sim.device))
     np.testing.assert_array_equal(sim.field("ctrl").cpu().numpy()[:, 42:], 3.0)
     with pytest.raises(ValueError):
-        sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, np.zeros((8, 47), dtype=np.float32))
+        sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, np.zeros((8, 41), dtype=np.float32))
+    with pytest.raises(ValueError):
+        sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, np.zeros((7, 42), dtype=np.float32))
     with pytest.raises(ValueError):
         sim.set_leg_adhesion_states(fly.name, np.ones((8, 5), dtype=np.float32))
+    # a wider array: its leading columns are used, as the reference's GPU class does (warp/simulation.py:236-258)
+    wide = np.concatenate([inputs, np.full((8, 24), 9.0, dtype=np.float32)], axis=1)
+    sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, 2 * wide)
+    np.testing.assert_array_equal(sim.field("ctrl").cpu().numpy()[:, :42], 2 * inputs)
+    np.testing.assert_array_equal(sim.field("ctrl").cpu().numpy()[:, 42:], 3.0)
+    sim.set_actuator_inputs(fly.name, ActuatorType.POSITION, inputs)
     for _ in range(50):
         sim.step()
     after = sim.get_joint_angles(fly.name).cpu().numpy()
