@@ -520,3 +520,79 @@ def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
     assert np.abs(got - want).max() < 2e-5            # float32: the position 100 + r carries 7.6e-6 per bit
     assert float(sim.field("qpos")[0, :2].abs().max()) < 1e-6 and float(sim.field("qpos")[0, 4:7].abs().max()) < 1e-6
     assert int(sim.field("stats")[0, 0].item()) == 0
+
+
+@pytest.mark.parametrize("config", ["config 4: gapped", "config 4: blocks", "config 5: mixed + gait adhesion"])
+def test_terrain_batches_step_like_the_oracle_from_their_own_states(torch_mod, oracle_lib, config):
+    """BASELINE configs 4 / 5 at their per-GPU sizes (4096 / 1024 flies walking over box terrain, chunked launches of the
+    ``Terrain<LEGS_ONLY>`` kernel): at three checkpoints of the walk, 24 worlds are drawn, the engine's OWN state of each is
+    handed to the float32 and float64 oracles, and the next step is compared — contact list (geoms, in order) equal to an
+    oracle's, accelerations to float32 accuracy where the lists agree with the float64 oracle's.  Rollouts over a terrain
+    separate at the first edge event; a single step from the engine's state cannot, so no resynchronisation is needed and
+    every sampled world counts."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+
+    cls, n, adhesion = {"config 4: gapped": ("GappedTerrainWorld", 4096, False), "config 4: blocks": ("BlocksTerrainWorld", 4096, False),
+                        "config 5: mixed + gait adhesion": ("MixedTerrainWorld", 1024, True)}[config]
+    fly, _, _ = make_model()
+    world = getattr(C, cls)()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    table = cpg.targets(n, 2500, device=sim.device, adhesion=(cpg.stance_bins(sim.model, fly), 20.0, 1.0) if adhesion else None)
+    ids = sim.replay_ids(fly.name, with_adhesion=adhesion)
+    ids_np = ids.cpu().numpy()
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    sim.warmup()
+    blob = sim.model.to_blob()
+    rng = np.random.default_rng(11)
+    cur, same, close, walls, total = 0, 0, 0, 0, 0
+    devs = []
+    for checkpoint in range(3):
+        for _ in range(6):
+            sim.step_replay(table, ids, cur, 50); cur += 50
+        picks = rng.choice(n, size=24, replace=False)
+        before = {k: sim.field(k)[torch.as_tensor(picks, device=sim.device)].cpu().numpy().astype(np.float64)
+                  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+        rows = table[torch.as_tensor(picks, device=sim.device)].cpu().numpy()
+        sim.step_replay(table, ids, cur, 1); cur += 1
+        torch.cuda.synchronize()
+        qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+        for j, w in enumerate(picks):
+            ref = {}
+            for prec in ("f64", "f32"):
+                r = oracle_lib.Oracle(blob, prec)
+                for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+                    r.arr(k)[:] = before[k][j]
+                r.step_replay(rows[j], ids_np, cur - 1, 1)
+                ref[prec] = r
+            nc = int(stats[w, 0])
+            mine = geom[w, :nc].astype(int).tolist()
+            total += 1
+            same += any(mine == r.ints()["con_geom"] for r in ref.values())
+            if mine == ref["f64"].ints()["con_geom"]:
+                # float32 accuracy of the solve: 2e-3 of max |qacc| as in the other single-step tests — or, where the contact
+                # problem is ill-conditioned (a hull patch straddling a block edge under 20x adhesion), no further from the
+                # float64 oracle than twice the float32 ORACLE is
+                scale = max(np.abs(ref["f64"].arr("qacc")).max(), 1e4)
+                dev = np.abs(qacc[w] - ref["f64"].arr("qacc")).max()
+                dev32 = np.abs(ref["f32"].arr("qacc") - ref["f64"].arr("qacc")).max() if mine == ref["f32"].ints()["con_geom"] else 0.0
+                devs.append((dev / scale, dev32 / scale))
+                assert dev < max(2e-3 * scale, 2.0 * dev32), f"{config}: world {w} at checkpoint {checkpoint}: {dev / scale:.2e} of max |qacc| (float32 oracle: {dev32 / scale:.2e})"
+                close += 1
+            fr = ref["f64"].arr("con_frame").reshape(-1, 9)
+            walls += int((fr[:, 2] == 0).sum()) if len(fr) else 0
+    devs = np.array(devs)
+    print(f"{config}: contact lists equal in {same}/{total}, comparable {close}; qacc deviation / max |qacc|: median {np.median(devs[:, 0]):.1e}, "
+          f"max {devs[:, 0].max():.1e} (float32 oracle: median {np.median(devs[:, 1]):.1e}, max {devs[:, 1].max():.1e}); wall contacts {walls}")
+    assert np.median(devs[:, 0]) < 5e-4
+    assert total == 72 and same >= 0.9 * total, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
+    assert close >= 0.8 * total, f"{config}: {close} of {total} steps comparable with the float64 oracle"
+    assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
+    assert float(stats[:, 0].mean()) > 3
+    if "blocks" in config or "mixed" in config:
+        assert walls > 0, "no sampled step touched a side face"
