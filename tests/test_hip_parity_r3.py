@@ -522,10 +522,11 @@ def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
     assert int(sim.field("stats")[0, 0].item()) == 0
 
 
-@pytest.mark.parametrize("config", ["config 4: gapped", "config 4: blocks", "config 5: mixed + gait adhesion"])
-def test_terrain_batches_step_like_the_oracle_from_their_own_states(torch_mod, oracle_lib, config):
-    """BASELINE configs 4 / 5 at their per-GPU sizes (4096 / 1024 flies walking over box terrain, chunked launches of the
-    ``Terrain<LEGS_ONLY>`` kernel): at three checkpoints of the walk, 24 worlds are drawn, the engine's OWN state of each is
+@pytest.mark.parametrize("config", ["config 2: flat", "config 2: flat, ALL_BIOLOGICAL", "config 4: gapped", "config 4: blocks",
+                                    "config 5: mixed + gait adhesion"])
+def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod, oracle_lib, config):
+    """BASELINE configs 2 / 4 / 5 at their per-GPU sizes (4096 / 1024 flies walking on flat ground or over box terrain,
+    chunked launches of the LEGS_ONLY, ALL_BIOLOGICAL and ``Terrain<LEGS_ONLY>`` kernels): at three checkpoints of the walk, 24 worlds are drawn, the engine's OWN state of each is
     handed to the float32 and float64 oracles, and the next step is compared — contact list (geoms, in order) equal to an
     oracle's, accelerations to float32 accuracy where the lists agree with the float64 oracle's.  Rollouts over a terrain
     separate at the first edge event; a single step from the engine's state cannot, so no resynchronisation is needed and
@@ -536,9 +537,12 @@ def test_terrain_batches_step_like_the_oracle_from_their_own_states(torch_mod, o
     from flygym_amd.controllers import TripodCPG
     from flygym_amd.utils.math import Rotation3D
 
-    cls, n, adhesion = {"config 4: gapped": ("GappedTerrainWorld", 4096, False), "config 4: blocks": ("BlocksTerrainWorld", 4096, False),
-                        "config 5: mixed + gait adhesion": ("MixedTerrainWorld", 1024, True)}[config]
-    fly, _, _ = make_model()
+    cls, n, adhesion, preset = {"config 2: flat": ("FlatGroundWorld", 4096, False, "legs_only"),
+                                "config 2: flat, ALL_BIOLOGICAL": ("FlatGroundWorld", 4096, False, "all_biological"),
+                                "config 4: gapped": ("GappedTerrainWorld", 4096, False, "legs_only"),
+                                "config 4: blocks": ("BlocksTerrainWorld", 4096, False, "legs_only"),
+                                "config 5: mixed + gait adhesion": ("MixedTerrainWorld", 1024, True, "legs_only")}[config]
+    fly, _, _ = make_model(joints_preset=preset)
     world = getattr(C, cls)()
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n, device=0)
