@@ -607,21 +607,27 @@ static void collide(const omodel* m, odata* d) {
     real dc = dot3(n, cw) + dot3(n, xp) - pd;
     if (dc - m->geom_bsphere[4 * g + 3] - m->terrain[4] > margin) continue;
     if (m->geom_type[g] == GEOM_CAPSULE) {
+      /* order within a geom: the contacts with the tops of cells (ground frame) first, then those with side faces — a
+       * leg's contact sensor reports the frame of its FIRST contact, i.e. the ground's unless the leg touches walls only */
+      real pws[2][3], dwalls[2]; int wls[2];
       for (int e = 0; e < 2; e++) {
         const real* pl = (e == 0 ? m->geom_p0 : m->geom_p1) + 3 * g;
-        real pw[3]; mat_vec(pw, R, pl);
+        real* pw = pws[e]; mat_vec(pw, R, pl);
         for (int k = 0; k < 3; k++) pw[k] += xp[k];
         real r = m->geom_radius[g];
-        real dist = dot3(n, pw) - pd - r, dwall = NMF_FAR; int wall = 0;
-        if (m->terrain_type) terrain_probe(m, pw, dot3(n, pw) - pd, r, &dist, &dwall, &wall);
+        real dist = dot3(n, pw) - pd - r;
+        dwalls[e] = NMF_FAR; wls[e] = 0;
+        if (m->terrain_type) terrain_probe(m, pw, dot3(n, pw) - pd, r, &dist, &dwalls[e], &wls[e]);
         if (dist <= margin) {
           real ps[3] = {pw[0] - n[0] * r, pw[1] - n[1] * r, pw[2] - n[2] * r};
           add_contact(m, d, g, dist, ps, n);
         }
-        if (wall && dwall <= margin) {      /* a side face of the terrain: horizontal normal */
-          const real* nw = kWallNormal[wall - 1];
+      }
+      for (int e = 0; e < 2; e++) {
+        if (wls[e] && dwalls[e] <= margin) {      /* a side face of the terrain: horizontal normal */
+          const real* nw = kWallNormal[wls[e] - 1]; const real* pw = pws[e]; real r = m->geom_radius[g];
           real ps[3] = {pw[0] - nw[0] * r, pw[1] - nw[1] * r, pw[2] - nw[2] * r};
-          add_contact(m, d, g, dwall, ps, nw);
+          add_contact(m, d, g, dwalls[e], ps, nw);
         }
       }
     } else {
@@ -642,12 +648,10 @@ static void collide(const omodel* m, odata* d) {
         } else di = dot3(nb, V + 3 * i) + c0;
         if (ia < 0 || di < dmin) { ia = i; dmin = di; }
       }
-      if (iw >= 0 && dwmin <= margin) {
-        real pw[3]; mat_vec(pw, R, V + 3 * iw);
-        for (int q = 0; q < 3; q++) pw[q] += xp[q];
-        add_contact(m, d, g, dwmin, pw, kWallNormal[wall - 1]);
-      }
-      if (ia < 0 || dmin > margin) continue;
+      const int face = iw >= 0 && dwmin <= margin;      /* emitted after the hull's patch contacts (same order rule as above) */
+#define HULL_FACE() do { if (face) { real pwf[3]; mat_vec(pwf, R, V + 3 * iw); for (int q = 0; q < 3; q++) pwf[q] += xp[q]; \
+                                     add_contact(m, d, g, dwmin, pwf, kWallNormal[wall - 1]); } } while (0)
+      if (ia < 0 || dmin > margin) { HULL_FACE(); continue; }
       real thr = dmin + m->hull_skin; if (thr > margin) thr = margin;
       int sel[4] = {ia, -1, -1, -1}; int nsel = 1;
       const real* va = V + 3 * ia;
@@ -693,6 +697,8 @@ static void collide(const omodel* m, odata* d) {
         for (int q = 0; q < 3; q++) pw[q] += xp[q];
         add_contact(m, d, g, dist, pw, n);
       }
+      HULL_FACE();
+#undef HULL_FACE
 #undef VDIST
     }
   }

@@ -522,8 +522,8 @@ def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
     assert int(sim.field("stats")[0, 0].item()) == 0
 
 
-@pytest.mark.parametrize("config", ["config 2: flat", "config 2: flat, ALL_BIOLOGICAL", "config 4: gapped", "config 4: blocks",
-                                    "config 5: mixed + gait adhesion"])
+@pytest.mark.parametrize("config", ["config 2: flat", "config 2: flat, ALL_BIOLOGICAL", "flat, LEGS_ACTIVE_ONLY", "flat, ALL_POSSIBLE",
+                                    "config 4: gapped", "config 4: blocks", "config 5: mixed + gait adhesion"])
 def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod, oracle_lib, config):
     """BASELINE configs 2 / 4 / 5 at their per-GPU sizes (4096 / 1024 flies walking on flat ground or over box terrain,
     chunked launches of the LEGS_ONLY, ALL_BIOLOGICAL and ``Terrain<LEGS_ONLY>`` kernels): at three checkpoints of the walk, 24 worlds are drawn, the engine's OWN state of each is
@@ -539,10 +539,12 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
 
     cls, n, adhesion, preset = {"config 2: flat": ("FlatGroundWorld", 4096, False, "legs_only"),
                                 "config 2: flat, ALL_BIOLOGICAL": ("FlatGroundWorld", 4096, False, "all_biological"),
+                                "flat, LEGS_ACTIVE_ONLY": ("FlatGroundWorld", 4096, False, "legs_active_only"),
+                                "flat, ALL_POSSIBLE": ("FlatGroundWorld", 2048, False, "all_possible"),
                                 "config 4: gapped": ("GappedTerrainWorld", 4096, False, "legs_only"),
                                 "config 4: blocks": ("BlocksTerrainWorld", 4096, False, "legs_only"),
                                 "config 5: mixed + gait adhesion": ("MixedTerrainWorld", 1024, True, "legs_only")}[config]
-    fly, _, _ = make_model(joints_preset=preset)
+    fly = _fly("ALL_POSSIBLE") if preset == "all_possible" else make_model(joints_preset=preset)[0]
     world = getattr(C, cls)()
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n, device=0)
@@ -554,7 +556,7 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
     sim.warmup()
     blob = sim.model.to_blob()
     rng = np.random.default_rng(11)
-    cur, same, close, walls, total = 0, 0, 0, 0, 0
+    cur, same, close, walls, total, legs_seen = 0, 0, 0, 0, 0, 0
     devs = []
     for checkpoint in range(3):
         for _ in range(6):
@@ -566,6 +568,7 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
         sim.step_replay(table, ids, cur, 1); cur += 1
         torch.cuda.synchronize()
         qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+        sens = sim.field("sensordata").cpu().numpy().reshape(n, 6, 16)
         for j, w in enumerate(picks):
             ref = {}
             for prec in ("f64", "f32"):
@@ -588,6 +591,18 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                 devs.append((dev / scale, dev32 / scale))
                 assert dev < max(2e-3 * scale, 2.0 * dev32), f"{config}: world {w} at checkpoint {checkpoint}: {dev / scale:.2e} of max |qacc| (float32 oracle: {dev32 / scale:.2e})"
                 close += 1
+                # the six legs' contact sensors of the same step (count exact; net force, centroid, frame)
+                so, sh = ref["f64"].arr("sensordata").reshape(6, 16), sens[w]
+                np.testing.assert_array_equal(sh[:, 0], so[:, 0])
+                fmax = max(np.abs(so[:, 1:4]).max(), 1e-9)
+                loose = max(5e-3, 4.0 * dev32 / scale * 10)      # ill-conditioned steps: as loose as the float32 oracle's solve
+                np.testing.assert_allclose(sh[:, 1:4], so[:, 1:4], rtol=loose, atol=loose * fmax)
+                # force-weighted centroid: where two contacts of a leg share a load the split is as uncertain as the solve —
+                # no further from the float64 oracle than twice the float32 oracle is
+                so32 = ref["f32"].arr("sensordata").reshape(6, 16) if mine == ref["f32"].ints()["con_geom"] else so
+                np.testing.assert_allclose(sh[:, 7:10], so[:, 7:10], atol=max(1e-4, 2.0 * np.abs(so32[:, 7:10] - so[:, 7:10]).max()))
+                np.testing.assert_array_equal(sh[:, 10:13], so[:, 10:13].astype(np.float32))
+                legs_seen += int((so[:, 0] > 0).sum())
             fr = ref["f64"].arr("con_frame").reshape(-1, 9)
             walls += int((fr[:, 2] == 0).sum()) if len(fr) else 0
     devs = np.array(devs)
@@ -597,6 +612,61 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
     assert total == 72 and same >= 0.9 * total, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
     assert close >= 0.8 * total, f"{config}: {close} of {total} steps comparable with the float64 oracle"
     assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
-    assert float(stats[:, 0].mean()) > 3
+    assert float(stats[:, 0].mean()) > 3 and legs_seen >= 150        # the sensor blocks compared were not empty
     if "blocks" in config or "mixed" in config:
         assert walls > 0, "no sampled step touched a side face"
+
+
+def test_walking_statistics_of_the_batch_match_an_oracle_ensemble(torch_mod, oracle_lib, bench_model):
+    """Beyond the horizon where single trajectories can be compared (contact-rich walking is chaotic): the STATISTICS of
+    0.1 s of CPG walking — 4096 flies on the kernel against 48 flies on the float64 oracle with the same controller and the
+    same spread of gait phases.  Forward speed, body height, contacts per step and Newton iterations per step agree within
+    the ensemble's own standard error (x4) plus 2 %."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world = bench_model[0], bench_model[1]
+    n, n_ref, steps = 4096, 48, 1000
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    table = cpg.targets(n, 2500, device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    sim.warmup()
+    for k in range(17):                                   # one gait cycle to leave the stance the warm-up ends in
+        sim.step_replay(table, ids, 50 * k, 50)
+    x0 = sim.field("qpos")[:, 0].clone()
+    s0 = sim.field("stats_sum").clone()
+    for k in range(steps // 50):
+        sim.step_replay(table, ids, 850 + 50 * k, 50)
+    torch.cuda.synchronize()
+    ds = (sim.field("stats_sum") - s0).double().cpu().numpy()
+    eng = dict(speed=((sim.field("qpos")[:, 0] - x0) / (steps * 1e-4)).double().cpu().numpy(), height=sim.field("qpos")[:, 2].double().cpu().numpy(),
+               contacts=ds[:, 1] / steps, iters=ds[:, 2] / steps)
+    assert (ds[:, 0] == steps).all() and ds[:, 3].max() == 0
+    picks = np.linspace(0, n, n_ref, endpoint=False).astype(int)          # the same spread of phase offsets
+    rows = table[torch.as_tensor(picks, device=sim.device)].cpu().numpy()
+    ids_np = ids.cpu().numpy()
+    blob = sim.model.to_blob()
+    base = oracle_lib.Oracle(blob, "f64")
+    base.ctrl[sim.model.nu - 6:] = 1.0
+    base.step(500)                                       # = sim.warmup(): 0.05 s at the neutral targets
+    ref = dict(speed=[], height=[], contacts=[], iters=[])
+    for row in rows:
+        o = base.clone_data()
+        o.step_replay(row, ids_np, 0, 850)
+        x_start, nc, it = o.qpos[0], 0, 0
+        for k in range(steps):
+            o.step_replay(row, ids_np, 850 + k, 1)
+            st = o.ints()
+            nc += st["ncon"]; it += st["solver_iter"]
+        ref["speed"].append((o.qpos[0] - x_start) / (steps * 1e-4)); ref["height"].append(o.qpos[2])
+        ref["contacts"].append(nc / steps); ref["iters"].append(it / steps)
+    for key in ("speed", "height", "contacts", "iters"):
+        r = np.array(ref[key]); e = eng[key]
+        sem = r.std(ddof=1) / np.sqrt(len(r))
+        print(f"{key}: kernel {e.mean():.4f} (sd {e.std():.4f}), oracle ensemble {r.mean():.4f} +- {sem:.4f}")
+        assert abs(e.mean() - r.mean()) < 4 * sem + 0.02 * abs(r.mean()), key
+        assert 0.5 * r.std() < e.std() < 2.0 * r.std() + 1e-9, key
+    assert eng["speed"].mean() > 5.0                     # they do walk (mm/s)
