@@ -565,10 +565,12 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
         before = {k: sim.field(k)[torch.as_tensor(picks, device=sim.device)].cpu().numpy().astype(np.float64)
                   for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
         rows = table[torch.as_tensor(picks, device=sim.device)].cpu().numpy()
+        t_before = sim.field("time")[torch.as_tensor(picks, device=sim.device), 0].cpu().numpy()
         sim.step_replay(table, ids, cur, 1); cur += 1
         torch.cuda.synchronize()
         qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
         sens = sim.field("sensordata").cpu().numpy().reshape(n, 6, 16)
+        after = {k: sim.field(k).cpu().numpy() for k in ("qpos", "qvel", "actuator_force", "seg_xpos", "seg_xquat", "time")}
         for j, w in enumerate(picks):
             ref = {}
             for prec in ("f64", "f32"):
@@ -603,6 +605,19 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                 np.testing.assert_allclose(sh[:, 7:10], so[:, 7:10], atol=max(1e-4, 2.0 * np.abs(so32[:, 7:10] - so[:, 7:10]).max()))
                 np.testing.assert_array_equal(sh[:, 10:13], so[:, 10:13].astype(np.float32))
                 legs_seen += int((so[:, 0] > 0).sum())
+                # the rest of what the step leaves behind: poses of the named segments, actuator forces (servo forces are
+                # functions of the state alone: tight; adhesion forces follow the contacts), the integrated state, the clock
+                r64 = ref["f64"]
+                np.testing.assert_allclose(after["seg_xpos"][w], r64.arr("seg_xpos"), atol=3e-6)
+                q_ref = r64.arr("seg_xquat").reshape(-1, 4); q_ref = q_ref * np.where(q_ref[:, :1] < 0, -1.0, 1.0)
+                np.testing.assert_allclose(after["seg_xquat"][w].reshape(-1, 4), q_ref, atol=3e-6)
+                af = r64.arr("actuator_force")
+                np.testing.assert_allclose(after["actuator_force"][w], af, rtol=1e-4, atol=1e-4 * max(np.abs(af).max(), 1.0))
+                # h x twice the acceleration bar (the Euler step solves once more, with M + h B)
+                tol_v = 2.0 * max(2e-3, 2.0 * dev32 / scale) * scale * 1e-4 + 1e-4 * np.abs(r64.qvel).max()
+                np.testing.assert_allclose(after["qvel"][w], r64.qvel, atol=tol_v)
+                np.testing.assert_allclose(after["qpos"][w], r64.qpos, atol=2e-6 + 1e-4 * tol_v)
+                assert after["time"][w, 0] - t_before[j] == pytest.approx(r64.time, rel=1e-3)      # one timestep on the clock
             fr = ref["f64"].arr("con_frame").reshape(-1, 9)
             walls += int((fr[:, 2] == 0).sum()) if len(fr) else 0
     devs = np.array(devs)
