@@ -523,7 +523,8 @@ def test_closed_form_joint_and_weld_recurrences_on_the_kernel(torch_mod):
 
 
 @pytest.mark.parametrize("config", ["config 2: flat", "config 2: flat, ALL_BIOLOGICAL", "flat, LEGS_ACTIVE_ONLY", "flat, ALL_POSSIBLE",
-                                    "config 4: gapped", "config 4: blocks", "config 5: mixed + gait adhesion"])
+                                    "flat, custom skeleton", "tethered", "config 4: gapped", "config 4: blocks",
+                                    "config 5: mixed + gait adhesion"])
 def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod, oracle_lib, config):
     """BASELINE configs 2 / 4 / 5 at their per-GPU sizes (4096 / 1024 flies walking on flat ground or over box terrain,
     chunked launches of the LEGS_ONLY, ALL_BIOLOGICAL and ``Terrain<LEGS_ONLY>`` kernels): at three checkpoints of the walk, 24 worlds are drawn, the engine's OWN state of each is
@@ -541,12 +542,15 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                                 "config 2: flat, ALL_BIOLOGICAL": ("FlatGroundWorld", 4096, False, "all_biological"),
                                 "flat, LEGS_ACTIVE_ONLY": ("FlatGroundWorld", 4096, False, "legs_active_only"),
                                 "flat, ALL_POSSIBLE": ("FlatGroundWorld", 2048, False, "all_possible"),
+                                "flat, custom skeleton": ("FlatGroundWorld", 2048, False, "custom"),       # general-tree kernel
+                                "tethered": ("TetheredWorld", 4096, False, "legs_only"),                   # WELD instantiation
+
                                 "config 4: gapped": ("GappedTerrainWorld", 4096, False, "legs_only"),
                                 "config 4: blocks": ("BlocksTerrainWorld", 4096, False, "legs_only"),
                                 "config 5: mixed + gait adhesion": ("MixedTerrainWorld", 1024, True, "legs_only")}[config]
-    fly = _fly("ALL_POSSIBLE") if preset == "all_possible" else make_model(joints_preset=preset)[0]
+    fly = _fly({"all_possible": "ALL_POSSIBLE", "custom": "custom"}[preset]) if preset in ("all_possible", "custom") else make_model(joints_preset=preset)[0]
     world = getattr(C, cls)()
-    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    world.add_fly(fly, (0, 0, 1.5 if config == "tethered" else 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n, device=0)
     cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
     table = cpg.targets(n, 2500, device=sim.device, adhesion=(cpg.stance_bins(sim.model, fly), 20.0, 1.0) if adhesion else None)
@@ -627,7 +631,10 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
     assert total == 72 and same >= 0.9 * total, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
     assert close >= 0.8 * total, f"{config}: {close} of {total} steps comparable with the float64 oracle"
     assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
-    assert float(stats[:, 0].mean()) > 3 and legs_seen >= 150        # the sensor blocks compared were not empty
+    if config == "tethered":
+        assert int(stats[:, 0].max()) == 0        # legs swinging in the air: the six weld rows are the only constraints
+    else:
+        assert float(stats[:, 0].mean()) > 3 and legs_seen >= 150        # the sensor blocks compared were not empty
     if "blocks" in config or "mixed" in config:
         assert walls > 0, "no sampled step touched a side face"
 
