@@ -692,3 +692,67 @@ def test_walking_statistics_of_the_batch_match_an_oracle_ensemble(torch_mod, ora
         assert abs(e.mean() - r.mean()) < 4 * sem + 0.02 * abs(r.mean()), key
         assert 0.5 * r.std() < e.std() < 2.0 * r.std() + 1e-9, key
     assert eng["speed"].mean() > 5.0                     # they do walk (mm/s)
+
+
+def test_collapsing_flies_with_every_segment_in_contact_step_like_the_oracle(torch_mod, oracle_lib):
+    """The hybrid kernel's FULL path at size: 2048 ALL_BIOLOGICAL flies with all 69 segments as contact geoms (two passes of
+    the collision stage) and no actuators, dropped from different heights and attitudes, collapse onto legs, abdomen, head
+    and wings — contacts on the rest of the body, so the Newton loop cannot take the reduced (root + legs) problem.  At four
+    checkpoints 24 worlds' own states go to the float32 / float64 oracles and the next step is compared: contact lists
+    (up to ~30 contacts) and accelerations."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, anatomy as A
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = C.Fly(name="t")
+    fly.add_joints(A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL),
+                   neutral_pose=C.KinematicPosePreset.NEUTRAL)
+    world = C.FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.5), Rotation3D("quat", (1, 0, 0, 0)), bodysegs_with_ground_contact="all")
+    n = 2048
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    assert sim.model.ng == 69 and sim.model.nu == 0
+    g = torch.Generator(device=sim.device); g.manual_seed(3)
+    q = sim.field("qpos")
+    q[:, 2] += 0.6 * torch.rand(n, device=sim.device, generator=g)                       # drop heights 0.5 .. 1.1 mm
+    quat = torch.randn((n, 4), device=sim.device, generator=g)                           # any attitude: many land on their back or side
+    q[:, 3:7] = quat / quat.norm(dim=1, keepdim=True)
+    q[:, 2] += 1.0                                                                       # clear of the ground whatever the attitude
+    blob = sim.model.to_blob()
+    rng = np.random.default_rng(4)
+    same, close, total, most, rest_contacts = 0, 0, 0, 0, 0
+    leg_geoms = {i for i, sg in enumerate(np.asarray(sim.model["geom_sensor"])) if sg >= 0}
+    for checkpoint in range(4):
+        sim.step(250)
+        picks = rng.choice(n, size=24, replace=False)
+        sel = torch.as_tensor(picks, device=sim.device)
+        before = {k: sim.field(k)[sel].cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+        sim.step(1)
+        torch.cuda.synchronize()
+        qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+        for j, w in enumerate(picks):
+            ref = {}
+            for prec in ("f64", "f32"):
+                r = oracle_lib.Oracle(blob, prec)
+                for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+                    r.arr(k)[:] = before[k][j]
+                r.step(1)
+                ref[prec] = r
+            nc = int(stats[w, 0])
+            mine = geom[w, :nc].astype(int).tolist()
+            total += 1; most = max(most, nc)
+            rest_contacts += sum(1 for gi in mine if gi not in leg_geoms)
+            same += any(mine == r.ints()["con_geom"] for r in ref.values())
+            if mine == ref["f64"].ints()["con_geom"]:
+                scale = max(np.abs(ref["f64"].arr("qacc")).max(), 1e4)
+                dev = np.abs(qacc[w] - ref["f64"].arr("qacc")).max()
+                dev32 = np.abs(ref["f32"].arr("qacc") - ref["f64"].arr("qacc")).max() if mine == ref["f32"].ints()["con_geom"] else 0.0
+                # (3e-3: a dozen and more simultaneous contacts on a body at rest — max |qacc| sits at the 1e4 floor)
+                assert dev < max(3e-3 * scale, 2.0 * dev32), f"world {w} at checkpoint {checkpoint}: {dev / scale:.2e} of max |qacc| (float32 oracle: {dev32 / scale:.2e})"
+                close += 1
+    summary = f"collapse: contact lists equal in {same}/{total}, comparable {close}; up to {most} contacts, {rest_contacts} on head / abdomen / wings / thorax"
+    print(summary)
+    assert same >= 0.9 * total and close >= 0.8 * total, summary
+    assert most >= 10 and rest_contacts >= 100, summary
+    assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
