@@ -107,3 +107,74 @@ def test_cylinder_sphere_and_capsule_fit():
     izz = mc * r * r / 2 + ms * 2 * r * r / 5
     ixx = mc * (r * r / 4 + h * h / 3) + ms * (2 * r * r / 5 + h * h + 3 * h * r / 4)
     np.testing.assert_allclose(np.diag(I) if np.ndim(I) == 2 else I[:3], [ixx, ixx, izz], rtol=1e-12)
+
+
+def test_invweight0_and_mean_inertia_from_an_independent_route(bench_model, oracle_lib):
+    """``seg_invweight0`` (what scales every contact's regulariser R) and ``stat_meaninertia`` (what scales the solver's
+    tolerance) are MuJoCo's documented quantities: tr(J M^-1 J^T) / 3 at the segment's centre of mass for translation and
+    rotation, and the mean diagonal of M, at qpos0.  The compiler computes them with its numpy kinematics
+    (compiler/rigid.py); here they are rebuilt from the C oracle's mass matrix (CRBA) and Jacobians taken by finite
+    differences of the oracle's forward kinematics — no code shared with the compiler."""
+    fly, world, m = bench_model
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.qpos[:] = m["qpos0"]
+    o.forward()
+    nv, nb = m.nv, m.nb
+    M = o.arr("M").reshape(nv, nv).copy()
+    assert float(m["stat_meaninertia"][0]) == pytest.approx(np.mean(np.diag(M)), rel=1e-9)
+    Minv = np.linalg.inv(M)
+    seg_body, body_ipos = np.asarray(m["seg_body"]), np.asarray(m["body_ipos"]).reshape(nb, 3)
+    counts = np.bincount(seg_body, minlength=nb)
+
+    def quat_to_mat(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def pose(seg):
+        p = o.arr("seg_xpos").reshape(-1, 3)[seg].copy()
+        q = o.arr("seg_xquat").reshape(-1, 4)[seg].copy()
+        return p, quat_to_mat(q / np.linalg.norm(q))
+
+    checked = 0
+    for seg in range(len(seg_body)):
+        b = int(seg_body[seg])
+        if b == 0 or counts[b] != 1 or np.abs(np.asarray(m["seg_pos"]).reshape(-1, 3)[seg]).max() > 0:
+            continue                       # a segment that IS its dynamic body: its centre of mass is the body's
+        if not fly_is_tarsus_or_tibia(m, seg):
+            continue
+        o.qpos[:] = m["qpos0"]; o.forward()
+        p0, R0 = pose(seg)
+        com0 = p0 + R0 @ body_ipos[b]
+        root_p, root_R = o.qpos[:3].copy(), quat_to_mat(o.qpos[3:7] / np.linalg.norm(o.qpos[3:7]))
+        J = np.zeros((6, nv))
+        J[3:6, 0:3] = np.eye(3)                                   # root translation
+        for i in range(3):                                        # root rotation about the root's own axes
+            ax = root_R[:, i]
+            J[0:3, 3 + i] = ax
+            J[3:6, 3 + i] = np.cross(ax, com0 - root_p)
+        eps = 1e-6
+        for j in range(6, nv):
+            o.qpos[:] = m["qpos0"]; o.qpos[j + 1] += eps; o.forward()
+            p1, R1 = pose(seg)
+            o.qpos[:] = m["qpos0"]; o.qpos[j + 1] -= eps; o.forward()
+            p2, R2 = pose(seg)
+            J[3:6, j] = ((p1 + R1 @ body_ipos[b]) - (p2 + R2 @ body_ipos[b])) / (2 * eps)
+            dR = R1 @ R2.T                                          # rotation by 2 eps about the joint axis (if an ancestor)
+            J[0:3, j] = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / (4 * eps)
+        A = J @ Minv @ J.T
+        want = np.asarray(m["seg_invweight0"]).reshape(-1, 2)[seg]
+        assert np.trace(A[3:6, 3:6]) / 3 == pytest.approx(want[0], rel=1e-5), f"segment {seg}: translational"
+        assert np.trace(A[0:3, 0:3]) / 3 == pytest.approx(want[1], rel=1e-5), f"segment {seg}: rotational"
+        checked += 1
+    assert checked >= 12
+
+
+def fly_is_tarsus_or_tibia(m, seg):
+    """Keep the test short: the distal leg segments (tibia and the five tarsal segments of each leg: the ones that touch the
+    ground) — bodies 7 levels and more down their chains."""
+    parent = np.asarray(m["body_parent"]); b = int(np.asarray(m["seg_body"])[seg]); depth = 0
+    while b > 0:
+        b = int(parent[b]); depth += 1
+    return depth >= 6
