@@ -574,7 +574,8 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
         torch.cuda.synchronize()
         qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
         sens = sim.field("sensordata").cpu().numpy().reshape(n, 6, 16)
-        after = {k: sim.field(k).cpu().numpy() for k in ("qpos", "qvel", "actuator_force", "seg_xpos", "seg_xquat", "time")}
+        after = {k: sim.field(k).cpu().numpy() for k in ("qpos", "qvel", "actuator_force", "seg_xpos", "seg_xquat", "time", "qacc_warmstart")}
+        assert np.array_equal(after["qacc_warmstart"], qacc)          # the next step's warm start is this step's acceleration
         for j, w in enumerate(picks):
             ref = {}
             for prec in ("f64", "f32"):
@@ -608,6 +609,10 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                 so32 = ref["f32"].arr("sensordata").reshape(6, 16) if mine == ref["f32"].ints()["con_geom"] else so
                 np.testing.assert_allclose(sh[:, 7:10], so[:, 7:10], atol=max(1e-4, 2.0 * np.abs(so32[:, 7:10] - so[:, 7:10]).max()))
                 np.testing.assert_array_equal(sh[:, 10:13], so[:, 10:13].astype(np.float32))
+                np.testing.assert_array_equal(sh[:, 13:16], so[:, 13:16].astype(np.float32))       # first tangent
+                # torque about the centroid: a difference of nearly equal moments, bounded by the force error x the patch size
+                tmax = np.abs(so[:, 4:7]).max()
+                np.testing.assert_allclose(sh[:, 4:7], so[:, 4:7], rtol=4 * loose, atol=max(4 * loose * tmax, loose * fmax * 0.1))
                 legs_seen += int((so[:, 0] > 0).sum())
                 # the rest of what the step leaves behind: poses of the named segments, actuator forces (servo forces are
                 # functions of the state alone: tight; adhesion forces follow the contacts), the integrated state, the clock
