@@ -35,7 +35,7 @@ class NativeError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_replay.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h",
+    srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_replay.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h", CSRC / "nmf_dual.h",
             INCLUDE / "nmf.h", Path(__file__)]   # this file holds the compiler flags
     if os.environ.get("NMF_HIP_LIB"):
         return LIB_PATH                       # an externally built variant: nothing to compile here

@@ -448,6 +448,11 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   } else {
     d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0; d.rest_fast = 0; d.rest_pack = nullptr;
   }
+  d.solver_flags = 0;
+  if (const char* e = getenv("NMF_SOLVER")) {      // diagnostics: primal | nohist (default: contact-space solve with the active-set history)
+    const std::string v(e);
+    d.solver_flags = v == "primal" ? 1 : v == "nohist" ? 2 : 0;
+  }
   if (rc == 0) {
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::DevModel)) != hipSuccess ||
@@ -481,10 +486,15 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->csched_buf = (nmf::ChunkSched*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     p = nullptr;
-    b->handoff_stride = (model->nq + 2 * model->nv + model->nu + 6 + 63) / 64 * 64;      // state, controls, clock + 5 running sums
+    b->handoff_stride = (model->nq + 2 * model->nv + model->nu + 6 + nmf::kActHistWords + 63) / 64 * 64;      // state, controls, clock + 5 running sums, active-set history
     if (hipMalloc(&p, sizeof(unsigned long long) * (size_t)n_worlds * (size_t)b->handoff_stride) == hipSuccess) {
       (void)hipMemset(p, 0, sizeof(unsigned long long) * (size_t)n_worlds * (size_t)b->handoff_stride);   // tag 0 = no launch's
       b->allocs.push_back(p); b->handoff_buf = (unsigned long long*)p;
+    } else rc |= fail("nmf_batch_create: out of device memory");
+    p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned int) * (size_t)n_worlds * nmf::kActHistWords) == hipSuccess) {
+      (void)hipMemset(p, 0, sizeof(unsigned int) * (size_t)n_worlds * nmf::kActHistWords);
+      b->allocs.push_back(p); st.act_hist = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     p = nullptr;
     if (hipMalloc(&p, 2 * sizeof(unsigned long long)) == hipSuccess) {

@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 constexpr int kRestLevels = 6;   // levels below the root the fast passes of the hybrid kernels unroll
 constexpr int kMaxCon = 48;      // contacts per fly kept by the engine (overflow is flagged)
 constexpr int kMaxCtrl = 48;
+constexpr int kActHistWords = 64; // 16 bits per geom, 128 geoms
 constexpr float kMinVal = 1e-15f;
 
 enum { GEOM_CAPSULE = 0, GEOM_HULL = 1 };
@@ -135,6 +136,9 @@ struct DevModel {
   // named engine semantics (blob entry sem_options; flygym_amd.compiler.model.EngineSemantics), shared with the oracle
   int sem_pyramid_plain, sem_adhesion_fused, sem_sensor_contact_frame, sem_max_hull_contacts;
   int sem_terrain_walls;    // terrains: the cells' side faces collide (flygym_amd/compose/world.py::terrain_probe)
+  // diagnostics (environment NMF_SOLVER at batch creation): bit 0 = every step on the primal Newton loop, bit 1 = the contact-space
+  // solve starts from the start point's own sign pattern instead of the previous step's active set.  Same optimum either way.
+  int solver_flags;
   const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   const NMF_G float *key_qpos, *key_ctrl;
   const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
@@ -150,6 +154,9 @@ struct DevState {
       *sensordata, *time, *stats, *qacc;
   unsigned int* stats_sum; // [n_worlds][4] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps
   float* contact_geom;     // [n_worlds][kMaxCon] geom index of contact c at the launch's last step (-1 beyond ncon)
+  // [n_worlds][kActHistWords] the constraint solver's second warm start: the active pyramid rows (4 bits) of up to four contacts
+  // per geom at the end of the last step the contact-space solve ran (nmf_dual.h); zero = nothing known
+  unsigned int* act_hist;
   float* cost;             // [n_worlds] shader cycles world w took in the last stepping launch
   const int* order;        // [n_worlds] block -> world (nullptr: identity); scheduling only
   struct SchedState* sched;   // launch-duration bookkeeping of the block-order policy (nullptr: off)

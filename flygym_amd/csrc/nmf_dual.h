@@ -1,0 +1,373 @@
+// nmf_dual.h — the constraint solve in contact space (star kernels: a free root + identical leg chains).
+//
+// Same problem, same Newton iterates and same optimum as the primal loop in physics_forward (MuJoCo's Newton solver with
+// exact line search, reference src/flygym/assets/model/mujoco_globals.yaml:13-14 behind mujoco_warp.step,
+// src/flygym/warp/simulation.py:260-263) — but no iteration walks the kinematic tree.  Every Newton iterate has the form
+//     qacc = qacc_smooth + c (qacc_warmstart - qacc_smooth) + M^-1 J^T lambda
+// (a scalar c and one multiplier per pyramid row), so the loop lives on the rows, lane = row:
+//   * once per step: A = J M^-1 J^T as a Gram matrix.  The smooth solve's articulated-body factors (U / sqrt D, 1 / sqrt D
+//     per hinge and per root axis) are kept in LDS; lane (contact, direction) pushes its unit force leaf-to-root through them
+//     — u_j / sqrt(D_j) at every hinge of its leg and at the six root axes, 17 numbers — and
+//     A[row][row'] = <root parts> + [same leg] <leg parts>:  M^-1 = L^-T D^-1 L^-1, and legs meet at the root only.
+//     The vectors stay in registers (a row's vector reaches the other lanes through v_readlane); A's lower triangle goes
+//     to LDS, over Ib..W which are dead until the next step's inertia stage.
+//   * per iteration: ONE Gauss-Jordan elimination of [R + A | j0] (R = 1 / D, j0 = J qacc_smooth - aref) with the active
+//     rows (J qacc - aref < 0) as pivots and every row taking part — see dual_eliminate.  It yields the Newton target
+//     directly: active rows lambda* = -x and residual -R lambda*, inactive rows the eliminated j0.  If the target's own sign
+//     pattern is the pivot set it is the optimum (KKT) and the loop ends; otherwise the exact line search towards it (rows
+//     in registers; the Gauss term's derivatives are row-space dot products) and the next iteration.
+//   * once at the end: qacc from the summed row responses (one root-to-leaf pass over the kept factors).
+// Steps with more than kDualMaxCon contacts (A's triangle no longer fits), tethered worlds and trees with more than
+// root + legs take the primal loop.
+// Code size matters here as much as instruction count: the step kernel's hot path fills the 64 KB instruction cache a pair
+// of CUs shares, so what runs once per row is a loop, and the elimination — unrolled, its multipliers live in registers — is
+// ordered so that only the blocks a step needs are ever fetched.
+#pragma once
+
+namespace nmf {
+
+template <class TP>
+struct DualFactors {
+  float leg[TP::NLEG * TP::NDL][8];     // per leg hinge: U / sqrt(D) (6), 1 / sqrt(D), pad
+  float root[6][8];                     // the six root axes in elimination order (angular z, y, x, linear z, y, x)
+};
+template <class TP>
+__device__ __forceinline__ DualFactors<TP>& dual_factors(FlyLds<TP>& s) {
+  static_assert(sizeof(DualFactors<TP>) <= sizeof(float) * 12 * kMaxCon, "articulated-body factors do not fit c_w + c_m3");
+  return *reinterpret_cast<DualFactors<TP>*>(&s.c_w[0][0]);
+}
+// A's lower triangle, row i at i (i + 1) / 2: over Ib..W (+ dual_pad)
+template <class TP>
+__device__ __forceinline__ float* dual_a(FlyLds<TP>& s) {
+  static_assert(sizeof(float) * (4 * kDualMaxCon) * (4 * kDualMaxCon + 1) / 2 <= sizeof(s.Ib) + sizeof(s.T) + sizeof(s.W) + sizeof(s.dual_pad),
+                "A does not fit Ib..W");
+  return &s.Ib[0][0];
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += NMF_DPP(v, 0xB1);
+  v += NMF_DPP(v, 0x4E);
+  return v;
+}
+constexpr int dual_root_axis(int i) { return i < 3 ? 2 - i : 8 - i; }     // elimination order of the root (aba_solve)
+
+// Gauss-Jordan elimination of [R + A | b], left-looking, unrolled by pivot ORDINAL (the p-th active row, whatever its index):
+// only the code of the pivots a step really has is ever fetched.  Lane i keeps cq[p] = (column of pivot p, row i) / sqrt(d_p),
+// zero on the pivot's own row; the pivot row's entry at a later pivot column kk is that column's entry of row kk by symmetry
+// of the not-yet-eliminated block — v_readlane(cq[q], kk) — so column kk of the current matrix is
+//   A[.][kk] - sum_{q < p} cq[q] * cq[q](lane kk)      (two chains: the sum is a dependent sequence of multiply-adds).
+// A's column kk is one read of the stored triangle, requested a pivot ahead.  On return b holds the eliminated right-hand
+// side, diag the pivot of the lane's own row (active rows).
+template <int PMAX>
+__device__ __forceinline__ void dual_eliminate(unsigned long long rem, const float* At, float R, int lane, float& b, float& diag) {
+  float cq[PMAX];
+  const int tri_own = lane * (lane + 1) / 2;
+  auto a_of = [&](int kk) {       // A[lane][kk] out of the lower triangle (both addresses formed, then selected: no branch)
+    int lo = tri_own + kk, up = kk * (kk + 1) / 2 + lane;
+    asm("" : "+v"(lo), "+v"(up));
+    return At[lane >= kk ? lo : up];
+  };
+  int kk_next = rem ? __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1) : 0;
+  float an = a_of(kk_next);
+#define NMF_DUAL_PIVOT(P)                                                                                   \
+  if constexpr (P < PMAX) {                                                                                 \
+    if (rem == 0ull) return;                                                                                \
+    const int kk = kk_next;                                                                                 \
+    rem &= rem - 1ull;                                                                                      \
+    float col = an + (lane == kk ? R : 0.f);                                                                \
+    kk_next = rem ? __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1) : 0;                       \
+    an = a_of(kk_next);                                                                                     \
+    { float c1 = 0.f;                                                                                       \
+      _Pragma("unroll") for (int q = 0; q + 1 < P; q += 2) {                                                \
+        col = fmaf(-cq[q], readlane_f(cq[q], kk), col); c1 = fmaf(-cq[q + 1], readlane_f(cq[q + 1], kk), c1); } \
+      if constexpr ((P) % 2) col = fmaf(-cq[P - 1], readlane_f(cq[P - 1], kk), col);                        \
+      col += c1; }                                                                                          \
+    const float d = readlane_f(col, kk);                                                                    \
+    const float rs = __builtin_amdgcn_rsqf(d);                                                              \
+    diag = lane == kk ? d : diag;                                                                           \
+    const float cp = lane == kk ? 0.f : col * rs;                                                           \
+    b = fmaf(-cp, readlane_f(b, kk) * rs, b);                                                               \
+    cq[P] = cp;                                                                                             \
+  }
+#define NMF_DUAL_PIVOT8(P) NMF_DUAL_PIVOT(P) NMF_DUAL_PIVOT(P + 1) NMF_DUAL_PIVOT(P + 2) NMF_DUAL_PIVOT(P + 3) NMF_DUAL_PIVOT(P + 4) NMF_DUAL_PIVOT(P + 5) NMF_DUAL_PIVOT(P + 6) NMF_DUAL_PIVOT(P + 7)
+  NMF_DUAL_PIVOT8(0) NMF_DUAL_PIVOT8(8) NMF_DUAL_PIVOT8(16) NMF_DUAL_PIVOT8(24) NMF_DUAL_PIVOT8(32) NMF_DUAL_PIVOT8(40) NMF_DUAL_PIVOT8(48) NMF_DUAL_PIVOT8(56)
+#undef NMF_DUAL_PIVOT8
+#undef NMF_DUAL_PIVOT
+}
+
+// aref of row (contact c, pyramid row k) is expected in s.vB[4 c + k] (physics_forward puts it there).  Leaves qacc and the
+// contact wrenches (c_w: the Euler step's solve takes them as forces on the bodies, J^T f is never formed); returns the
+// number of Newton iterations (= eliminations).
+template <class TP, int NC>
+__device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls STAGE_ARG) {
+  constexpr int NDL = TP::NDL, NLEG = TP::NLEG, SW = row_width_s<TP>();
+  ncon = __builtin_amdgcn_readfirstlane(ncon);
+  walls = __builtin_amdgcn_readfirstlane((int)walls) != 0;
+  const Frame fr0 = ld_frame(s, m);
+  DualFactors<TP>& DF = dual_factors(s);
+  float* const At = dual_a(s);
+  const int n4 = 4 * ncon;
+  const bool on = lane < n4;
+  const int cc = on ? lane >> 2 : 0, k = lane & 3;
+  const int info = s.c_info[cc];
+  const int body = info_body(info);
+  const V3 r = ld3(s.c_r[cc]);
+  const float mu = s.c_mu[cc];
+  const float D = on ? s.c_D[cc] : 0.f, R = on ? __builtin_amdgcn_rcpf(s.c_D[cc]) : 0.f;
+  Frame cf = fr0;
+  if constexpr (TP::kTerrain) { if (walls) cf = contact_frame(info_fid(info), fr0); }
+  int leg = -1, dlast = -1;
+  if (body >= TP::LB0) {
+    leg = (body - TP::LB0) / TP::NBL;
+    const int lb = (body - TP::LB0) % TP::NBL;
+    static_for<TP::NBL>([&](auto I) { constexpr int l = decltype(I)::value; dlast += lb >= l ? TP::dofs(l) : 0; });
+  }
+  const int legA = leg < 0 ? 0 : leg;
+  const float smu = (k & 1) ? -mu : mu;
+  const V3 drow = cf.n + smu * (k < 2 ? cf.t1 : cf.t2);       // this row's direction: n +- mu t
+  const SV wrow = SV{cross(r, drow), drow};                   // J_row x = wrow . (twist of the body under x)
+
+  // the rows of this contact that were active at the end of the previous step (0: unknown), then the table is cleared for
+  // this step's result
+  const int hist_g = info_geom(info);
+  int hist_slot = 0;
+#pragma unroll
+  for (int o = 1; o <= 3; ++o) hist_slot += (cc >= o && info_geom(s.c_info[cc >= o ? cc - o : 0]) == hist_g) ? 1 : 0;
+  const unsigned int hist_nib = on && hist_slot < 4 ? (s.act_hist[hist_g >> 1] >> ((hist_g & 1) * 16 + 4 * hist_slot)) & 0xfu : 0u;
+  const bool hist_any = __ballot(hist_nib != 0u) != 0ull;
+  WSYNC();
+  if (lane < kActHistWords) s.act_hist[lane] = 0u;
+
+  // ---- j0 = J qacc_smooth - aref (the smooth solve left twists(qacc_smooth) in T); warm start e = qacc_ws - qacc_smooth:
+  // je = J e, eMe = e.M e
+  float j0 = 0.f, je = 0.f;
+  if (on) j0 = dot(wrow, ldsv(s.T[body])) - s.vB[lane];
+  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qacc[j] - s.qacc_smooth[j];
+  WSYNC();
+  sweep_twists(s, s.vA, s.T, m, lane);
+  float eMe = 0.f;
+  if (on) je = dot(wrow, ldsv(s.T[body]));
+  for (int b = lane; b < TP::NB; b += kWave) { const SV tb = ldsv(s.T[b]); eMe += dot(tb, inert_mul(s.Ib[b], tb)); }
+  for (int j = lane; j < TP::NV; j += kWave) eMe += s.arm[j] * s.vA[j] * s.vA[j];
+  float c_ws;      // the scalar c: 1 = warm start, 0 = unconstrained acceleration
+  float gauss, ccost;
+  {
+    const float x1 = j0 + je;
+    const float v_ws = on && x1 < 0.f ? 0.5f * D * x1 * x1 : 0.f, v_sm = on && j0 < 0.f ? 0.5f * D * j0 * j0 : 0.f;
+    eMe = wave_sum(eMe);
+    const float cost_ws = 0.5f * eMe + wave_sum(v_ws), cost_sm = wave_sum(v_sm);
+    if (cost_sm < cost_ws) { c_ws = 0.f; gauss = 0.f; ccost = cost_sm; } else { c_ws = 1.f; gauss = 0.5f * eMe; ccost = cost_ws - 0.5f * eMe; }
+  }
+  WSYNC();       // T, Ib are free from here: A goes there
+  STAGE(8);
+
+  // ---- responses of the unit forces, lane = (contact, direction n / t1 / t2)
+  float ur[6], ul[NDL];
+  {
+    const V3 dm = k == 0 ? cf.n : (k == 1 ? cf.t1 : cf.t2);
+    const V3 tq = cross(r, dm);
+    float w[6] = {tq.x, tq.y, tq.z, dm.x, dm.y, dm.z};
+    const lds_cptr Sl = lds_pinned(&s.S[TP::LD0 + legA * NDL][0]);
+    const lds_cptr Fl = lds_pinned(&DF.leg[legA * NDL][0]);
+    static_for<NDL>([&](auto DD) {
+      constexpr int d = NDL - 1 - decltype(DD)::value;
+      float sj[6], f[7];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sj[i] = Sl[d * SW + i];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) f[i] = Fl[d * 8 + i];
+      float pr = sj[0] * w[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) pr = fmaf(sj[i], w[i], pr);
+      const float u = d <= dlast ? pr * f[6] : 0.f;
+      ul[d] = u;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) w[i] = fmaf(-f[i], u, w[i]);
+    });
+    static_for<6>([&](auto II) {
+      constexpr int i = decltype(II)::value, e = dual_root_axis(i);
+      float f[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) f[q] = DF.root[i][q];
+      const float u = w[e] * f[6];
+      ur[i] = u;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w[q] = fmaf(-f[q], u, w[q]);
+    });
+  }
+  // this lane's row: n +- mu t, from the direction lanes of its quad (lane 0: n, 1: t1, 2: t2)
+  {
+    auto row_of = [&](float v) {
+      const float vn = NMF_DPP(v, 0x00), v1 = NMF_DPP(v, 0x55), v2 = NMF_DPP(v, 0xAA);
+      return fmaf(smu, k < 2 ? v1 : v2, vn);
+    };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ur[i] = row_of(ur[i]);
+#pragma unroll
+    for (int d = 0; d < NDL; ++d) ul[d] = row_of(ul[d]);
+  }
+  // ---- A = J M^-1 J^T, every unordered pair of rows once: in round t lane i takes the row t lanes below it (cyclically over
+  // the n4 rows), whose vector comes through ds_bpermute — n4 / 2 + 1 rounds instead of one per row
+  {
+    const int tri_own = lane * (lane + 1) / 2;
+    const int half = n4 >> 1;
+    for (int t = 0; t <= half; ++t) {
+      int kk = lane - t;
+      kk = kk < 0 ? kk + n4 : kk;
+      const int src = (on ? kk : lane) << 2;
+      auto from = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v))); };
+      float a = from(ur[0]) * ur[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) a = fmaf(from(ur[i]), ur[i], a);
+      float bl = from(ul[0]) * ul[0];
+#pragma unroll
+      for (int d = 1; d < NDL; ++d) bl = fmaf(from(ul[d]), ul[d], bl);
+      a += __builtin_amdgcn_ds_bpermute(src, leg) == leg ? bl : 0.f;
+      int lo = tri_own + kk, up = kk * (kk + 1) / 2 + lane;
+      asm("" : "+v"(lo), "+v"(up));
+      if (on) At[lane >= kk ? lo : up] = a;
+    }
+  }
+  WSYNC();
+  STAGE(9);
+
+  // ---- Newton iterations on the rows
+  float jar = fmaf(c_ws, je, j0), lam = 0.f;
+  const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
+  int iters = 0;
+  // The first active set: the rows that were active at the end of the previous step, for the contacts that existed then (same
+  // geom, same place among the geom's contacts) — an active row's residual -R lambda is small, so the start point's own sign
+  // pattern mispredicts exactly the rows that matter; the previous solution's set is right about nine times in ten, and then
+  // one elimination proves it.  A guess that does not even give a descent direction falls back to the start point's pattern.
+  bool guessed = hist_any && !(m.solver_flags & 2);
+  unsigned long long mask = guessed ? __ballot(on && (hist_nib ? ((hist_nib >> k) & 1) != 0 : jar < 0.f)) : __ballot(on && jar < 0.f);
+  for (int iter = 0; iter < m.max_iter; ++iter) {
+    iters = iter + 1;
+    // Gauss-Jordan on [R + A | j0]: pivots = active rows in index order, every row takes part
+    float b = j0, diag = 1.f;
+    dual_eliminate<4 * NC>(mask, At, R, lane, b, diag);
+    const bool act = (mask >> lane) & 1ull;
+    const float lam_t = act ? -b * __builtin_amdgcn_rcpf(diag) : 0.f;
+    const float jar_t = act ? -R * lam_t : b;
+    const unsigned long long tmask = __ballot(on && jar_t < 0.f);
+    STAGE(10);
+    if (tmask == mask) {       // the target satisfies its own active set: the optimum
+      lam = lam_t; jar = jar_t; c_ws = 0.f;
+      break;
+    }
+    // line search towards the target
+    const float jv = jar_t - jar, dlam = lam_t - lam, dc = -c_ws;
+    float g1, g2, s1, s2;
+    {
+      const float Alam = jar - j0 - c_ws * je, Adlam = fmaf(c_ws, je, jv);
+      const bool neg = on && jar < 0.f;
+      const float S1 = wave_sum(on ? je * lam : 0.f), S2 = wave_sum(on ? je * dlam : 0.f);
+      const float S3 = wave_sum(on ? dlam * Alam : 0.f), S4 = wave_sum(on ? dlam * Adlam : 0.f);
+      s1 = wave_sum(neg ? D * jar * jv : 0.f); s2 = wave_sum(neg ? D * jv * jv : 0.f);
+      g1 = c_ws * dc * eMe + dc * S1 + c_ws * S2 + S3;
+      g2 = dc * dc * eMe + 2.f * dc * S2 + S4;
+    }
+    STAGE(11);
+    float alpha = 0.f, lo = 0.f, hi = -1.f;
+    for (int ls = 0; ls < 30; ++ls) {
+      float d1 = s1 + g1, d2 = s2 + g2;
+      if (ls > 0) {
+        const float x = fmaf(alpha, jv, jar);
+        const bool neg = on && x < 0.f;
+        d1 = wave_sum(neg ? D * x * jv : 0.f) + g1 + alpha * g2;
+        d2 = wave_sum(neg ? D * jv * jv : 0.f) + g2;
+      }
+      if (d2 <= 0.f || d1 == 0.f) break;
+      if (d1 < 0.f) lo = alpha; else hi = alpha;
+      float next = alpha - d1 / d2;
+      bool bisected = false;
+      if (hi >= 0.f && (next <= lo || next >= hi)) { next = 0.5f * (lo + hi); bisected = true; }
+      const bool moved = on && ((fmaf(alpha, jv, jar) < 0.f) != (fmaf(next, jv, jar) < 0.f));
+      const bool same = !bisected && !__any(moved);
+      const float change = fabsf(next - alpha);
+      alpha = next;
+      if (same || change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
+    }
+    STAGE(12);
+    if (alpha <= 0.f) {
+      if (!guessed) break;
+      guessed = false; mask = __ballot(on && jar < 0.f);
+      continue;
+    }
+    const bool was_guess = guessed;      // a step towards a guessed set's target is not a Newton step: its size says nothing about convergence
+    guessed = false;
+    lam = fmaf(alpha, dlam, lam); c_ws = fmaf(alpha, dc, c_ws); jar = fmaf(alpha, jv, jar);
+    const float newccost = wave_sum(on && jar < 0.f ? 0.5f * D * jar * jar : 0.f);
+    const float dgauss = alpha * (g1 + 0.5f * alpha * g2);
+    const float improvement = (ccost - newccost) - dgauss;
+    gauss += dgauss; ccost = newccost;
+    STAGE(13);
+    if (!was_guess && (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
+    mask = __ballot(on && jar < 0.f);
+  }
+  // the final active set, for the next step
+  {
+    const unsigned long long fin = __ballot(on && jar < 0.f);
+    if (on && k == 0 && hist_slot < 4) {
+      const unsigned int nib = (unsigned int)(fin >> (4 * cc)) & 0xfu;
+      atomicOr(&s.act_hist[hist_g >> 1], nib << ((hist_g & 1) * 16 + 4 * hist_slot));
+    }
+  }
+  STAGE(9);
+
+  // ---- qacc = qacc_smooth + c e + M^-1 J^T lambda: the rows' responses summed per hinge (root axes: wave sums; leg hinges:
+  // LDS adds, the rows of a leg are few), then root-to-leaf over the factors
+  float* const acc = s.vB;                       // [NLEG * NDL leg hinges | 6 root axes]
+  static_assert(NLEG * NDL + 6 <= 3 * TP::NV, "hinge sums do not fit vB..vD");
+  for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
+  WSYNC();
+  {
+    const float l0 = on ? lam : 0.f;
+    if (l0 != 0.f && leg >= 0) {
+#pragma unroll
+      for (int d = 0; d < NDL; ++d) if (d <= dlast) (void)__hip_atomic_fetch_add(&acc[leg * NDL + d], l0 * ul[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    float rsum[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rsum[i] = wave_sum(l0 * ur[i]);
+    if (lane < 6) {
+      float v = rsum[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) v = lane == i ? rsum[i] : v;
+      acc[NLEG * NDL + lane] = v;
+    }
+  }
+  WSYNC();
+  {
+    const LaneRole L = lane_role<TP>(lane);
+    float a = 0.f, xw[6];
+    static_for<6>([&](auto II) {
+      constexpr int i = 5 - decltype(II)::value, e = dual_root_axis(i);
+      const float xe = DF.root[i][6] * (acc[NLEG * NDL + i] - grp8_sum(L.mask * DF.root[i][L.rr] * a));
+      xw[e] = xe;
+      a = L.rr == e ? a + xe : a;
+    });
+    if (lane < 3) {
+      s.qacc[lane] = s.qacc_smooth[lane] + c_ws * s.vA[lane] + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
+      s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + c_ws * s.vA[3 + lane] + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
+    }
+    const int jb = TP::LD0 + L.lg * NDL;
+    static_for<NDL>([&](auto DD) {
+      constexpr int d = decltype(DD)::value;
+      const float xj = DF.leg[L.lg * NDL + d][6] * (acc[L.lg * NDL + d] - grp8_sum(L.mask * DF.leg[L.lg * NDL + d][L.rr] * a));
+      s.qacc[jb + d] = s.qacc_smooth[jb + d] + c_ws * s.vA[jb + d] + xj;
+      a = fmaf(xj, s.S[jb + d][L.rr], a);
+    });
+  }
+  WSYNC();      // the factors are dead: c_w takes the contact wrenches again
+  STAGE(14);
+  // ---- contact wrenches and J^T f
+  {
+    const float f = on && jar < 0.f ? -D * jar : 0.f;
+    const V3 F = v3(quad_sum(f * drow.x), quad_sum(f * drow.y), quad_sum(f * drow.z));
+    if (on && k == 0) stsv(s.c_w[cc], SV{cross(r, F), F});
+  }
+  WSYNC();
+  return iters;
+}
+
+}  // namespace nmf

@@ -158,6 +158,21 @@ constexpr int conflict_free_width(int rows_per_leg, int nleg) {
 }
 template <class TP> constexpr int row_width_s() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NDL, TP::NLEG) : 6; else return 6; }
 template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6; else return 6; }
+// Star kernels without a rest-of-body tree solve the constraints in contact space (nmf_dual.h) while a step has at most
+// kDualMaxCon contacts (A's triangle in LDS).  NMF_NO_DUAL: development switch, every step on the primal loop.
+constexpr int kDualMaxCon = 12;
+#ifdef NMF_NO_DUAL
+template <class TP> inline constexpr bool kDual = false;
+#else
+template <class TP> inline constexpr bool kDual = has_cm3<TP>();
+#endif
+template <class TP> constexpr int dual_pad_floats() {
+  if constexpr (kDual<TP>) {
+    constexpr int need = (4 * kDualMaxCon) * (4 * kDualMaxCon + 1) / 2;      // A's lower triangle (nmf_dual.h)
+    constexpr int have = TP::NB * 11 + 2 * TP::NB * (TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6);
+    return need > have ? need - have : 0;
+  } else return 0;
+}
 
 // What the non-inlined stages (kinematics, collision) need of the model, staged in LDS once per launch.  Inside a
 // non-inlined function the model is a generic reference: every field would be a flat load (full memory latency, and the
@@ -198,8 +213,9 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float S[TP::NV][row_width_s<TP>()];
   // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap).  Rows are 11
   // floats apart where LDS allows: lane = body loops then hit 32 different banks (stride 10: bodies b and b + 16 collide)
-  float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
   float Isym[kHasIsym<TP> ? TP::NB : 1][kHasIsym<TP> ? 21 : 1];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
+  // (Ib, T, W are contiguous and 16-byte aligned: the contact-space solve (nmf_dual.h) keeps its per-contact response vectors there)
+  alignas(kDual<TP> ? 16 : 4) float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
   static_assert(7 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
   __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
@@ -209,14 +225,18 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // body twists / wrenches, contiguous (12 NB floats).  Velocities live in W until the bias stage; the
   // kinematics stage borrows T..W for relative transforms; the ABA borrows it for its leg -> root hand-off
   float T[TP::NB][row_width_tw<TP>()], W[TP::NB][row_width_tw<TP>()];
+  float dual_pad[dual_pad_floats<TP>()];      // what the contact-space solve's scratch needs beyond Ib..W (skeletons with few bodies)
   // dof_armature / dof_damping, staged once per launch.  The LDS-bound kernels (hybrid, tree) keep only the armature:
   // damping enters one passive-force pass and the Euler solve of a step, which read it from the model (dof_damp())
   float arm[TP::NV], damp[kHasCm3<TP> ? TP::NV : 1];
   float dlt[kHasCm3<TP> ? TP::NV : 1];   // armature + timestep * damping: the diagonal term of the Euler step's solve (star kernels)
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
-  float xpos_root[3];
-  float c_w[kMaxCon][7];     // contact wrenches (6 used; odd stride: lane = contact stores hit 32 different banks)
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
+  alignas(kDual<TP> ? 16 : 4) float xpos_pad_[kDual<TP> ? 1 : 0];
+  float xpos_root[3];
+  // (c_w, c_m3 are contiguous and 16-byte aligned: between the smooth solve and the end of the contact-space solve they hold
+  // the articulated-body factors of the mass matrix, DualFactors)
+  float c_w[kMaxCon][7];     // contact wrenches (6 used; odd stride: lane = contact stores hit 32 different banks)
   // star kernels: the 3x3 pyramid-coefficient matrix of every contact for its active rows (nn, n1, n2, 11, 22), written
   // with the active-row mask; the hybrid kernels have no LDS to spare and rebuild it from the mask
   float c_m3[kHasCm3<TP> ? kMaxCon : 1][kHasCm3<TP> ? 5 : 1];
@@ -245,6 +265,8 @@ struct __align__(16) FlyLds : TreeLds<TP> {
       return k < kInCw ? &c_w[0][0] + 27 * k : &T[0][0] + sizeof(AbaHandoff<TP>) / sizeof(float) + 27 * (k - kInCw);
     } else return this->slot[k];
   }
+  // the constraint solver's second warm start (DevState::act_hist), carried from step to step: 16 bits per geom
+  unsigned int act_hist[kDual<TP> ? kActHistWords : 0];
   int ncon, overflow, iters;
   int nwall;                            // contacts of this step that touch a terrain side face (frame id != 0)
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
@@ -933,7 +955,13 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     if (lane < nsel && nh + lane < kMaxCon) {
       const int vi = lane == 0 ? ia : lane == 1 ? s1 : lane == 2 ? s2 : s3;
       const V3 v = ld3(V + 3 * vi);
-      const float dist = vdist(v);
+      // The deepest vertex keeps the distance the scan found for it.  Over a terrain a second evaluation is not guaranteed to
+      // agree with the scan's: a vertex within rounding of a cell boundary can be a top contact for one inlined copy of the
+      // probe and a side face's (top distance kFar) for the other — round 3 stored that kFar as the contact's distance, a
+      // contact 1e30 mm away that the solver then carried as a row.  The other patch vertices were selected with a distance
+      // <= thr: one that comes back larger is the same tie and is stored at thr.
+      float dist = lane == 0 ? dmin : vdist(v);
+      if (rough && lane != 0 && !(dist <= margin)) dist = fminf(dmin + hull_skin, margin);
       const V3 pw = mat_vec(R, v) + xp;
       X.info[nh + lane] = (g0 + g) | (lane << 8) | (b << 12);
       X.dist[nh + lane] = dist;
@@ -1247,7 +1275,7 @@ __device__ __forceinline__ void aba_step(float (&IA)[6], float& pA, const float*
 // rows, so U / D needs no mask either.
 template <bool SHADOW0>
 __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const float* sj, float sr, float mask, float delta,
-                                                float tauj, float& UDout, float& uDout) {
+                                                float tauj, float& UDout, float& uDout, float& Uraw, float& invDraw) {
   f2 a01 = mk2(IA[0], IA[1]), a23 = mk2(IA[2], IA[3]), a45 = mk2(IA[4], IA[5]);
   f2 acc = a01 * mk2(sj[0], sj[1]);
   acc = __builtin_elementwise_fma(a23, mk2(sj[2], sj[3]), acc);
@@ -1265,6 +1293,7 @@ __device__ __forceinline__ void aba_step_scaled(float (&IA)[6], float& pA, const
   IA[0] = a01.x; IA[1] = a01.y; IA[2] = a23.x; IA[3] = a23.y; IA[4] = a45.x; IA[5] = a45.y;
   pA += k * u;
   UDout = SHADOW0 ? k : mask * k; uDout = u * invD;
+  Uraw = U; invDraw = invD;
 }
 // LDS pointer whose value the optimizer may not look through: the accesses made from it carry their (small, constant)
 // offsets in the instruction — a ds_read2 reaches 255 dwords — instead of one address add per access pair, which is what
@@ -1277,11 +1306,19 @@ __device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
   return q;
 }
 
+template <class TP> struct DualFactors;
+template <class TP> __device__ __forceinline__ DualFactors<TP>& dual_factors(FlyLds<TP>& s);
+
 template <class TP, bool WELD>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
-                          const GModel& m, int lane) {
+                          const GModel& m, int lane, bool store = false, bool withF = false) {
   if constexpr (!TP::kStar) { tree_aba_solve<TP, WELD>(s, tau_id, x_id, withK, hdamp, m, lane); return; } else {
   withK = __builtin_amdgcn_readfirstlane((int)withK) != 0;          // wave-uniform: scalar branches, no exec masking
+  // store: keep the factors (U / sqrt D, 1 / sqrt D per hinge and root axis) in LDS for the contact-space solve (nmf_dual.h)
+  store = kDual<TP> && __builtin_amdgcn_readfirstlane((int)store) != 0;
+  // withF: the contact wrenches in c_w act on their bodies as external forces (the Euler step's solve after a contact-space
+  // constraint solve: J^T f is never projected onto the dofs)
+  withF = kDual<TP> && __builtin_amdgcn_readfirstlane((int)withF) != 0;
   const float* tau = s.vec(tau_id);
   float* x = s.vec(x_id);
   Frame fr{};
@@ -1319,8 +1356,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     KL.ia = __float_as_int(q[9]); KL.ib = __float_as_int(q[10]);
   }
   int cs[TP::NBL + 1], cs_root0 = 0, cs_root1 = 0;                         // contact ranges of the leg's bodies / the root
-  static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK ? s.body_cstart[b0 + l] : 0; });
-  if (withK) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
+  static_for<TP::NBL + 1>([&](auto I) { constexpr int l = decltype(I)::value; cs[l] = withK || withF ? s.body_cstart[b0 + l] : 0; });
+  if (withK || withF) { cs_root0 = s.body_cstart[0]; cs_root1 = s.body_cstart[1]; }
   // hybrid: the rest of the body (head, abdomen, wings, ...) is eliminated level by level first; its children-of-root
   // hand their articulated inertias to the root below through s.slot
   const bool red = rest_reduced(s);
@@ -1348,7 +1385,10 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
         float row[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
-        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
+        if constexpr (kDual<TP>) {
+          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= s.c_w[c][L.rr];
+        }
+        if (withK) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
         add6(IA, row);
       } else {
         add_inertia_row(IA, s, b, IM);
@@ -1361,7 +1401,14 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     const float sown = Sown[d * SW];
     const float sr = kShadow0 ? sown : L.mask * sown;
     if constexpr (kKeepS) Sreg[d] = sown;        // shadow rows: zero (kShadow0), else row 5's (same T word, same value)
-    aba_step_scaled<kShadow0>(IA, pA, sj, sr, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d]);
+    float Uraw, invDraw;
+    aba_step_scaled<kShadow0>(IA, pA, sj, sr, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d], Uraw, invDraw);
+    if constexpr (kDual<TP>) {
+      if (store) {      // rows 0..5: U / sqrt D; lanes 6, 7 of the group: 1 / sqrt D
+        const float rs = __builtin_sqrtf(invDraw);
+        dual_factors(s).leg[L.lg * TP::NDL + d][L.r < 6 ? L.r : 6] = L.r < 6 ? Uraw * rs : rs;
+      }
+    }
   });
 #pragma unroll
   for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
@@ -1387,6 +1434,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       if constexpr (WELD) static_for<6>([&](auto I) { constexpr int i = decltype(I)::value; row[i] += L.rr == i ? s.weldD[i] : 0.f; });
     }
     pA = 0.f;
+    if constexpr (kDual<TP>) {
+      if (withF) for (int c = cs_root0; c < cs_root1; ++c) pA -= s.c_w[c][L.rr];
+    }
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
       add6(row, H.legIA[k][L.rr]);
@@ -1438,6 +1488,12 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       { const float bb[6] = {b0, b1, b2, b3, b4, b5}; fma6(IA, -k, bb); }
       pA += k * u;
       Ur[e] = kShadow0 ? k : L.mask * k; ur[e] = u * invD;
+      if constexpr (kDual<TP>) {
+        if (store) {
+          const float rs = __builtin_sqrtf(invD);
+          dual_factors(s).root[i][L.r < 6 ? L.r : 6] = L.r < 6 ? U * rs : rs;
+        }
+      }
     });
   }
   // ---- forward sweep: root (linear x, y, z, then angular x, y, z), then down the leg
@@ -1547,6 +1603,8 @@ __device__ float constraint_cost(const ContactRegs& c, const WeldRow& wr) {
 // body) and the dofs project.  SEEDED: W already holds per-body wrenches (I_b T_b of the search direction) that ride
 // the same sweep, so  alpha M search − JT df  costs one pass.  The active-row mask of c.jar goes to c_info for the ABA.
 template <class TP, bool SEEDED, class Emit>
+__device__ __forceinline__ void contact_sweep(FlyLds<TP>& s, float seed_scale, const GModel& m, int lane, Emit&& emit);
+template <class TP, bool SEEDED, class Emit>
 __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs& c, const WeldRow& wr, const Frame& fr,
                                                 const float* rows, float weld_row, float seed_scale,
                                                 const GModel& m, int lane, bool walls, Emit&& emit) {
@@ -1569,6 +1627,11 @@ __device__ __forceinline__ void contact_project(FlyLds<TP>& s, const ContactRegs
     }
   }
   WSYNC();
+  contact_sweep<TP, SEEDED>(s, seed_scale, m, lane, emit);
+}
+// the second half of contact_project: the contact wrenches are in c_w (and the tether's in weld_w)
+template <class TP, bool SEEDED, class Emit>
+__device__ __forceinline__ void contact_sweep(FlyLds<TP>& s, float seed_scale, const GModel& m, int lane, Emit&& emit) {
   if constexpr (!TP::kStar) {
     tree_sweep_project(s, s.W, m, lane, [&](int b, SV w) {
       SV own = SEEDED ? seed_scale * w : SV{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
@@ -1623,6 +1686,10 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
   for (int k = 0; k < 4; k++) f[k] = c.jar[k] < 0.f ? -sign * c.D * c.jar[k] : 0.f;
 }
 
+}  // namespace nmf
+#include "nmf_dual.h"
+namespace nmf {
+
 // The control-table row of the NEXT step, requested from inside the current one.  Every non-inlined stage function begins
 // with `s_waitcnt vmcnt(0)` (the calling convention: a callee cannot know what is in flight), so a load issued right before
 // a call — round 2 requested the row at the top of the step, just ahead of the kinematics call — is waited for at once, HBM
@@ -1636,7 +1703,7 @@ struct CtrlPrefetch {
 
 // ------------------------------------------------------------------ the step
 template <class TP, bool WELD>
-__device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, CtrlPrefetch& pf STAGE_ARG) {
+__device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, CtrlPrefetch& pf STAGE_ARG) {
   // hybrid kernels: per-lane addresses are rebuilt every step instead of living across the item loop — hoisted, they left
   // the 132-dof kernel 19 spilled registers and a dozen scratch reloads per step (the 72-dof kernels have the registers to
   // keep them: recomputing costs those 2 %)
@@ -1817,13 +1884,29 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   });
   STAGE(6);
   // ---- unconstrained acceleration
-  aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane);
+  // contact-space solve (nmf_dual.h) for steps with 1..kDualMaxCon contacts: the smooth solve keeps its factors for it
+  const bool dual = kDual<TP> && !WELD && ncon > 0 && ncon <= kDualMaxCon && !(m.solver_flags & 1);
+  aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane, dual);
   contact_reload(c, s, lane);
   STAGE(7);
 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
-  if (ncon == 0 && !WELD) {
+  bool solved = false;
+  if constexpr (kDual<TP> && !WELD) {
+    if (dual) {
+      if (c.on) {      // reference accelerations of the rows: lane = row from here on
+#pragma unroll
+        for (int k = 0; k < 4; k++) s.vB[4 * lane + k] = c.aref[k];
+      }
+      WSYNC();
+      iters = dual_solve<TP, kDualMaxCon>(s, m, lane, ncon, walls STAGE_PASS);
+      solved = true;
+    }
+  }
+  if constexpr (kDual<TP>) { if (!solved && lane < kActHistWords) s.act_hist[lane] = 0u; }      // nothing known for the next step
+  if (solved) {
+  } else if (ncon == 0 && !WELD) {
     for (int j = lane; j < s.nv(); j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
     WSYNC();
   } else {
@@ -2076,16 +2159,21 @@ __device__ void physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   }
   WSYNC();
   STAGE(17);
+  return solved;     // the constraint forces are contact wrenches in c_w (contact-space solve), not J^T f in vD
 }
 
 template <class TP, bool WELD>
-__device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane STAGE_ARG) {
+__device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane, bool wrenches STAGE_ARG) {
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
-  for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
-  WSYNC();
-  aba_solve<TP, WELD>(s, V_A, V_B, false, h, m, lane);
+  wrenches = __builtin_amdgcn_readfirstlane((int)wrenches) != 0;
+  if (wrenches) aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_B, false, h, m, lane, false, true);
+  else {
+    for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
+    WSYNC();
+    aba_solve<TP, WELD>(s, V_A, V_B, false, h, m, lane);
+  }
   for (int j = lane; j < s.nv(); j += kWave) s.qvel[j] += h * s.vB[j];
   WSYNC();
   if (lane == 0) {
@@ -2148,8 +2236,10 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
     // lanes 0..5: the clock and what the world's items have accumulated so far (steps, contacts, iterations, overflow steps —
     // as integer bit patterns — and cycles): one store; the launch's final item adds them to the world's counters
     if (lane < 6) st_tagged(&hb[nq + 2 * nv + m.nu + lane], lane == 0 ? time : carry, tag);
+    if constexpr (kDual<TP>) { if (lane < (m.ng + 1) / 2) st_tagged(&hb[nq + 2 * nv + m.nu + 6 + lane], __uint_as_float(s.act_hist[lane]), tag); }
     return;
   }
+  if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < (m.ng + 1) / 2 ? s.act_hist[lane] : 0u; }
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
@@ -2280,6 +2370,7 @@ __global__ void __launch_bounds__(kWave) nmf_reset_kernel(const DevModel* __rest
   write_poses(s, m, st, w, lane);
   write_outputs(s, m, st, w, lane, 0.f, true);
   if (lane < 4) st.stats_sum[4 * (size_t)w + lane] = 0u;
+  if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = 0u;
   if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
 }
 
@@ -2356,6 +2447,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           for (int i = ln; i < nv; i += kWave) { s.qvel[i] = ld_tagged(&hb[nq + i], want, ok); s.qacc[i] = ld_tagged(&hb[nq + nv + i], want, ok); }
           for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_tagged(&hb[nq + 2 * nv + i], want, ok);
           carry = lane < 6 ? ld_tagged(&hb[nq + 2 * nv + m.nu + ln], want, ok) : 0.f;     // lane 0: the clock; 1..5: running sums
+          if constexpr (kDual<TP>) { s.act_hist[lane] = lane < (m.ng + 1) / 2 ? __float_as_uint(ld_tagged(&hb[nq + 2 * nv + m.nu + 6 + ln], want, ok)) : 0u; }
           if (!__any(!ok)) break;            // wave-uniform: every granule carried the expected tag
           __builtin_amdgcn_s_sleep(8);
         }
@@ -2367,6 +2459,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
         }
         for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
+        if constexpr (kDual<TP>) { if (lane < kActHistWords) s.act_hist[lane] = st.act_hist[(size_t)w * kActHistWords + ln]; }
         time = ld_state(&st.time[w]);
       }
       WSYNC();
@@ -2380,8 +2473,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           WSYNC();
         }
         STAGE(0);
-        physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, pf STAGE_PASS);     // pure outputs: the launch's last step only
-        physics_integrate<TP, WELD>(s, m, lane STAGE_PASS);
+        const bool wrenches = physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, pf STAGE_PASS);     // pure outputs: the launch's last step only
+        physics_integrate<TP, WELD>(s, m, lane, wrenches STAGE_PASS);
         STAGE(15);
         time += m.timestep;
         sum_con += (unsigned int)s.ncon; sum_it += (unsigned int)s.iters; sum_of += (unsigned int)s.overflow;

@@ -596,7 +596,7 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                 dev = np.abs(qacc[w] - ref["f64"].arr("qacc")).max()
                 dev32 = np.abs(ref["f32"].arr("qacc") - ref["f64"].arr("qacc")).max() if mine == ref["f32"].ints()["con_geom"] else 0.0
                 devs.append((dev / scale, dev32 / scale))
-                assert dev < max(2e-3 * scale, 2.0 * dev32), f"{config}: world {w} at checkpoint {checkpoint}: {dev / scale:.2e} of max |qacc| (float32 oracle: {dev32 / scale:.2e})"
+                assert dev < max(2e-3 * scale, 2.0 * dev32), f"{config}: world {w} at checkpoint {checkpoint}: {dev / scale:.2e} of max |qacc| (float32 oracle: {dev32 / scale:.2e}); {nc} contacts, {int(stats[w, 1])} iterations (oracle {ref['f64'].ints()['solver_iter']})"
                 close += 1
                 # the six legs' contact sensors of the same step (count exact; net force, centroid, frame)
                 so, sh = ref["f64"].arr("sensordata").reshape(6, 16), sens[w]
@@ -647,8 +647,10 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
 def test_walking_statistics_of_the_batch_match_an_oracle_ensemble(torch_mod, oracle_lib, bench_model):
     """Beyond the horizon where single trajectories can be compared (contact-rich walking is chaotic): the STATISTICS of
     0.1 s of CPG walking — 4096 flies on the kernel against 48 flies on the float64 oracle with the same controller and the
-    same spread of gait phases.  Forward speed, body height, contacts per step and Newton iterations per step agree within
-    the ensemble's own standard error (x4) plus 2 %."""
+    same spread of gait phases.  Forward speed, body height and contacts per step agree within the ensemble's own standard
+    error (x4) plus 2 %.  Newton iterations are no longer a shared statistic: since round 4 the kernel's contact-space solve
+    starts from the previous step's active set (csrc/nmf_dual.h) and reaches the same optimum in fewer eliminations than the
+    oracle's primal Newton has iterations — asserted as such."""
     torch = torch_mod
     from flygym_amd import HIPSimulation
     from flygym_amd.controllers import TripodCPG
@@ -690,7 +692,9 @@ def test_walking_statistics_of_the_batch_match_an_oracle_ensemble(torch_mod, ora
             nc += st["ncon"]; it += st["solver_iter"]
         ref["speed"].append((o.qpos[0] - x_start) / (steps * 1e-4)); ref["height"].append(o.qpos[2])
         ref["contacts"].append(nc / steps); ref["iters"].append(it / steps)
-    for key in ("speed", "height", "contacts", "iters"):
+    print(f"iterations per step: kernel {eng['iters'].mean():.3f}, oracle {np.mean(ref['iters']):.3f}")
+    assert 1.0 <= eng["iters"].mean() <= np.mean(ref["iters"]) + 0.05
+    for key in ("speed", "height", "contacts"):
         r = np.array(ref[key]); e = eng[key]
         sem = r.std(ddof=1) / np.sqrt(len(r))
         print(f"{key}: kernel {e.mean():.4f} (sd {e.std():.4f}), oracle ensemble {r.mean():.4f} +- {sem:.4f}")

@@ -1,0 +1,125 @@
+"""Round 4: the contact-space constraint solve (csrc/nmf_dual.h) against the primal Newton loop and the oracle, and the
+collision fix it exposed.  GPU tests, through the C ABI."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+def _walkers(n, solver, torch):
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world, _ = make_model()
+    old = os.environ.get("NMF_SOLVER")
+    if solver: os.environ["NMF_SOLVER"] = solver
+    else: os.environ.pop("NMF_SOLVER", None)
+    try:
+        sim = HIPSimulation(world, n_worlds=n, device=0)          # the switch is read when the batch is created
+    finally:
+        if old is None: os.environ.pop("NMF_SOLVER", None)
+        else: os.environ["NMF_SOLVER"] = old
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(n, 2500, device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    return sim, table, ids
+
+
+def test_contact_space_solve_reaches_the_primal_loops_optimum(torch_mod, oracle_lib):
+    """The same 2048 walking flies on three builds of the solver — contact-space with the active-set history (default),
+    contact-space from the start point's own sign pattern (NMF_SOLVER=nohist: MuJoCo's Newton iterates, row by row) and the
+    primal loop (NMF_SOLVER=primal) — stepped from IDENTICAL states: one optimum, so the accelerations agree to float32
+    accuracy, the contact-space ones no further from the float64 oracle than the primal ones; the history only shortens the
+    way (fewer eliminations than Newton iterations), it never changes where it ends."""
+    torch = torch_mod
+    n = 2048
+    sims = {k: _walkers(n, k, torch) for k in ("", "nohist", "primal")}
+    lead, table, ids = sims[""]
+    lead.warmup(); lead.step_replay(table, ids, 0, 850)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    blob = lead.model.to_blob()
+    it_sum = {k: 0.0 for k in sims}
+    worst = {k: 0.0 for k in sims}
+    cur = 850
+    for checkpoint in range(6):
+        lead.step_replay(table, ids, cur, 37); cur += 37
+        state = {k: lead.field(k).clone() for k in keys}
+        qacc = {}
+        for name, (sim, _, _) in sims.items():
+            if sim is not lead:
+                for k in keys: sim.field(k)[:] = state[k]
+            if name != "": sim.step_replay(table, ids, cur, 1)
+        lead.step_replay(table, ids, cur, 1); cur += 1
+        torch.cuda.synchronize()
+        for name, (sim, _, _) in sims.items():
+            qacc[name] = sim.field("qacc").cpu().numpy().astype(np.float64)
+            it_sum[name] += float(sim.field("stats")[:, 1].double().mean().item())
+        nc = {name: sim.field("stats")[:, 0].cpu().numpy() for name, (sim, _, _) in sims.items()}
+        assert np.array_equal(nc[""], nc["primal"]) and np.array_equal(nc[""], nc["nohist"])          # same collision stage, same state
+        scale = np.abs(qacc["primal"]).max(axis=1)
+        for name in ("", "nohist"):
+            dev = np.abs(qacc[name] - qacc["primal"]).max(axis=1) / scale
+            assert np.median(dev) < 2e-4 and np.quantile(dev, 0.99) < 2e-3 and dev.max() < 2e-2, (name, np.sort(dev)[-4:])      # the stated tolerance (the primal loop is the less accurate of the two)
+        for w in np.random.default_rng(checkpoint).choice(n, size=12, replace=False):
+            r = oracle_lib.Oracle(blob, "f64")
+            for k in keys: r.arr(k)[:] = state[k][w].cpu().numpy().astype(np.float64)
+            r.step_replay(table[w].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
+            if r.ints()["ncon"] != int(nc[""][w]): continue
+            a = r.arr("qacc")
+            for name in sims:
+                worst[name] = max(worst[name], float(np.abs(qacc[name][w] - a).max() / np.abs(a).max()))
+    its = {k: v / 6 for k, v in it_sum.items()}
+    print("iterations per step", {k or "default": round(v, 2) for k, v in its.items()}, "worst |qacc - oracle| / max", {k or "default": f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 2e-3
+    assert worst[""] < 2.0 * worst["primal"] + 1e-4                 # the contact-space solve is at least as accurate
+    assert its[""] < 0.75 * its["nohist"] and abs(its["nohist"] - its["primal"]) < 0.3      # same Newton iterates without the history
+
+
+def test_hull_vertex_on_a_cell_edge_keeps_its_scan_distance(torch_mod, oracle_lib):
+    """A state from a walk over BlocksTerrainWorld where a tarsus hull's deepest vertex sits within rounding of a cell edge.
+    Round 3's collision stage evaluated that vertex's distance twice; the second evaluation took the other side of the tie
+    (a side face owns the vertex: top distance kFar) and stored a contact 1e30 mm away, which the primal loop carried as a
+    forever-inactive row — the step's accelerations were off by a factor of two, unnoticed under the percentage bars.  The
+    contact-space solve, started from the previous step's active set, turned it into a NaN and so found it.  Two steps from
+    the saved state (the first one builds the history): contact list and accelerations of the second like the oracle's."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.utils.math import Rotation3D
+
+    d = np.load(GOLD / "terrain_edge_tie_state.npz")
+    fly = make_model(joints_preset="legs_only")[0]
+    world = C.BlocksTerrainWorld()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    sim = HIPSimulation(world, n_worlds=4, device=0)
+    ids = sim.replay_ids(fly.name)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    rows = torch.as_tensor(d["rows"], device=sim.device)[None].repeat(4, 1, 1).contiguous()
+    for k in keys: sim.field(k)[:] = torch.as_tensor(d[k], device=sim.device)[None, :]
+    sim.step_replay(rows, ids, 0, 1)
+    state = {k: sim.field(k)[0].cpu().numpy().astype(np.float64) for k in keys}
+    sim.step_replay(rows, ids, 1, 1)
+    torch.cuda.synchronize()
+    qacc = sim.field("qacc").cpu().numpy(); stats = sim.field("stats").cpu().numpy(); geom = sim.field("contact_geom").cpu().numpy()
+    assert np.isfinite(qacc).all() and stats[0, 1] < 10
+    r = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+    for k in keys: r.arr(k)[:] = state[k]
+    r.step_replay(d["rows"], ids.cpu().numpy(), 1, 1)
+    nc = int(stats[0, 0])
+    assert nc == r.ints()["ncon"] == 7 and geom[0, :nc].astype(int).tolist() == r.ints()["con_geom"]
+    assert min(r.arr("con_dist")) > -0.05                         # every contact a real one
+    a = r.arr("qacc")
+    assert np.abs(qacc[0] - a).max() < 2e-3 * np.abs(a).max()
