@@ -78,8 +78,9 @@ def parse_args(argv=None):
                     help="flat = BASELINE config 2; gapped/blocks = config 4; mixed = config 5 (build-defined height maps)")
     ap.add_argument("--cpg-adhesion", type=float, default=0.0, metavar="ON",
                     help="drive leg adhesion from the CPG: control ON in stance, 1 (the reference's minimum) in swing (config 5)")
-    ap.add_argument("--joint-preset", choices=["legs_only", "legs_active_only", "all_biological"], default="legs_only",
-                    help="skeleton: the benchmark's LEGS_ONLY (default) or the full-body ALL_BIOLOGICAL (hybrid kernel)")
+    ap.add_argument("--joint-preset", choices=["legs_only", "legs_active_only", "all_biological", "all_possible"], default="legs_only",
+                    help="skeleton: the benchmark's LEGS_ONLY (default), the 48-dof LEGS_ACTIVE_ONLY, or the full-body ALL_BIOLOGICAL / "
+                         "ALL_POSSIBLE (hybrid kernels)")
     ap.add_argument("--odor", action="store_true", help="evaluate the four odor sensors every control tick (config 5)")
     ap.add_argument("--vision", choices=["off", "resample", "render"], default="off",
                     help="BASELINE config 3: per vision tick (every --vision-every physics steps = one launch) both 512 x 450 eye "
@@ -93,6 +94,8 @@ def parse_args(argv=None):
                     help="do not re-run the workload under rocprofv3 --pmc after the timed region (N = 1): roofline.traffic / "
                          ".issue then come from the committed passes under profiles/ and say so")
     ap.add_argument("--cpu-steps", type=int, default=200000)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="do not append the short runs of BASELINE configs 1, 3, 4 and 5 (`other_configs`, N = 1 only)")
     return ap.parse_args(argv)
 
 
@@ -251,7 +254,7 @@ def live_counters(spl, kernel, launches=6, budget_s=240.0, passes=None):
             skip = drop[key] if "=" not in a else 0
             continue
         argv.append(a)
-    inner = [sys.executable, str(Path(__file__).resolve()), *argv, "--no-cpu-baseline", "--no-live-counters", "--steps-per-launch", str(spl),
+    inner = [sys.executable, str(Path(__file__).resolve()), *argv, "--no-cpu-baseline", "--no-live-counters", "--no-other-configs", "--steps-per-launch", str(spl),
              "--steps", str(spl * launches), "--warmup", "0", "--repeats", "1"]
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.perf_counter()
@@ -290,7 +293,7 @@ def idle_rank(args, torch, dist, device, total_worlds, shard_sizes, rank, world_
     order the working ranks issue them, and nothing else."""
     from flygym_amd.sharding import ObsGather
 
-    nj = {"legs_only": 66, "legs_active_only": 42, "all_biological": 126}[args.joint_preset]
+    nj = PRESET_NV[args.joint_preset] - 6
     gather = ObsGather(0, nj, 42, device, total_worlds=total_worlds, shard_sizes=shard_sizes)
     empty = [torch.zeros((0, w), dtype=torch.float32, device=device) for w in (7 + nj, 6 + nj, 48, 96)]
 
@@ -312,11 +315,13 @@ def idle_rank(args, torch, dist, device, total_worlds, shard_sizes, rank, world_
     dist.destroy_process_group()
 
 
-def main():
-    args = parse_args()
-    env_ws = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and env_ws is None:
-        raise SystemExit(self_spawn(args))
+PRESET_NV = {"legs_only": 72, "legs_active_only": 48, "all_biological": 132, "all_possible": 210}
+
+
+def run(args, primary=True):
+    """One workload, settled, timed and gated.  primary: the command line's own workload (distributed set-up, live
+    counters, CPU baseline); otherwise one of the short `other_configs` runs in the same process (N = 1)."""
+    env_ws = os.environ.get("WORLD_SIZE") if primary else "1"
 
     import torch
     import torch.distributed as dist
@@ -333,7 +338,7 @@ def main():
     torch.cuda.set_device(local_rank)
     # NMF_BENCH_FORCE_DIST=1 exercises the RCCL code path (process group, all-gather, barrier, max-reduce)
     # even with one rank, so it can be validated on a single-GPU box
-    use_dist = world_size > 1 or bool(os.environ.get("NMF_BENCH_FORCE_DIST"))
+    use_dist = primary and (world_size > 1 or bool(os.environ.get("NMF_BENCH_FORCE_DIST")))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -342,7 +347,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    resident = resident_worlds({"legs_only": 72, "legs_active_only": 48, "all_biological": 132}[args.joint_preset])
+    resident = resident_worlds(PRESET_NV[args.joint_preset])
     if args.scaling == "strong":
         total_worlds = args.worlds_per_gpu
         if total_worlds < world_size and args.shard_policy == "spread":
@@ -372,8 +377,9 @@ def main():
     repeats = args.repeats if args.repeats > 0 else (1 if args.steps >= 500 else min(100, max(2, math.ceil(1000 / args.steps))))
 
     if n_local == 0:         # --shard-policy fill left this rank without worlds: it only keeps the collectives company
-        return idle_rank(args, torch, dist, torch.device("cuda", local_rank), total_worlds, shard_sizes, rank, world_size,
-                         1 + repeats * n_launches)
+        idle_rank(args, torch, dist, torch.device("cuda", local_rank), total_worlds, shard_sizes, rank, world_size,
+                  1 + repeats * n_launches)
+        return None, True, rank
     fly, world, _ = make_model(joints_preset=args.joint_preset, simplify_geom=args.simplify_geom)
     if args.terrain != "flat":
         import flygym_amd.compose as C
@@ -528,7 +534,7 @@ def main():
         issue_source = "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_* passes of this command run by the builder)" if issue else None
         live, live_note = None, ("off (--no-live-counters)" if args.no_live_counters else "N > 1: committed passes" if world_size > 1
                                  else "vision run: the live passes go to the retina kernel (`roofline`), this block uses the committed ones")
-        if not args.no_live_counters and world_size == 1 and see is None:
+        if primary and not args.no_live_counters and world_size == 1 and see is None:
             live, live_note = live_counters(spl, "nmf_step_kernel")
         if live:
             # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KiB; FETCH_SIZE under-reports wide reads by 2x on
@@ -577,6 +583,9 @@ def main():
                                 "(checker ground, sky, one sphere, the fly's own body) and resampled to 2 x 721 x 2 ommatidia readings in one kernel"}[args.vision]),
                 "control": args.workload,
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
+                # pure outputs (segment poses, contact sensors, actuator forces) are computed on a launch's last step only: a
+                # caller of nmf_step(n) cannot observe the intermediate ones (the reference's captured loop computes them every step)
+                "outputs_every_steps": spl,
                 "shard_sizes": shard_sizes, "active_gpus": active_gpus, "resident_worlds_per_gpu": resident, "shard_note": shard_note,
                 "settle_steps": {"neutral": settle_neutral, "gait": settle_gait, "warmup": args.warmup},
                 "repeats": repeats, "timed_steps_total": args.steps * repeats,
@@ -625,7 +634,7 @@ def main():
                 vt = rec.get("traffic_bytes_per_eye_frame", 0) * 2 * n_local or None
             vt_source = "profiles/vision_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder)" if vt else None
             vlive = None
-            if not args.no_live_counters and world_size == 1 and args.vision == "resample":
+            if primary and not args.no_live_counters and world_size == 1 and args.vision == "resample":
                 vlive, vnote = live_counters(spl, "nmf_retina_stream_kernel", passes=LIVE_PASSES[:2])
                 if vlive:      # wide coalesced 16-byte reads: the x2 of the guide's gfx950 correction applies in full
                     vt, vt_source = 1024.0 * (2.0 * vlive["FETCH_SIZE"] + vlive["WRITE_SIZE"]), vnote
@@ -645,7 +654,7 @@ def main():
                 out["roofline"]["rays_per_s"] = 2 * n_local * 512 * 450 / (vis_ms * 1e-3)
             out["config"]["vision"] = {"mode": args.vision, "every_steps": args.vision_every, "kernel_ms_per_tick": vis_ms,
                                        "physics_kernel_ms_per_tick": ms}
-        if not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
+        if primary and not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
             n_rows = min(n_local, host_cores())
             rows = np.ascontiguousarray(table[:n_rows, :, :42].cpu().numpy())
             out["cpu_baseline"] = cpu_baseline(sim.model.to_blob(), rows, np.arange(42, dtype=np.int32), settle_neutral,
@@ -653,6 +662,59 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    del sim
+    torch.cuda.empty_cache()
+    return out, valid, rank
+
+
+# BASELINE configs other than the headline's (config 2), as short validity-gated runs appended to the line at N = 1
+# (reference protocol: src/flygym_demo/benchmark/time_gpu_simulation.py:108-198; same settle, same gate, fewer timed steps)
+OTHER_CONFIGS = (
+    ("config 1: 1 fly, flat, kinematic replay, one step per launch", dict(worlds_per_gpu=1, workload="replay", steps_per_launch=1, steps=200)),
+    ("config 3: 4096 flies, vision every 20 steps, raw frames resampled", dict(vision="resample", steps=200)),
+    ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast", dict(vision="render", steps=200)),
+    ("config 4: 4096 flies per GPU, gapped terrain", dict(terrain="gapped", steps=200)),
+    ("config 4: 4096 flies per GPU, blocks terrain", dict(terrain="blocks", steps=200)),
+    ("config 5: 1024 flies, mixed terrain + odor sensors + gait-driven adhesion", dict(worlds_per_gpu=1024, terrain="mixed", odor=True, cpg_adhesion=20.0, steps=200)),
+)
+
+
+def other_configs(args):
+    import argparse
+
+    res = []
+    t0 = time.perf_counter()
+    for name, over in OTHER_CONFIGS:
+        a = argparse.Namespace(**vars(args))
+        a.gpus, a.scaling, a.warmup, a.repeats, a.no_cpu_baseline, a.no_live_counters = 1, "weak", 0, 0, True, True
+        a.workload, a.terrain, a.odor, a.cpg_adhesion, a.vision, a.worlds_per_gpu, a.steps_per_launch = "cpg", "flat", False, 0.0, "off", 4096, 50
+        a.joint_preset, a.simplify_geom = "legs_only", False
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            o, ok, _ = run(a, primary=False)
+            c = o["config"]
+            rec = {"config": name, "value": o["value"], "unit": o["unit"], "valid": ok, "worlds": c["total_worlds"], "steps": a.steps,
+                   "steps_per_launch": c["steps_per_launch"], "kernel_ms_per_launch": c["kernel_ms_per_launch"]["mean"],
+                   "mean_contacts": c["mean_contacts"], "mean_newton_iters": c["mean_newton_iters"]}
+            if "vision" in c:
+                rec["vision_kernel_ms_per_tick"] = c["vision"]["kernel_ms_per_tick"]
+                rec["vision_kernel"] = o["roofline"]["kernel"]
+                rec["vision_roofline_frac"] = o["roofline"]["frac"]
+        except Exception as e:      # a broken side run must never take the headline down with it
+            rec = {"config": name, "valid": False, "error": f"{type(e).__name__}: {e}"}
+        res.append(rec)
+    return res, time.perf_counter() - t0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and os.environ.get("WORLD_SIZE") is None:
+        raise SystemExit(self_spawn(args))
+    out, valid, rank = run(args, primary=True)
+    if out is not None and out["n_gpus"] == 1 and not args.no_other_configs and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        out["other_configs"], secs = other_configs(args)
+        out["other_configs_seconds"] = secs
     if rank == 0:
         sys.stdout.flush()
         try:

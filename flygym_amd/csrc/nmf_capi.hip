@@ -522,7 +522,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     hipDeviceProp_t prop;
     // flies (= single-wave workgroups) a CU holds at once: asked of the runtime for the kernel this batch will launch
     // (LDS- or register-limited, whichever binds); fallback = the LDS-limited figures of the shipped build
-    int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 6 : 5)));
+    int per_cu = topo < 2 ? 8 : (topo == 2 ? 4 : (topo == 3 ? 3 : (topo == 4 ? 8 : 5)));
     {
       const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
       if (weld && terrain) { nmf_batch_destroy(b); fail("nmf_batch_create: a tethered world has no terrain"); return nullptr; }

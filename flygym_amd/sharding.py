@@ -22,9 +22,11 @@ def shard_range(total_worlds: int, rank: int, world_size: int) -> tuple[int, int
 
 def resident_worlds(nv: int) -> int:
     """Worlds one MI355X steps at once (one wavefront per world; 256 CUs x the flies a CU holds — register- or
-    LDS-limited, ``scripts/kernel_stats.py``): 8 per CU for the leg skeletons (nv <= 72), 7 for ALL_BIOLOGICAL (nv 132),
-    5 for ALL_POSSIBLE (nv 210) and the general-tree kernels' 4 / 3 rounded to the smaller figure."""
-    return 2048 if nv <= 72 else 1792 if nv <= 132 else 1280 if nv <= 210 else 768
+    LDS-limited, ``scripts/kernel_stats.py``): 8 per CU for the leg skeletons (nv <= 72) and ALL_BIOLOGICAL (nv 132; 7 until
+    round 3's commit aab7290), 5 for ALL_POSSIBLE (nv 210) and the general-tree kernels' 4 / 3 rounded to the smaller
+    figure.  The library asks the occupancy API for the kernel it will launch (``nmf_batch_create``); this table is the
+    host-side estimate used before a batch exists."""
+    return 2048 if nv <= 132 else 1280 if nv <= 210 else 768
 
 
 def shard_plan(total_worlds: int, world_size: int, resident: int = 2048, policy: str = "fill") -> list[int]:

@@ -186,7 +186,7 @@ def test_shard_plan_fills_gpus_to_residency():
     ceil(total / resident) ranks and leaves the others without worlds; `spread` is shard_range."""
     from flygym_amd.sharding import resident_worlds, shard_plan
 
-    assert resident_worlds(72) == 2048 and resident_worlds(48) == 2048 and resident_worlds(132) == 1792
+    assert resident_worlds(72) == 2048 and resident_worlds(48) == 2048 and resident_worlds(132) == 2048 and resident_worlds(210) == 1280
     assert shard_plan(1024, 8) == [1024] + [0] * 7                       # BASELINE config 5: one GPU holds them all
     assert shard_plan(4096, 8) == [2048, 2048] + [0] * 6
     assert shard_plan(5000, 8) == [1667, 1667, 1666] + [0] * 5
