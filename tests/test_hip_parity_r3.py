@@ -178,7 +178,8 @@ def test_all_biological_batch_follows_the_oracle(torch_mod, oracle_lib):
         bases[prec].ctrl[nu - 6:] = 1.0
         bases[prec].step(300)
     ids_np = ids.cpu().numpy()
-    errs, errs64, same_contacts = [], [], []
+    errs, errs64, same_contacts, spread = [], [], [], []
+    rng = np.random.default_rng(9)
     for row, w in zip(rows, picks):
         ref = {}
         for prec in ("f64", "f32"):
@@ -189,12 +190,22 @@ def test_all_biological_batch_follows_the_oracle(torch_mod, oracle_lib):
         nc = int(stats[w, 0])
         same_contacts.append(any(nc == r.ints()["ncon"] and geom[w, :nc].astype(int).tolist() == r.ints()["con_geom"]
                                  for r in ref.values()))
-    errs, errs64 = np.array(errs), np.array(errs64)
-    # same bars as the LEGS_ONLY batch test (tests/test_hip_parity_r2.py): the bulk to rounding against whichever oracle
-    # the engine's float32 rounding follows, every world bounded, contact lists equal to an oracle's
-    assert (errs < 5e-5).mean() >= 0.8, np.sort(errs)[-6:]
-    assert np.median(errs64) < 1e-5 and errs64.max() < 5e-3, np.sort(errs64)[-6:]
-    assert np.mean(same_contacts) >= 0.8
+        sp = 0.0        # the float64 oracle jittered at float32's scale (see tests/test_hip_parity_r2.py): this world's sensitivity
+        for _ in range(3):
+            o = bases["f64"].clone_data()
+            for k0 in range(0, 150, 5):
+                o.qpos[7:] += 3e-7 * rng.standard_normal(o.nq - 7)
+                o.step_replay(row, ids_np, k0, 5)
+            sp = max(sp, float(np.abs(o.qpos - ref["f64"].qpos).max()))
+        spread.append(sp)
+    errs, errs64, spread, same_contacts = np.array(errs), np.array(errs64), np.array(spread), np.array(same_contacts)
+    # as the LEGS_ONLY batch test (tests/test_hip_parity_r2.py), round 4: a world is followed to rounding against whichever
+    # oracle the engine's float32 rounding follows, or the float64 oracle itself lands as far off when jittered
+    explained = (errs < 5e-5) | (errs < 5.0 * spread)
+    print(f"followed {int((errs < 5e-5).sum())} / {len(errs)}, chaotic {int(((errs >= 5e-5) & explained).sum())}, unexplained {int((~explained).sum())}")
+    assert explained.all(), (np.sort(errs)[-6:], spread[np.argsort(errs)[-6:]])
+    assert (errs < 5e-5).sum() >= len(errs) - 3 and np.median(errs64) < 1e-5 and errs64.max() < 5e-3, np.sort(errs64)[-6:]
+    assert same_contacts[errs < 5e-5].all()
     assert stats[:, 0].mean() > 3
 
 
@@ -632,9 +643,11 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
     devs = np.array(devs)
     print(f"{config}: contact lists equal in {same}/{total}, comparable {close}; qacc deviation / max |qacc|: median {np.median(devs[:, 0]):.1e}, "
           f"max {devs[:, 0].max():.1e} (float32 oracle: median {np.median(devs[:, 1]):.1e}, max {devs[:, 1].max():.1e}); wall contacts {walls}")
-    assert np.median(devs[:, 0]) < 5e-4
-    assert total == 72 and same >= 0.9 * total, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
-    assert close >= 0.8 * total, f"{config}: {close} of {total} steps comparable with the float64 oracle"
+    # round 4: the bars are what the test sees (72 / 72 lists on every configuration, median deviation 1e-4), with one step
+    # of slack for a contact within rounding of its margin — not the 90 % / 80 % of round 3
+    assert np.median(devs[:, 0]) < 2e-4
+    assert total == 72 and same >= total - 1, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
+    assert close >= total - 2, f"{config}: {close} of {total} steps comparable with the float64 oracle"
     assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
     if config == "tethered":
         assert int(stats[:, 0].max()) == 0        # legs swinging in the air: the six weld rows are the only constraints
@@ -762,6 +775,6 @@ def test_collapsing_flies_with_every_segment_in_contact_step_like_the_oracle(tor
                 close += 1
     summary = f"collapse: contact lists equal in {same}/{total}, comparable {close}; up to {most} contacts, {rest_contacts} on head / abdomen / wings / thorax"
     print(summary)
-    assert same >= 0.9 * total and close >= 0.8 * total, summary
+    assert same >= total - 1 and close >= total - 2, summary       # (round 3: 90 % / 80 %; observed 96 / 96)
     assert most >= 10 and rest_contacts >= 100, summary
     assert bool(torch.isfinite(sim.field("qpos")).all()) and int(sim.field("stats_sum")[:, 3].max()) == 0
