@@ -48,6 +48,9 @@ for p in (ROOT, ROOT / "oracle"):
 # qacc_warmstart 72, write qpos 73 + qvel 72 + qacc_warmstart 72  = 482 floats.
 BYTES_PER_ENV_STEP = 1928
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# eye renderer: arithmetic of one ray of the common case: theta^2 3 flop, the two lens polynomials 15 fma, the
+# direction 6 fma + 3 mul, the ground hit and checker parity ~14, the byte selection / run sums are integer work
+EYE_FLOP_PER_RAY = 3 + 30 + 15 + 14
 VALU_PEAK_TFLOPS = 157.3       # same guide: FP32 vector peak (256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz)
 OBS_DIM = 66 + 66 + 42 + 96    # joint angles, joint velocities, actuator forces, contact sensors
 SETTLE_NEUTRAL_S = 0.05        # reference Simulation.warmup(duration_s=0.05)
@@ -411,6 +414,8 @@ def run(args, primary=True):
 
         eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(8.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]))
         see = lambda: eyes.render()
+        # rays cast per eye view: the 16-pixel chunks of the raw image that touch an ommatidium (the rest of the frame is never rendered)
+        EYE_RAYS_PER_VIEW = int((eyes.retina.id_map.reshape(-1, 16) > 0).any(axis=1).sum()) * 16
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
     if args.workload == "replay":
         table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
@@ -639,9 +644,15 @@ def run(args, primary=True):
                 if vlive:      # wide coalesced 16-byte reads: the x2 of the guide's gfx950 correction applies in full
                     vt, vt_source = 1024.0 * (2.0 * vlive["FETCH_SIZE"] + vlive["WRITE_SIZE"]), vnote
             ach = per_launch / (vis_ms * 1e-3) / 1e9
+            peak, unit = HBM_PEAK_GBS, "GB/s"
+            if args.vision == "render":
+                # compute-bound: the arithmetic a ray of the common case needs (EYE_FLOP_PER_RAY) x the rays
+                # cast, against the f32 vector peak
+                n_rays = 2 * n_local * EYE_RAYS_PER_VIEW
+                ach, peak, unit = n_rays * EYE_FLOP_PER_RAY / (vis_ms * 1e-3) / 1e12, VALU_PEAK_TFLOPS, "TFLOP/s"
             out["roofline"] = {
-                "bound": "hbm" if args.vision == "resample" else "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": vt,
+                "bound": "hbm" if args.vision == "resample" else "valu", "achieved": ach, "peak": peak, "unit": unit,
+                "frac": ach / peak, "traffic": vt,
                 "traffic_source": vt_source, "counters": "live" if vlive else "replayed",
                 "kernel": "nmf_retina_stream_kernel" if args.vision == "resample" else "nmf_eye_kernel",
                 "kernel_ms_per_launch": vis_ms, "eye_frames_per_launch": 2 * n_local,
@@ -651,7 +662,9 @@ def run(args, primary=True):
                          "ray-casts the views instead of reading frames: compute-bound, the HBM figure is the readings written only"),
             }
             if args.vision == "render":
-                out["roofline"]["rays_per_s"] = 2 * n_local * 512 * 450 / (vis_ms * 1e-3)
+                out["roofline"]["rays_per_s"] = 2 * n_local * EYE_RAYS_PER_VIEW / (vis_ms * 1e-3)
+                out["roofline"]["rays_per_view"] = EYE_RAYS_PER_VIEW
+                out["roofline"]["algorithmic_flop_per_ray"] = EYE_FLOP_PER_RAY
             out["config"]["vision"] = {"mode": args.vision, "every_steps": args.vision_every, "kernel_ms_per_tick": vis_ms,
                                        "physics_kernel_ms_per_tick": ms}
         if primary and not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only

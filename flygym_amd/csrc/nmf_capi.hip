@@ -90,6 +90,8 @@ struct nmf_batch {
   int resident_waves = 0;        // step-kernel waves the device holds at once
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned long long* handoff_buf = nullptr;   // chunk hand-off granules (nmf_step_kernel); allocated with the batch
+  // eye renderer: the visit plan of the last id map it was called with ([0] chunks that touch an ommatidium, [1] all chunks)
+  struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0; float fov = 0.f; int n_groups[2] = {0, 0}; int* visit[2] = {nullptr, nullptr}; float* cones[2] = {nullptr, nullptr}; float* chunk_cones[2] = {nullptr, nullptr}; } eye_plan;
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
@@ -726,6 +728,84 @@ extern "C" int nmf_retina_resample(const uint8_t* images_dev, const int16_t* id_
 
 extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 
+// Visit plan of the eye renderer: the chunks (16 consecutive raw pixels) to render, sorted by 32 x 32-pixel tile and cut
+// into groups of 64 (one wave's turn), each group with the bounding cone of its rays in the camera frame (axis, cos and
+// sin of the half-angle) — so that a wave can decide per group what it can see at all.  Built on the host once per id map.
+static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w, float fov_deg) {
+  auto& P = b->eye_plan;
+  if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg) return 0;
+  const int n_pix = h * w, n_chunk = n_pix / 16;
+  std::vector<int16_t> ids((size_t)n_pix);
+  HIP_OK(hipMemcpy(ids.data(), id_map_dev, sizeof(int16_t) * (size_t)n_pix, hipMemcpyDeviceToHost));
+  const double half_fov = 0.5 * fov_deg * 3.14159265358979323846 / 180.0, inv_half_h = 2.0 / h, cx = 0.5 * w, cy = 0.5 * h;
+  std::vector<double> ray((size_t)n_pix * 3);
+  for (int i = 0; i < n_pix; ++i) {
+    const int row = i / w, col = i - row * w;
+    const double u = (col + 0.5 - cx) * inv_half_h, v = (row + 0.5 - cy) * inv_half_h;
+    const double rho = std::sqrt(std::max(u * u + v * v, 1e-24)), th = rho * half_fov;
+    ray[3 * (size_t)i] = std::sin(th) * u / rho; ray[3 * (size_t)i + 1] = -std::sin(th) * v / rho; ray[3 * (size_t)i + 2] = -std::cos(th);
+  }
+  // bounding cone (axis, cos of the half-angle) of a set of pixels
+  auto cone_of = [&](const std::vector<size_t>& px, double margin, float* out) {
+    double ax = 0, ay = 0, az = 0;
+    for (size_t i : px) { ax += ray[3 * i]; ay += ray[3 * i + 1]; az += ray[3 * i + 2]; }
+    const double nrm = std::sqrt(ax * ax + ay * ay + az * az);
+    if (px.empty() || nrm < 1e-9) { out[0] = 0.f; out[1] = 0.f; out[2] = -1.f; out[3] = px.empty() ? 1.f : -1.f; return; }   // nothing / everything
+    ax /= nrm; ay /= nrm; az /= nrm;
+    double cmin = 1.0;
+    for (size_t i : px) cmin = std::min(cmin, ax * ray[3 * i] + ay * ray[3 * i + 1] + az * ray[3 * i + 2]);
+    out[0] = (float)ax; out[1] = (float)ay; out[2] = (float)az; out[3] = (float)std::max(-1.0, cmin - margin);
+  };
+  bool lens_ok = true;
+  for (int i = 0; i < n_pix; ++i) lens_ok = lens_ok && ray[3 * (size_t)i + 2] < -std::cos(2.1);
+  for (int mode = 0; mode < 2; ++mode) {
+    // chunks that stay inside one image row, by tile; the ones that wrap to the next row (their rays lie at both image
+    // edges: no common cone) in groups of their own, with one cone per piece
+    std::vector<int> plain, wrapped;
+    for (int ch = 0; ch < n_chunk; ++ch) {
+      bool on = mode == 1;
+      for (int k = 0; k < 16 && !on; ++k) on = (ids[(size_t)ch * 16 + k] & 0x7fff) != 0;
+      if (!on) continue;
+      ((ch * 16) / w == (ch * 16 + 15) / w ? plain : wrapped).push_back(ch);
+    }
+    auto key = [&](int ch) { const int row = (ch * 16) / w, col = ch * 16 - row * w; return ((long long)(row / 32) << 40) | ((long long)(col / 32) << 28) | ((long long)row << 12) | col; };
+    std::sort(plain.begin(), plain.end(), [&](int a, int c) { return key(a) < key(c); });
+    const int g_plain = (int)((plain.size() + 63) / 64), g_wrapped = (int)((wrapped.size() + 63) / 64), n_groups = g_plain + g_wrapped;
+    std::vector<int> visit((size_t)n_groups * 64, -1);
+    std::copy(plain.begin(), plain.end(), visit.begin());
+    std::copy(wrapped.begin(), wrapped.end(), visit.begin() + (size_t)g_plain * 64);
+    // per group: [0..3] cone of piece 0, [4..7] cone of piece 1 (wrapped groups), [8] 1 = two pieces; per slot: two cones
+    std::vector<float> cones((size_t)n_groups * 12, 0.f), ccones(visit.size() * 8, 0.f);
+    for (int g = 0; g < n_groups; ++g) {
+      std::vector<size_t> gp[2];
+      for (int l = 0; l < 64; ++l) {
+        const size_t sl = (size_t)g * 64 + l;
+        const int ch = visit[sl];
+        std::vector<size_t> cp[2];
+        if (ch >= 0) {
+          const int row0 = (ch * 16) / w;
+          for (int k = 0; k < 16; ++k) { const size_t i = (size_t)ch * 16 + k; const int pc = (int)(i / w) == row0 ? 0 : 1; cp[pc].push_back(i); gp[pc].push_back(i); }
+        }
+        cone_of(cp[0], 1e-5, &ccones[8 * sl]); cone_of(cp[1], 1e-5, &ccones[8 * sl + 4]);
+      }
+      cone_of(gp[0], 1e-4, &cones[(size_t)g * 12]); cone_of(gp[1], 1e-4, &cones[(size_t)g * 12 + 4]);
+      cones[(size_t)g * 12 + 8] = g >= g_plain ? 1.f : 0.f;
+      cones[(size_t)g * 12 + 9] = lens_ok ? 1.f : 0.f;      // [9]: every ray of the IMAGE within the range of the kernel's lens polynomials
+    }
+    void* pv = nullptr; void* pc = nullptr; void* pcc = nullptr;
+    if (hipMalloc(&pv, sizeof(int) * visit.size()) != hipSuccess || hipMalloc(&pc, sizeof(float) * cones.size()) != hipSuccess ||
+        hipMalloc(&pcc, sizeof(float) * ccones.size()) != hipSuccess)
+      return fail("nmf_eye_render: out of device memory for the visit plan");
+    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(pcc);
+    HIP_OK(hipMemcpy(pv, visit.data(), sizeof(int) * visit.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pc, cones.data(), sizeof(float) * cones.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pcc, ccones.data(), sizeof(float) * ccones.size(), hipMemcpyHostToDevice));
+    P.visit[mode] = (int*)pv; P.cones[mode] = (float*)pc; P.chunk_cones[mode] = (float*)pcc; P.n_groups[mode] = n_groups;
+  }
+  P.id_map = id_map_dev; P.h = h; P.w = w; P.fov = fov_deg;
+  return 0;
+}
+
 extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int32_t* capsule_seg_dev,
                               const float* capsule_geom_dev, const int16_t* id_map_dev,
                               const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
@@ -770,10 +850,12 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
     A.rgb[3][c] = c < 3 ? p->wall_rgb[c] : 0; A.rgb[4][c] = c < 3 ? p->body_rgb[c] : 0;
     for (int s = 0; s < nmf::kMaxSpheres; ++s) A.rgb[5 + s][c] = c < 3 ? p->sphere_rgb[s][c] : 0;
   }
+  if (build_eye_plan(b, id_map_dev, p->height, p->width, p->fov_deg) != 0) return -1;
+  const int mode = frames_out_dev ? 1 : 0;
   hipLaunchKernelGGL(nmf::nmf_eye_kernel, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A,
                      b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,
                      capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),
-                     reinterpret_cast<const int*>(static_cast<const char*>(plan_dev) + (size_t)(p->height * p->width / 16) * 16),
+                     b->eye_plan.visit[mode], b->eye_plan.cones[mode], reinterpret_cast<const float4*>(b->eye_plan.chunk_cones[mode]), b->eye_plan.n_groups[mode],
                      id_map_dev, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev);
   HIP_OK(hipGetLastError());
   return 0;
@@ -822,6 +904,15 @@ extern "C" int nmf_debug_stage_cycles(unsigned long long* out, int n, int reset)
   if (hipMemcpyFromSymbol(host, HIP_SYMBOL(nmf::g_stage_cycles), sizeof(host)) != hipSuccess) return -1;
   for (int i = 0; i < n && i < NMF_NSTAGE; ++i) out[i] = host[i];
   if (reset) { unsigned long long z[NMF_NSTAGE] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(nmf::g_stage_cycles), z, sizeof(z)); }
+  return 0;
+}
+#endif
+#ifdef NMF_EYE_STATS
+extern "C" int nmf_debug_eye_stats(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nmf::g_eye_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(nmf::g_eye_stats), z, sizeof(z));
   return 0;
 }
 #endif

@@ -5,7 +5,12 @@
 // src/flygym/assets/model/legacy/flygym1_config.yaml:141-173), so the camera model and the scene are build-defined
 //  and pinned by the numpy oracle oracle/sensors_oracle.py::render_eye_frames.
 //
-// One workgroup per (world, eye).  A lane owns 16 consecutive raw pixels (the resample's chunk, same run plan):
+// One workgroup per (world, eye); a wave takes GROUPS of 64 chunks that form a compact patch of the image (visit plan built
+// once per id map by nmf_capi.hip: chunks sorted by 32 x 32-pixel tile, each group with the bounding cone of its rays in
+// the camera frame).  Per group the wave decides once — lane = object — which body capsules and spheres its cone can see
+// and whether any ray of it points below the horizon; most groups see sky or ground only and skip the rest.  (Round 3
+// tested all 55 capsules per lane and chunk: 41 of ~230 instructions per ray, and cast every ray against the ground.)
+// A lane owns 16 consecutive raw pixels (the resample's chunk, same run plan):
 // per pixel it builds the equidistant-fisheye ray, rotates it into the world, intersects the ground — the flat plane
 // (checker texture) or, on the build-defined terrains, the relief the physics collides with (constant-height cells of
 // h(x, y) followed cell by cell, side walls included) — the spheres and the fly's own body (the visible segments as
@@ -17,7 +22,10 @@
 
 namespace nmf {
 
-constexpr int kEyeThreads = 512;
+#ifdef NMF_EYE_STATS
+__device__ unsigned long long g_eye_stats[8];
+#endif
+constexpr int kEyeThreads = 256;
 constexpr int kMaxSpheres = 8;
 constexpr int kMaxCaps = 64;            // capsules of the fly's own body an eye can see
 constexpr int kMaxTerrainCells = 64;    // cells a ray is followed through the relief before the far field is taken as flat
@@ -78,10 +86,13 @@ __device__ __forceinline__ V3 eye_ray(int row, int col, float cx, float cy, floa
   return v3(st * u * rinv, -st * v * rinv, -ct);          // x right, y up, looks along -z
 }
 
-__global__ void __launch_bounds__(kEyeThreads)
+#ifndef NMF_EYE_WAVES
+#define NMF_EYE_WAVES 6
+#endif
+__global__ void __launch_bounds__(kEyeThreads) __attribute__((amdgpu_waves_per_eu(NMF_EYE_WAVES, NMF_EYE_WAVES)))
 nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __restrict__ seg_xquat, int nseg,
                const float* __restrict__ spheres, const int* __restrict__ cap_seg, const float* __restrict__ cap_geom,
-               const u32x4* __restrict__ plan, const int* __restrict__ active,
+               const u32x4* __restrict__ plan, const int* __restrict__ visit, const float* __restrict__ cones, const float4* __restrict__ chunk_cones, int n_groups,
                const int16_t* __restrict__ id_map,
                const uint8_t* __restrict__ pale, const float* __restrict__ inv_norm, int n_omm,
                uint8_t* __restrict__ frames_out, float* __restrict__ omm_out) {
@@ -92,6 +103,9 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   // 9-11 pb, 12 pa.pa - r^2, 13 pb.pb - r^2, 14-16 unit direction to the bounding sphere's centre, 17 / 18 cos / sin of its
   // angular radius (+ margin)
   __shared__ float capd[kMaxCaps][20];
+  // a capsule's angular cover: three discs (unit direction, cos / sin of the angular radius) over its thirds
+  __shared__ float capc[kMaxCaps][3][5];
+  __shared__ float sphc[kMaxSpheres][8];     // unit direction to the sphere's centre, cos / sin of its angular radius (+ margin)
   const int w = blockIdx.x >> 1, eye = blockIdx.x & 1;
   for (int i = threadIdx.x; i < n_omm; i += kEyeThreads) acc[i] = 0u;
   if (threadIdx.x < A.n_spheres * 4) (&sph[0][0])[threadIdx.x] = spheres[(size_t)w * A.sphere_stride + threadIdx.x];
@@ -121,7 +135,17 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     cc = dot(oc, oc) - sph[s][3] * sph[s][3];
   }
   __syncthreads();
-  if (threadIdx.x < A.n_spheres) { float* q = sph[threadIdx.x]; q[0] = oc.x; q[1] = oc.y; q[2] = oc.z; q[3] = cc; }
+  if (threadIdx.x < A.n_spheres) {
+    float* q = sph[threadIdx.x];
+    const float r = q[3];
+    q[0] = oc.x; q[1] = oc.y; q[2] = oc.z; q[3] = cc;
+    const float dist = sqrtf(dot(oc, oc));
+    const float inv = dist > 1e-6f ? 1.0f / dist : 0.f;
+    float* c = sphc[threadIdx.x];
+    c[0] = -oc.x * inv; c[1] = -oc.y * inv; c[2] = -oc.z * inv;
+    const float ang = dist > r ? asinf(r / dist) + 0.03f : 3.2f;
+    c[3] = ang < 3.1f ? cosf(ang) : -2.f; c[4] = ang < 3.1f ? sinf(ang) : 0.f;
+  }
   if (threadIdx.x < A.n_caps) {
     const int c = threadIdx.x, cs = cap_seg[c];
     const float* g = cap_geom + 7 * c;
@@ -136,71 +160,104 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     q[0] = pa.x; q[1] = pa.y; q[2] = pa.z; q[3] = ba.x; q[4] = ba.y; q[5] = ba.z; q[6] = baba; q[7] = baoa;
     q[8] = baba * oaoa - baoa * baoa - r * r * baba;
     q[9] = pb.x; q[10] = pb.y; q[11] = pb.z; q[12] = oaoa - r * r; q[13] = dot(pb, pb) - r * r;
-    const V3 mid = 0.5f * (pa + pb);
-    const float dist = sqrtf(dot(mid, mid)), Rb = 0.5f * sqrtf(baba) + r;
-    const float inv = dist > 1e-6f ? 1.0f / dist : 0.f;
-    q[14] = mid.x * inv; q[15] = mid.y * inv; q[16] = mid.z * inv;
-    const float ang = dist > Rb ? asinf(Rb / dist) + 0.03f : 3.2f;       // camera inside the bound: always a candidate
-    q[17] = ang < 3.1f ? cosf(ang) : -2.f; q[18] = ang < 3.1f ? sinf(ang) : 0.f; q[19] = 0.f;
+    q[14] = 0.f; q[15] = 0.f; q[16] = 0.f; q[17] = 0.f; q[18] = 0.f; q[19] = 0.f;
+    // angular cover: the thirds of the axis, each inside a sphere of radius (length / 6 + r) — a leg segment's single
+    // bounding sphere covers 3-10 x its angular area
+    const float Rb = sqrtf(baba) * (1.0f / 6.0f) + r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const V3 mid = pa + ((2.f * (float)i + 1.f) * (1.0f / 6.0f)) * ba;
+      const float dist = sqrtf(dot(mid, mid));
+      const float inv = dist > 1e-6f ? 1.0f / dist : 0.f;
+      const float ang = dist > Rb ? asinf(Rb / dist) + 0.004f : 3.2f;       // camera inside the bound: always a candidate
+      float* cq = capc[c][i];
+      cq[0] = mid.x * inv; cq[1] = mid.y * inv; cq[2] = mid.z * inv;
+      cq[3] = ang < 3.1f ? cosf(ang) : -2.f; cq[4] = ang < 3.1f ? sinf(ang) : 0.f;
+    }
   }
   __syncthreads();
   uint8_t* fout = frames_out ? frames_out + (size_t)blockIdx.x * n_pix * 3 : nullptr;
-  // readings only: visit just the chunks that touch an ommatidium (43 % of the frame lies outside the lattice)
-  const int n_visit = fout ? n_chunk : active[n_chunk];
-  for (int it = threadIdx.x; it < n_visit; it += kEyeThreads) {
-    const int ch = fout ? it : active[it];
+  // the visit plan lists the chunks to render (readings only: those that touch an ommatidium — 43 % of the frame lies outside
+  // the lattice) in groups of 64, one group per wave and turn
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int grp = wave; grp < n_groups; grp += kEyeThreads / 64) {
+    const int ch = visit[grp * 64 + lane];
+    // the group's cone(s), world axes: one, or — groups of chunks that wrap to the next image row — one per piece
+    const float* cn = cones + (size_t)__builtin_amdgcn_readfirstlane(grp) * 12;
+    const bool two = cn[8] != 0.f;
+    V3 gw[2]; float g_cos[2], g_sin[2];
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const float ax = cn[4 * pc], ay = cn[4 * pc + 1], az = cn[4 * pc + 2];
+      gw[pc] = v3(R[0] * ax + R[1] * ay + R[2] * az, R[3] * ax + R[4] * ay + R[5] * az, R[6] * ax + R[7] * ay + R[8] * az);
+      g_cos[pc] = cn[4 * pc + 3]; g_sin[pc] = sqrtf(fmaxf(1.f - g_cos[pc] * g_cos[pc], 0.f));
+    }
+    // does a cone (axis a, half-angle by cos / sin) meet a disc of angular radius (qc, qs) about the unit direction q?
+    auto meets = [](V3 a, float c_cos, float c_sin, float qx, float qy, float qz, float qc, float qs) {
+      const float ca = qx * a.x + qy * a.y + qz * a.z;
+      return qc < -1.5f || ca >= c_cos * qc - c_sin * qs || c_sin * qc + c_cos * qs <= 0.f;      // (last: the two angles add up to pi or more)
+    };
+    auto cone_sees = [&](float qx, float qy, float qz, float qc, float qs) {
+      return meets(gw[0], g_cos[0], g_sin[0], qx, qy, qz, qc, qs) || (two && meets(gw[1], g_cos[1], g_sin[1], qx, qy, qz, qc, qs));
+    };
+    bool sees_cap = false;
+    if (lane < A.n_caps) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float* cq = capc[lane][i]; sees_cap = sees_cap || cone_sees(cq[0], cq[1], cq[2], cq[3], cq[4]); }
+    }
+    const unsigned long long grp_caps = __ballot(sees_cap);
+    const unsigned int grp_sph = (unsigned int)__ballot(lane < A.n_spheres && cone_sees(sphc[lane < A.n_spheres ? lane : 0][0], sphc[lane < A.n_spheres ? lane : 0][1],
+                                                                                      sphc[lane < A.n_spheres ? lane : 0][2], sphc[lane < A.n_spheres ? lane : 0][3], sphc[lane < A.n_spheres ? lane : 0][4]));
+    const bool grp_ground = gw[0].z < g_sin[0] + 1e-3f || (two && gw[1].z < g_sin[1] + 1e-3f);          // some ray of the group points below the horizon
+    if (ch < 0) continue;
     const u32x4 pl = plan[ch];
     const bool planned = !(pl.y & 0x10000u);
     int row = (ch * 16) / A.width, col = ch * 16 - row * A.width;
     unsigned int tot = 0u, sA = 0u, sAB = 0u;
-    unsigned int obytes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     // body capsules this chunk can see: its rays lie in a cone about the mean of its first and last ray — two cones for
     // a chunk that wraps to the next image row (one per row piece).  A capsule is a candidate if its bounding sphere's
     // angular disc reaches into a cone.
-    unsigned long long cand = 0ull;
-    if (A.n_caps > 0) {
-      const int row_l = (ch * 16 + 15) / A.width, col_l = ch * 16 + 15 - row_l * A.width;
-      const bool wrapped = row_l != row;
-      V3 cw[2]; float ch_cos[2], ch_sin[2];
+    unsigned long long cand = 0ull, ucand = 0ull;         // this chunk's candidates / the union over the wave's chunks
+    if (grp_caps) {
+      V3 cw[2]; float c_cos[2], c_sin[2];
 #pragma unroll
-      for (int piece = 0; piece < 2; ++piece) {
-        const int ra = piece == 0 ? row : row_l, ca_ = piece == 0 ? col : 0;
-        const int rb = piece == 0 ? row : row_l, cb_ = piece == 0 ? (wrapped ? A.width - 1 : col_l) : col_l;
-        float th0, th1;
-        const V3 c0 = eye_ray(ra, ca_, cx, cy, inv_half_h, A.half_fov, th0), c1 = eye_ray(rb, cb_, cx, cy, inv_half_h, A.half_fov, th1);
-        V3 cm = c0 + c1;
-        cm = __builtin_amdgcn_rsqf(fmaxf(dot(cm, cm), 1e-12f)) * cm;
-        cw[piece] = v3(R[0] * cm.x + R[1] * cm.y + R[2] * cm.z, R[3] * cm.x + R[4] * cm.y + R[5] * cm.z, R[6] * cm.x + R[7] * cm.y + R[8] * cm.z);
-        ch_cos[piece] = fminf(dot(cm, c0), 1.f); ch_sin[piece] = sqrtf(fmaxf(1.f - ch_cos[piece] * ch_cos[piece], 0.f));
+      for (int pc = 0; pc < 2; ++pc) {
+        if (pc == 1 && !two) break;
+        const float4 cc = chunk_cones[(grp * 64 + lane) * 2 + pc];          // bounding cone of the piece's rays, camera frame
+        cw[pc] = v3(R[0] * cc.x + R[1] * cc.y + R[2] * cc.z, R[3] * cc.x + R[4] * cc.y + R[5] * cc.z, R[6] * cc.x + R[7] * cc.y + R[8] * cc.z);
+        c_cos[pc] = cc.w; c_sin[pc] = sqrtf(fmaxf(1.f - cc.w * cc.w, 0.f));
       }
-      for (int c = 0; c < A.n_caps; ++c) {
-        const float* q = capd[c];
-        const float qx = q[14], qy = q[15], qz = q[16], qc = q[17], qs = q[18];
-        bool hit = qc < -1.5f;                                              // camera inside the bound
+      for (unsigned long long gm = grp_caps; gm; gm &= gm - 1ull) {
+        const int c = __ffsll((long long)gm) - 1;
+        bool hit = false;
 #pragma unroll
-        for (int piece = 0; piece < 2; ++piece) {
-          if (piece == 1 && !wrapped) break;
-          const float ca = qx * cw[piece].x + qy * cw[piece].y + qz * cw[piece].z;   // cos(angle between the cone axis and the capsule)
-          const float lim = ch_cos[piece] * qc - ch_sin[piece] * qs;       // cos(cone half-angle + capsule angular radius)
-          hit = hit || ca >= lim || ch_cos[piece] * qc < ch_sin[piece] * qs;
+        for (int i = 0; i < 3; ++i) {
+          const float* cq = capc[c][i];
+          hit = hit || meets(cw[0], c_cos[0], c_sin[0], cq[0], cq[1], cq[2], cq[3], cq[4]) || (two && meets(cw[1], c_cos[1], c_sin[1], cq[0], cq[1], cq[2], cq[3], cq[4]));
         }
         if (hit) cand |= 1ull << c;
+        if (__any(hit)) ucand |= 1ull << c;
       }
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float theta;
-      const V3 dc = eye_ray(row, col, cx, cy, inv_half_h, A.half_fov, theta);
-      const float dx = dc.x, dy = dc.y, dz = dc.z;
-      const V3 d = v3(R[0] * dx + R[1] * dy + R[2] * dz, R[3] * dx + R[4] * dy + R[5] * dz, R[6] * dx + R[7] * dy + R[8] * dz);
-      // branch-free: ground plane (checker), then the spheres; the nearest positive hit wins
-      const float t = -hz * __builtin_amdgcn_rcpf(d.z);
-      const bool ghit = d.z < 0.f && t > 0.f;
-      const float gx = (cam.x + t * d.x) * inv_cs, gy = (cam.y + t * d.y) * inv_cs;
-      const int par = ((int)floorf(ghit ? gx : 0.f) + (int)floorf(ghit ? gy : 0.f)) & 1;
-      int mat = ghit ? 1 + par : 0;
-      float tbest = ghit ? t : INFINITY;
-      if (A.terrain_kind != 0 && d.z < 0.f) {
+#ifdef NMF_EYE_STATS
+    if (lane == 0) { atomicAdd(&g_eye_stats[0], 1ull); atomicAdd(&g_eye_stats[1], (unsigned long long)__popcll(grp_caps)); atomicAdd(&g_eye_stats[2], (unsigned long long)__popcll(ucand));
+                     atomicAdd(&g_eye_stats[4], grp_ground ? 1ull : 0ull); atomicAdd(&g_eye_stats[5], (unsigned long long)__popc(grp_sph)); atomicAdd(&g_eye_stats[6], ucand ? 1ull : 0ull); }
+    atomicAdd(&g_eye_stats[3], (unsigned long long)__popcll(cand));
+#endif
+    // what a world-axis ray sees: ground plane (checker) where the group's cone reaches below the horizon, then the spheres
+    // and capsules the group can see; the nearest positive hit wins
+    auto scene = [&](const V3 d) {
+      int mat = 0;
+      float tbest = INFINITY;
+      if (grp_ground) {
+        const float t = -hz * __builtin_amdgcn_rcpf(d.z);
+        const bool ghit = d.z < 0.f && t > 0.f;
+        const float gx = (cam.x + t * d.x) * inv_cs, gy = (cam.y + t * d.y) * inv_cs;
+        const int par = ((int)floorf(ghit ? gx : 0.f) + (int)floorf(ghit ? gy : 0.f)) & 1;
+        mat = ghit ? 1 + par : 0;
+        tbest = ghit ? t : INFINITY;
+      }
+      if (grp_ground && A.terrain_kind != 0 && d.z < 0.f) {
         // relief: follow the ray through the cells of h(x, y) from the highest level down; a cell entered below its level
         // is a side wall, else its top is hit if the ray reaches the level before leaving the cell
         const float rdz = 1.0f / d.z;
@@ -224,16 +281,18 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           tc = t_out;
         }
       }
-#pragma unroll 1
-      for (int s = 0; s < A.n_spheres; ++s) {
+      for (unsigned int sm = grp_sph; sm; sm &= sm - 1u) {
+        const int s = __ffs((int)sm) - 1;
         const float b = sph[s][0] * d.x + sph[s][1] * d.y + sph[s][2] * d.z;
         const float disc = b * b - sph[s][3];
         const float ts = -b - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
         const bool ok = disc > 0.f && ts > 0.f && ts < tbest;
         tbest = ok ? ts : tbest; mat = ok ? 5 + s : mat;
       }
-      for (unsigned long long cm = cand; cm; cm &= cm - 1ull) {
-        const float* q = capd[__ffsll((long long)cm) - 1];
+      for (unsigned long long cm = ucand; cm; cm &= cm - 1ull) {
+        const int ci = __ffsll((long long)cm) - 1;
+        if (!((cand >> ci) & 1ull)) continue;
+        const float* q = capd[ci];
         const float bard = q[3] * d.x + q[4] * d.y + q[5] * d.z;
         const float rdoa = -(q[0] * d.x + q[1] * d.y + q[2] * d.z);
         const float a = q[6] - bard * bard;
@@ -253,38 +312,89 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
         }
         if (tcap < tbest) { tbest = tcap; mat = 4; }
       }
-      mat = theta > 3.14159265f ? -1 : mat;                                  // behind the fisheye's full sphere: black
-      const unsigned int rgbw = mats[mat + 1];
-      const unsigned int val = ((pl.z >> k) & 1u) ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
-      if (planned) {
-        tot += val;
-        sA += ((pl.w >> k) & 1u) ? val : 0u;
-        sAB += ((pl.w >> (16 + k)) & 1u) ? val : 0u;
-      } else {
-        const unsigned int tid = (unsigned short)id_map[(size_t)ch * 16 + k];
-        const int id = (int)(tid & 0x7fffu);
-        if (id > 0) atomicAdd(&acc[id - 1], val);
-      }
-      if (fout) {
+      return mat;
+    };
+    if (!two && planned && cn[9] != 0.f) {
+      // The common case — a chunk inside one image row, three or fewer runs, the whole image within the lens polynomials' range
+      // (cn[9]; both are properties of the chunk / the lens, so a pixel takes the same path whatever the call renders) — on a diet: the row's part of the ray is hoisted, sin(theta) / rho and cos(theta) are polynomials in
+      // theta^2 (theta <= 2.1 for a lens up to 240 degrees: truncation < 1e-7, no rsq / sin / cos), the chosen colour byte
+      // of a pixel goes into packed words with one v_perm each and the run sums are v_dot4 against the plan's masks.
+      const float vv = ((float)row + 0.5f - cy) * inv_half_h;
+      const float hf2 = A.half_fov * A.half_fov, v2 = vv * vv;
+      const V3 rowv = v3(-vv * R[1], -vv * R[4], -vv * R[7]);
+      // (four pixels per turn of a rolled loop: the scene code exists four times, not sixteen — the kernel has to fit the
+      // instruction cache too)
+#pragma unroll 1
+      for (int g = 0; g < 4; ++g) {
+        unsigned int G4 = 0u, B4 = 0u, raw[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int cidx = 0; cidx < 3; ++cidx) {
-          const int bpos = 3 * k + cidx;
-          obytes[bpos >> 2] |= ((rgbw >> (8 * cidx)) & 0xffu) << ((bpos & 3) * 8);
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const float u = ((float)(col + 4 * g + k4) + 0.5f - cx) * inv_half_h;
+          const float x = fmaf(u, u, v2) * hf2;               // theta^2
+          float sc = -1.0f / 1307674368000.f;                 // sin(theta) / theta
+          sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
+          sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
+          float cs = 1.0f / 20922789888000.f;                 // cos(theta)
+          cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
+          cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
+          const float s1 = sc * A.half_fov;                   // sin(theta) / rho
+          const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
+          const unsigned int rgbw = mats[scene(d) + 1];
+          constexpr unsigned int keep = 0x03020100u;
+          G4 = __builtin_amdgcn_perm(rgbw, G4, (keep & ~(0xffu << (8 * k4))) | (5u << (8 * k4)));
+          B4 = __builtin_amdgcn_perm(rgbw, B4, (keep & ~(0xffu << (8 * k4))) | (6u << (8 * k4)));
+          if (fout) {
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx) {
+              const int bpos = 3 * k4 + cidx;
+              raw[bpos >> 2] |= ((rgbw >> (8 * cidx)) & 0xffu) << ((bpos & 3) * 8);
+            }
+          }
+        }
+        const unsigned int P4 = ((((pl.z >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+        const unsigned int V4 = (B4 & P4) | (G4 & ~P4);
+        tot = __builtin_amdgcn_udot4(V4, 0x01010101u, tot, false);
+        sA = __builtin_amdgcn_udot4(V4, (((pl.w >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sA, false);
+        sAB = __builtin_amdgcn_udot4(V4, (((pl.w >> (16 + 4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sAB, false);
+        if (fout) {
+          unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48) + 3 * g;
+          o[0] = raw[0]; o[1] = raw[1]; o[2] = raw[2];
         }
       }
-      if (++col == A.width) { col = 0; ++row; }
+    } else {
+      // everything else (a chunk that wraps to the next row, more than three runs, a lens beyond the polynomials' range): per
+      // pixel, rolled
+#pragma unroll 1
+      for (int k = 0; k < 16; ++k) {
+        float theta;
+        const V3 dc = eye_ray(row, col, cx, cy, inv_half_h, A.half_fov, theta);
+        const float dx = dc.x, dy = dc.y, dz = dc.z;
+        const V3 d = v3(R[0] * dx + R[1] * dy + R[2] * dz, R[3] * dx + R[4] * dy + R[5] * dz, R[6] * dx + R[7] * dy + R[8] * dz);
+        int mat = scene(d);
+        mat = theta > 3.14159265f ? -1 : mat;                                  // behind the fisheye's full sphere: black
+        const unsigned int rgbw = mats[mat + 1];
+        const unsigned int val = ((pl.z >> k) & 1u) ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
+        if (planned) {
+          tot += val;
+          sA += ((pl.w >> k) & 1u) ? val : 0u;
+          sAB += ((pl.w >> (16 + k)) & 1u) ? val : 0u;
+        } else {
+          const unsigned int tid = (unsigned short)id_map[(size_t)ch * 16 + k];
+          const int id = (int)(tid & 0x7fffu);
+          if (id > 0) atomicAdd(&acc[id - 1], val);
+        }
+        if (fout) {
+          uint8_t* o = fout + (size_t)ch * 48 + 3 * k;
+          o[0] = (uint8_t)(rgbw & 0xffu); o[1] = (uint8_t)((rgbw >> 8) & 0xffu); o[2] = (uint8_t)((rgbw >> 16) & 0xffu);
+        }
+        if (++col == A.width) { col = 0; ++row; }
+      }
     }
     if (planned) {
       const int ia = (int)(pl.x & 0x7fffu), ib = (int)((pl.x >> 16) & 0x7fffu), ic = (int)(pl.y & 0x7fffu);
       if (ia > 0) atomicAdd(&acc[ia - 1], sA);
       if (ib > 0) atomicAdd(&acc[ib - 1], sAB - sA);
       if (ic > 0) atomicAdd(&acc[ic - 1], tot - sAB);
-    }
-    if (fout) {
-      u32x4* o = reinterpret_cast<u32x4*>(fout + (size_t)ch * 48);
-      o[0] = u32x4{obytes[0], obytes[1], obytes[2], obytes[3]};
-      o[1] = u32x4{obytes[4], obytes[5], obytes[6], obytes[7]};
-      o[2] = u32x4{obytes[8], obytes[9], obytes[10], obytes[11]};
     }
   }
   __syncthreads();
