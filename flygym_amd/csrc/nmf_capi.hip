@@ -450,6 +450,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   } else {
     d.body_parent = d.tree_body = d.tree_child_start = d.tree_child_count = nullptr; d.tree_nlevel = 0; d.rest_fast = 0; d.rest_pack = nullptr;
   }
+  d.noslip_iter = 0;
+  if (const HostArray* os2 = model->find("opt_solver")) { if (os2->i.size() > 1) d.noslip_iter = os2->i[1]; }
   d.solver_flags = 0;
   if (const char* e = getenv("NMF_SOLVER")) {      // diagnostics: primal | nohist (default: contact-space solve with the active-set history)
     const std::string v(e);

@@ -139,6 +139,9 @@ struct DevModel {
   // diagnostics (environment NMF_SOLVER at batch creation): bit 0 = every step on the primal Newton loop, bit 1 = the contact-space
   // solve starts from the start point's own sign pattern instead of the previous step's active set.  Same optimum either way.
   int solver_flags;
+  // option/noslip_iterations of the CPU flavour (reference mujoco_globals.yaml:15): sweeps of the friction-only post-pass after the
+  // Newton solve (contact-space solve only, nmf_dual.h); 0 on the batched path, as the reference's GPU class sets it
+  int noslip_iter;
   const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   const NMF_G float *key_qpos, *key_ctrl;
   const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;

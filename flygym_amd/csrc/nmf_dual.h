@@ -304,6 +304,41 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     if (!was_guess && (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
     mask = __ballot(on && jar < 0.f);
   }
+  // the rows' forces
+  float frow = on && jar < 0.f ? -D * jar : 0.f;
+  // ---- noslip post-pass (the CPU flavour's option/noslip_iterations, reference mujoco_globals.yaml:15 under mujoco.mj_step,
+  // src/flygym/simulation.py:74-76; restated from MuJoCo's documentation in oracle/nmf_oracle.c::noslip): Gauss-Seidel over
+  // the pairs of opposing pyramid edges with the regulariser removed — a pair (mid + y, mid - y) keeps its sum, y in
+  // [-mid, mid] minimises 1/2 f^T A f + f^T j0; an update that raises the cost is undone; up to noslip_iter sweeps.
+  // A is the triangle in LDS, a pair's residual two wave sums.  Not a throughput path: the batched class strips the option.
+  if (m.noslip_iter > 0) {
+    const int tri_own = lane * (lane + 1) / 2;
+    auto a_at = [&](int i, int j) { return i >= j ? At[i * (i + 1) / 2 + j] : At[j * (j + 1) / 2 + i]; };
+    for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
+      float improvement = sweep == 0 ? wave_sum(0.5f * frow * frow * R) : 0.f;       // the regulariser's share of the cost drops out
+      for (int c2 = 0; c2 < ncon; ++c2) {
+        for (int pp = 0; pp < 2; ++pp) {
+          const int r0 = 4 * c2 + 2 * pp, r1 = r0 + 1;
+          const float col0 = At[lane >= r0 ? tri_own + r0 : r0 * (r0 + 1) / 2 + lane], col1 = At[lane >= r1 ? tri_own + r1 : r1 * (r1 + 1) / 2 + lane];
+          const float res0 = wave_sum(on ? col0 * frow : 0.f) + readlane_f(j0, r0), res1 = wave_sum(on ? col1 * frow : 0.f) + readlane_f(j0, r1);
+          const float a00 = a_at(r0, r0), a01 = a_at(r1, r0), a11 = a_at(r1, r1);
+          const float old0 = readlane_f(frow, r0), old1 = readlane_f(frow, r1);
+          const float bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
+          const float mid = 0.5f * (old0 + old1);
+          const float K1 = a00 + a11 - 2.f * a01, K0 = mid * (a00 - a11) + bc0 - bc1;
+          float n0 = mid, n1 = mid;
+          if (!(K1 < kMinVal)) { const float y = fminf(fmaxf(-K0 / K1, -mid), mid); n0 = mid + y; n1 = mid - y; }
+          const float d0 = n0 - old0, d1 = n1 - old1;
+          float change = 0.5f * (d0 * (a00 * d0 + a01 * d1) + d1 * (a01 * d0 + a11 * d1)) + d0 * res0 + d1 * res1;
+          if (change > 1e-10f) { n0 = old0; n1 = old1; change = 0.f; }
+          frow = lane == r0 ? n0 : lane == r1 ? n1 : frow;
+          improvement -= change;
+        }
+      }
+      if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
+    }
+    lam = frow; c_ws = 0.f;       // qacc = M^-1 (qfrc_smooth + J^T f)
+  }
   // the final active set, for the next step
   {
     const unsigned long long fin = __ballot(on && jar < 0.f);
@@ -362,8 +397,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   STAGE(14);
   // ---- contact wrenches and J^T f
   {
-    const float f = on && jar < 0.f ? -D * jar : 0.f;
-    const V3 F = v3(quad_sum(f * drow.x), quad_sum(f * drow.y), quad_sum(f * drow.z));
+    const V3 F = v3(quad_sum(frow * drow.x), quad_sum(frow * drow.y), quad_sum(frow * drow.z));
     if (on && k == 0) stsv(s.c_w[cc], SV{cross(r, F), F});
   }
   WSYNC();

@@ -1905,6 +1905,8 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     }
   }
   if constexpr (kDual<TP>) { if (!solved && lane < kActHistWords) s.act_hist[lane] = 0u; }      // nothing known for the next step
+  // a step the contact-space solve cannot take has no noslip pass: flagged with the overflow counter, never silent
+  if (m.noslip_iter > 0 && !solved && ncon > 0 && lane == 0) s.overflow = 1;
   if (solved) {
   } else if (ncon == 0 && !WELD) {
     for (int j = lane; j < s.nv(); j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }

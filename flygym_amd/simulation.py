@@ -36,12 +36,13 @@ class HIPSimulation:
     """
 
     def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
-                 max_contacts: int = 500, device: int | None = None) -> None:
+                 max_contacts: int = 500, device: int | None = None, _cpu_flavour: bool = False) -> None:
         import torch
 
         if len(world.fly_lookup) == 0:
             raise ValueError("The world must contain at least one fly.")
-        self._strip_unsupported_options(world)
+        if not (_cpu_flavour and self._noslip_supported(world)):      # (flygym_amd.Simulation keeps the CPU class's noslip pass)
+            self._strip_unsupported_options(world)
         self.world = world
         self.n_worlds = int(n_worlds)
         self.max_constraints = max_constraints
@@ -92,6 +93,14 @@ class HIPSimulation:
                 self._model_h = None
         except Exception:
             pass
+
+    @staticmethod
+    def _noslip_supported(world: BaseWorld) -> bool:
+        """The noslip post-pass lives in the contact-space solve (csrc/nmf_dual.h): leg-chain skeletons (LEGS_ONLY,
+        LEGS_ACTIVE_ONLY) on untethered worlds.  Elsewhere the option is stripped, with the reference's warning."""
+        m = world.compile_model()
+        star = tuple(int(v) for v in np.asarray(m["star"]).ravel())
+        return star in ((1, 6, 11, 8), (1, 6, 7, 4)) and int(np.asarray(m["weld_active"]).ravel()[0]) == 0
 
     @staticmethod
     def _strip_unsupported_options(world: BaseWorld) -> bool:
@@ -402,12 +411,14 @@ class Simulation:
 
     For user loops written against ``flygym.Simulation``; throughput work belongs on :class:`HIPSimulation`
     (a single world is launch-latency bound: ≈ 0.1 ms per ``step()``; use ``step(n)`` to fuse steps).  Differences:
-    no ``mj_model`` / ``mj_data`` (the engine arrays are reachable through ``batch.field(name)``), no noslip
-    post-pass (as on the reference's batched path), rendering handed off.
+    no ``mj_model`` / ``mj_data`` (the engine arrays are reachable through ``batch.field(name)``), rendering handed off.
+    The CPU class's noslip post-pass (``option/noslip_iterations = 5``, ``mujoco_globals.yaml:15``) runs here too — on the
+    leg-chain skeletons, where the contact-space solve has the matrix it needs; a step with more than 12 contacts cannot
+    take it and is counted in the overflow statistic.
     """
 
     def __init__(self, world: BaseWorld, device: int | None = None) -> None:
-        self.batch = HIPSimulation(world, 1, device=device)
+        self.batch = HIPSimulation(world, 1, device=device, _cpu_flavour=True)
         self.world = world
         self.renderer = None
         self.mj_model, self.mj_data = self.batch.mj_model, self.batch.mj_data

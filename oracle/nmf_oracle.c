@@ -122,6 +122,7 @@ typedef struct {
   /* tether: soft weld of the root body to its spawn pose (reference compose/world.py:358-365) */
   int weld_active; real weld_pos[3], weld_quat[4], weld_solref[2], weld_solimp[5], weld_invweight[2];
   int max_iter;
+  int noslip_iter;                     /* option/noslip_iterations (mujoco_globals.yaml:15); 0 on the batched path */
   int *body_parent, *body_dofadr, *body_dofnum;
   real *body_pos, *body_quat, *body_mass, *body_ipos, *body_inertia;
   int *dof_body, *dof_parent;
@@ -176,6 +177,7 @@ typedef struct {
    *    a 1-D Newton step keeps the active set);
    * 1: MuJoCo-documented rules only — gradient / improvement against `tolerance`, line search iterated to its fixed
    *    point — kept untouched by kernel work so that the converged solution has an independent anchor */
+  int noslip_on;                       /* 1: run the model's noslip_iter sweeps (the CPU class); 0: the batched class strips them */
   int solver_mode;
   /* scratch */
   real *w1, *w2, *w3, *w4, *w5, *H;
@@ -251,7 +253,8 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
     memcpy(m->weld_solref, t + 7, 2 * sizeof(real)); memcpy(m->weld_solimp, t + 9, 5 * sizeof(real));
     memcpy(m->weld_invweight, t + 14, 2 * sizeof(real)); free(t); }
   t = blob_real(blob, "stat_meaninertia", NULL); m->meaninertia = t[0]; free(t);
-  int* it = blob_int(blob, "opt_solver", NULL); m->max_iter = it[0]; free(it);
+  int64_t n_opt = 0;
+  int* it = blob_int(blob, "opt_solver", &n_opt); m->max_iter = it[0]; m->noslip_iter = n_opt > 1 ? it[1] : 0; free(it);
   it = blob_int(blob, "n_sensor", NULL); m->nsensor = it[0]; free(it);
   return m;
 }
@@ -990,6 +993,64 @@ static void solve_constraints(const omodel* m, odata* d) {
   }
 }
 
+/* ------------------------------------------------------------------ stage: noslip post-pass (CPU flavour only)
+ * MuJoCo's mj_solNoSlip as documented (computation chapter, "Noslip solver"; the reference's CPU class runs it with
+ * option/noslip_iterations = 5, src/flygym/assets/model/mujoco_globals.yaml:15, src/flygym/simulation.py:74-76; the batched
+ * class strips it, src/flygym/warp/simulation.py:427-448): a Gauss-Seidel pass over the FRICTION dimensions of the contacts
+ * with the regulariser removed (A = J M^-1 J^T, no R).  Pyramidal cones: the normal force of a contact is the sum of its
+ * pyramid-edge forces, so every pair of opposing edges (f0, f1) = (mid + y, mid - y) keeps its sum and y in [-mid, mid]
+ * minimises 1/2 f^T A f + f^T b (b = J qacc_smooth - aref); a pair update that raises the cost is undone; the pass stops after
+ * noslip_iterations sweeps or when a sweep improves the cost by less than noslip_tolerance (1e-6, MuJoCo's default), scaled by
+ * 1 / (meaninertia nv).  Then qfrc_constraint = J^T f and qacc = M^-1 (qfrc_smooth + qfrc_constraint). */
+#define NMF_NOSLIP_TOLERANCE ((real)1e-6)
+static void noslip(const omodel* m, odata* d) {
+  int nv = m->nv, nefc = d->nefc;
+  if (!d->noslip_on || m->noslip_iter <= 0 || d->ncon == 0) return;
+  real* A = (real*)malloc(sizeof(real) * (size_t)nefc * nefc);
+  real* b = (real*)malloc(sizeof(real) * (size_t)nefc);
+  real* col = (real*)malloc(sizeof(real) * (size_t)nv);
+  factor_tree(m, d->M, d->L, d->Ld);
+  for (int i = 0; i < nefc; i++) {
+    memcpy(col, d->J + (size_t)i * nv, sizeof(real) * (size_t)nv);
+    solve_tree(m, d->L, d->Ld, col);
+    for (int k = 0; k < nefc; k++) { real s = 0; const real* row = d->J + (size_t)k * nv; for (int j = 0; j < nv; j++) s += row[j] * col[j]; A[(size_t)k * nefc + i] = s; }
+    real s = 0; const real* row = d->J + (size_t)i * nv; for (int j = 0; j < nv; j++) s += row[j] * d->qacc_smooth[j];
+    b[i] = s - d->efc_aref[i];
+  }
+  real* f = d->efc_force;
+  real scale = (real)1 / (m->meaninertia * (real)(nv > 1 ? nv : 1));
+  for (int iter = 0; iter < m->noslip_iter; iter++) {
+    real improvement = 0;
+    if (iter == 0) for (int i = 0; i < nefc; i++) improvement += (real)0.5 * f[i] * f[i] / d->efc_D[i];   /* the regulariser's share of the cost drops out */
+    for (int c = 0; c < d->ncon; c++) {                              /* contact c owns rows 4c .. 4c + 3; the weld's rows follow the contacts' */
+      int i = 4 * c;
+      for (int p = 0; p < 2; p++) {
+        int j0 = i + 2 * p, j1 = j0 + 1;
+        real old0 = f[j0], old1 = f[j1], res0 = b[j0], res1 = b[j1];
+        for (int k = 0; k < nefc; k++) { res0 += A[(size_t)j0 * nefc + k] * f[k]; res1 += A[(size_t)j1 * nefc + k] * f[k]; }
+        real a00 = A[(size_t)j0 * nefc + j0], a01 = A[(size_t)j0 * nefc + j1], a11 = A[(size_t)j1 * nefc + j1];
+        real bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
+        real mid = (real)0.5 * (old0 + old1);
+        real K1 = a00 + a11 - (real)2 * a01, K0 = mid * (a00 - a11) + bc0 - bc1;
+        real n0, n1;
+        if (K1 < (real)1e-15) { n0 = mid; n1 = mid; }
+        else { real y = -K0 / K1; if (y < -mid) y = -mid; if (y > mid) y = mid; n0 = mid + y; n1 = mid - y; }
+        real d0 = n0 - old0, d1 = n1 - old1;
+        real change = (real)0.5 * (d0 * (a00 * d0 + a01 * d1) + d1 * (a01 * d0 + a11 * d1)) + d0 * res0 + d1 * res1;
+        if (change > (real)1e-10) { n0 = old0; n1 = old1; change = 0; }
+        f[j0] = n0; f[j1] = n1;
+        improvement -= change;
+      }
+    }
+    if (scale * improvement < NMF_NOSLIP_TOLERANCE) break;
+  }
+  memset(d->qfrc_constraint, 0, sizeof(real) * (size_t)nv);
+  for (int i = 0; i < nefc; i++) if (f[i] != 0) { const real* row = d->J + (size_t)i * nv; for (int j = 0; j < nv; j++) d->qfrc_constraint[j] += row[j] * f[i]; }
+  for (int j = 0; j < nv; j++) d->qacc[j] = d->qfrc_smooth[j] + d->qfrc_constraint[j];
+  solve_tree(m, d->L, d->Ld, d->qacc);
+  free(A); free(b); free(col);
+}
+
 /* ------------------------------------------------------------------ stage: contact sensors */
 static void contact_sensors(const omodel* m, odata* d) {
   memset(d->sensordata, 0, sizeof(real) * 96);
@@ -1047,6 +1108,7 @@ EXPORT void SFX(nmfo_forward)(const void* mv, void* dv) {
   memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(real) * (size_t)nv);
   solve_tree(m, d->L, d->Ld, d->qacc_smooth);
   solve_constraints(m, d);
+  noslip(m, d);
   contact_sensors(m, d);
   memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * (size_t)nv);
 }
@@ -1125,6 +1187,7 @@ EXPORT void* SFX(nmfo_ptr)(const void* mv, void* dv, const char* name, int* coun
 }
 
 EXPORT void SFX(nmfo_set_solver_mode)(void* dv, int mode) { ((odata*)dv)->solver_mode = mode; }
+EXPORT void SFX(nmfo_set_noslip)(void* dv, int on) { ((odata*)dv)->noslip_on = on; }
 
 EXPORT void SFX(nmfo_ints)(const void* mv, void* dv, int* out, int* con_geom) {
   (void)mv; odata* d = (odata*)dv;

@@ -43,6 +43,7 @@ def _lib(precision: str):
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
             ("nmfo_ptr", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
             ("nmfo_set_solver_mode", None, [ctypes.c_void_p, ctypes.c_int]),
+            ("nmfo_set_noslip", None, [ctypes.c_void_p, ctypes.c_int]),
             ("nmfo_ints", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
         ]:
             fn = getattr(lib, name + sfx)
@@ -54,7 +55,10 @@ def _lib(precision: str):
 class Oracle:
     """One world stepped on the CPU.  ``precision`` is ``"f64"`` or ``"f32"``."""
 
-    def __init__(self, model_blob: bytes, precision: str = "f64"):
+    def __init__(self, model_blob: bytes, precision: str = "f64", cpu_flavour: bool = False):
+        """``cpu_flavour``: run the model's ``noslip_iterations`` after the Newton solve, as the reference's CPU class does
+        (``src/flygym/simulation.py:74-76`` with ``mujoco_globals.yaml:15``); the default is the batched class's behaviour,
+        which strips the option (``src/flygym/warp/simulation.py:427-448``)."""
         self.precision = precision
         self.dtype = np.float64 if precision == "f64" else np.float32
         self._lib = _lib(precision)
@@ -68,13 +72,15 @@ class Oracle:
         (self.nq, self.nv, self.nu, self.nb, self.nseg, self.ng, self.nsite, self.maxcon,
          self.nsensor, _) = list(dims)
         self._d = self._call("nmfo_data_create", self._m)
+        self.cpu_flavour = bool(cpu_flavour)
+        self._call("nmfo_set_noslip", self._d, int(self.cpu_flavour))
         self.reset()
 
     def _call(self, name, *args):
         return getattr(self._lib, name + self._sfx)(*args)
 
     def clone_data(self) -> "Oracle":
-        other = Oracle(self._blob, self.precision)
+        other = Oracle(self._blob, self.precision, self.cpu_flavour)
         for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
             other.arr(k)[:] = self.arr(k)
         other.arr("time")[:] = self.arr("time")

@@ -123,3 +123,51 @@ def test_hull_vertex_on_a_cell_edge_keeps_its_scan_distance(torch_mod, oracle_li
     assert min(r.arr("con_dist")) > -0.05                         # every contact a real one
     a = r.arr("qacc")
     assert np.abs(qacc[0] - a).max() < 2e-3 * np.abs(a).max()
+
+
+def test_noslip_pass_of_the_cpu_flavour(torch_mod, oracle_lib):
+    """``flygym_amd.Simulation`` — the drop-in for the reference's CPU class — keeps ``option/noslip_iterations = 5``
+    (``mujoco_globals.yaml:15``) and runs MuJoCo's documented friction-only post-pass after the Newton solve; the batched
+    class strips it, as the reference's does.  The pass itself is anchored on the oracle by a closed-form case
+    (tests/test_oracle_closed_form.py::test_noslip_removes_the_creep: a one-body model, which the kernel steps on its
+    general-tree path where the pass does not exist); here the benchmark fly walks on the kernel and every sampled step is
+    compared with the oracle running the same pass from the same state — and with the oracle WITHOUT it: the pass moves the
+    accelerations by far more than the two engines differ."""
+    torch = torch_mod
+    import warnings
+    from flygym_amd import Simulation, make_model
+    from flygym_amd.controllers import TripodCPG
+    fly, world, _ = make_model()
+    assert world.noslip_iterations == 5
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # the CPU flavour must not warn about noslip any more
+        sim = Simulation(world)
+    assert sim.batch.model["opt_solver"][1] == 5
+    batch = sim.batch
+    batch.set_leg_adhesion_states(fly.name, np.ones((1, 6), dtype=np.float32))
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(1, 2500, device=batch.device)
+    ids = batch.replay_ids(fly.name)
+    batch.warmup(); batch.step_replay(table, ids, 0, 700)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    blob5 = batch.model.to_blob()
+    world0 = make_model()[1]; world0.noslip_iterations = 0
+    blob0 = world0.compile_model().to_blob()
+    worst, changed, cur = 0.0, 0.0, 700
+    for k in range(12):
+        batch.step_replay(table, ids, cur, 23); cur += 23
+        state = {kk: batch.field(kk)[0].cpu().numpy().astype(np.float64) for kk in keys}
+        batch.step_replay(table, ids, cur, 1); cur += 1
+        torch.cuda.synchronize()
+        qacc = batch.field("qacc")[0].cpu().numpy().astype(np.float64)
+        refs = {}
+        for name, blob in (("noslip", blob5), ("plain", blob0)):
+            r = oracle_lib.Oracle(blob, "f64", cpu_flavour=True)
+            for kk in keys: r.arr(kk)[:] = state[kk]
+            r.step_replay(table[0].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
+            refs[name] = r
+        if refs["noslip"].ints()["ncon"] != int(batch.field("stats")[0, 0].item()): continue
+        scale = np.abs(refs["noslip"].arr("qacc")).max()
+        worst = max(worst, np.abs(qacc - refs["noslip"].arr("qacc")).max() / scale)
+        changed = max(changed, np.abs(refs["noslip"].arr("qacc") - refs["plain"].arr("qacc")).max() / scale)
+    assert worst < 2e-3 and changed > 10 * worst, (worst, changed)
+    assert int(batch.field("stats_sum")[0, 3].item()) == 0         # no step fell outside the contact-space solve

@@ -121,6 +121,32 @@ def test_creep_velocity_on_an_incline(oracle_lib, precision, rtol, slope):
     assert MU * (f[:, 2] - f[:, 3]).sum() == pytest.approx(MASS * G * np.sin(theta), rel=max(rtol, 1e-7))
 
 
+@pytest.mark.parametrize("precision,vtol", [("f64", 1e-6), ("f32", 5e-2)])      # float32: the velocity carries the rounding of a position near 0.1
+@pytest.mark.parametrize("slope", [0.2, 0.45])
+def test_noslip_removes_the_creep(oracle_lib, precision, vtol, slope):
+    """The CPU flavour's post-pass (option/noslip_iterations = 5, reference mujoco_globals.yaml:15): friction dimensions
+    re-solved without the regulariser, normal forces kept.  The unregularised pair equation is J a = aref = -B v on the
+    sliding axis, and a pair of opposing pyramid edges keeps its SUM (at rest: half the normal force), so on a slope with
+    tan theta < mu / 2 the creep velocity of the soft rows decays at the rate B (1e4 / s) instead of persisting: the body
+    comes to rest at the penetration that carries m g cos(theta), held by a friction force of exactly m g sin(theta).
+    (Beyond mu / 2 the pair saturates at its sum and the creep stays: the pyramid's limit, not the pass's.)"""
+    theta = np.arctan(slope * MU)
+    n = tilted_normal(theta, 0.0)
+    m = sphere_on_plane(MASS, RADIUS, normal=n, mu=MU, solref=SOLREF, solimp=SOLIMP, margin=MARGIN, start_height=RADIUS + MARGIN, noslip_iterations=5)
+    o = oracle_lib.Oracle(m.to_blob(), precision, cpu_flavour=True)
+    o.step(600)
+    v_creep, _ = creep_prediction(theta)
+    t1, t2 = plane_frame(n)
+    assert np.abs(o.qvel[:3]).max() < vtol * v_creep                          # at rest: no creep
+    assert np.abs(o.arr("qacc")[:3]).max() < 1e-3 * G
+    rtol = 1e-6 if precision == "f64" else 2e-2
+    np.testing.assert_allclose(o.arr("con_dist") - MARGIN, rest_position(MASS * G * np.cos(theta)), rtol=rtol)
+    f = o.arr("efc_force").reshape(2, 4)
+    assert f.sum() == pytest.approx(MASS * G * np.cos(theta), rel=max(rtol, 1e-7))
+    assert MU * (f[:, 2] - f[:, 3]).sum() == pytest.approx(MASS * G * np.sin(theta), rel=max(rtol, 1e-6))
+    assert (f >= 0).all()
+
+
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 @pytest.mark.parametrize("direction", ["axis", "diagonal", "oblique"])
 def test_stick_slip_threshold_of_the_pyramid(oracle_lib, precision, direction):

@@ -18,7 +18,8 @@ from flygym_amd.compiler.model import CompiledModel, EngineSemantics
 
 def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solref=(2e-4, 1.0),
                     solimp=(0.98, 0.99, 0.5, 0.9999, 2.0), margin=1e-3, gravity=(0.0, 0.0, -9810.0), timestep=1e-4,
-                    start_height=None, semantics: EngineSemantics | None = None, terrain=None, start_xy=None) -> CompiledModel:
+                    start_height=None, semantics: EngineSemantics | None = None, terrain=None, start_xy=None,
+                    noslip_iterations=0) -> CompiledModel:
     """``terrain``: ``(type, (p0, p1, p2, p3))`` of a build-defined terrain (flygym_amd/compose/world.py) over the z = 0
     plane; ``start_xy``: where the sphere starts (with ``start_height`` above z = 0)."""
     n = np.asarray(normal, dtype=np.float64)
@@ -47,7 +48,7 @@ def sphere_on_plane(mass=1e-3, radius=0.1, normal=(0.0, 0.0, 1.0), mu=1.0, solre
         geom_p0=f([0, 0, 0]), geom_p1=f([0, 0, 0]), geom_radius=f(radius), geom_bsphere=f([0, 0, 0, radius]),
         geom_invweight0=f(1.0 / mass), hull_vert=np.zeros((1, 3)), hull_skin=f(1e-3),
         pair_friction=f([mu, mu, 0.02, 1e-4, 1e-4]), pair_solref=f(list(solref)), pair_solimp=f(list(solimp)), pair_margin=f(margin),
-        opt_timestep=f(timestep), opt_gravity=f(*gravity), opt_tolerance=f(1e-8), opt_solver=i(100, 0),
+        opt_timestep=f(timestep), opt_gravity=f(*gravity), opt_tolerance=f(1e-8), opt_solver=i(100, noslip_iterations),
         stat_meaninertia=f(mass), plane=f(*n, 0.0), terrain_type=i(t_type), terrain_params=f(*t_par, t_max),
         weld_active=i(0), weld_params=np.zeros(16), n_sensor=i(0), star=i(0, 0, 0, 0), sem_options=sem.flags(),
     )
