@@ -223,11 +223,20 @@ def terrain_probe(kind, params, p, rho=0.0):
     With ``z_b = p_z - rho`` the probe's lowest point, ``h0`` the height of its cell, ``delta_e`` the distance from ``p``
     to the cell's boundary in direction e and ``h_e`` the height of the cell across it:
 
-    * a neighbour with ``h_e > z_b`` shows the probe a side face at ``dist = delta_e - rho`` whose outward normal is -e;
-    * ``z_b >= h0`` (above its own cell): ``dist_top = z_b - h0``;
+    * a neighbour with ``h_e > z_b`` concerns the probe.  With the centre below the neighbour's top (``p_z < h_e``; always
+      so for a point) it shows a side face at ``dist = delta_e - rho`` whose outward normal is -e.  With the centre above
+      it by ``v = p_z - h_e`` (only possible for a sphere, ``0 <= v < rho``) the sphere reaches over the neighbour's top
+      EDGE, and the box's nearest feature is axis-aligned only approximately: nearer the face than the top
+      (``delta_e >= v``) it is the face as above, otherwise the neighbour's top carries it, ``dist = z_b - h_e`` with
+      normal +z (round 4: before, the face applied for every ``h_e > z_b``, so a sphere rolling off a cell's top edge went
+      from a 1 um top contact to a ``rho``-deep wall contact; now the depth is continuous across the edge, and across
+      the 45 degree line ``delta_e = v`` where the normal turns);
+    * ``z_b >= h0`` (above its own cell): ``dist_top = z_b - h0``, or the distance to a neighbour's top found above if
+      that is smaller;
     * ``z_b < h0`` (inside its own cell's box): the ways out are up (``h0 - z_b``) and sideways through every face with a
       neighbour the probe would be clear of (``h_e <= z_b``: ``delta_e + rho``).  The shortest wins: sideways gives a face
-      at ``dist = -(delta_e + rho)`` with outward normal +e and ``dist_top`` = +inf; up gives ``dist_top = z_b - h0``;
+      at ``dist = -(delta_e + rho)`` with outward normal +e and ``dist_top`` = the nearest neighbour's top (+inf if none);
+      up gives ``dist_top = z_b - h0``;
     * of all the faces found the one with the smallest distance is reported.
 
     A contact exists where a distance is within the pair's margin; its point is the probe's surface point along the
@@ -243,19 +252,23 @@ def terrain_probe(kind, params, p, rho=0.0):
     across = ((x_hi + _PROBE_EPS, y), (x_lo - _PROBE_EPS, y), (x, y_hi + _PROBE_EPS), (x, y_lo - _PROBE_EPS))
     he = [float(_terrain_height(kind, params, np.float64(a), np.float64(b))) if np.isfinite(d) else h0
           for d, (a, b) in zip(delta, across)]
-    best, code = np.inf, 0
-    for e in range(4):                                                    # side faces that look at the probe
-        if np.isfinite(delta[e]) and he[e] > zb and delta[e] - rho < best:
+    best, code, edge_top = np.inf, 0, np.inf
+    for e in range(4):                                                    # neighbours that reach above the probe's lowest point
+        if not (np.isfinite(delta[e]) and he[e] > zb):
+            continue
+        if z - he[e] > delta[e]:                                          # over the neighbour's top edge, nearer its top
+            edge_top = min(edge_top, zb - he[e])
+        elif delta[e] - rho < best:                                       # its side face
             best, code = delta[e] - rho, (2, 1, 4, 3)[e]                  # normal -e
     if zb >= h0:
-        return zb - h0, best, code
+        return min(zb - h0, edge_top), best, code
     pen, out = h0 - zb, 0
     for e in range(4):                                                    # inside its own cell's box: the ways out
         if np.isfinite(delta[e]) and he[e] <= zb and delta[e] + rho < pen:
             pen, out = delta[e] + rho, (1, 2, 3, 4)[e]                    # through the face towards e: normal +e
     if out == 0:
-        return zb - h0, best, code
-    return (np.inf, -pen, out) if -pen < best else (np.inf, best, code)
+        return min(zb - h0, edge_top), best, code
+    return (edge_top, -pen, out) if -pen < best else (edge_top, best, code)
 
 
 class GappedTerrainWorld(_TerrainWorld):

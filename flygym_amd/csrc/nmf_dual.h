@@ -100,6 +100,9 @@ __device__ __forceinline__ void dual_eliminate(unsigned long long rem, const flo
 template <class TP, int NC>
 __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls STAGE_ARG) {
   constexpr int NDL = TP::NDL, NLEG = TP::NLEG, SW = row_width_s<TP>();
+  // (per-lane addresses of this stage are rebuilt every step: hoisted out of the persistent item loop they sat in registers
+  // across all other stages and pushed 16 of the loop's other invariants into scratch — ten reloads per step)
+  lane = opaque(lane);
   ncon = __builtin_amdgcn_readfirstlane(ncon);
   walls = __builtin_amdgcn_readfirstlane((int)walls) != 0;
   const Frame fr0 = ld_frame(s, m);

@@ -641,15 +641,25 @@ __device__ __forceinline__ void terrain_probe(int terrain_type, const float* p, 
       he[e] = e == 0 ? terrain_height(terrain_type, p, b[1] + kProbeEps, y) : e == 1 ? terrain_height(terrain_type, p, b[0] - kProbeEps, y)
             : e == 2 ? terrain_height(terrain_type, p, x, b[3] + kProbeEps) : terrain_height(terrain_type, p, x, b[2] - kProbeEps);
   }
+  // Neighbours that reach above the probe's lowest point.  Centre below the neighbour's top (every point probe): its side
+  // face, codes 2, 1, 4, 3 (the face's normal is -e).  Centre above it by v < rho: the sphere reaches over the top EDGE —
+  // nearer the face (delta >= v) it is still the face, otherwise the neighbour's top carries it (normal +z): the depth
+  // stays continuous when a capsule end rolls off a cell's edge.
+  float edge_top = kFar;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)          // side faces that look at the probe (codes 2, 1, 4, 3: the face's normal is -e)
-    if (delta[e] - rho <= reach && he[e] > zb && delta[e] - rho < dwall) { dwall = delta[e] - rho; wall = (e ^ 1) + 1; }
-  if (zb >= h0) return;
-  float pen = h0 - zb; int code = 0;   // inside its own cell's box: the ways out (codes 1..4: the normal is +e)
+  for (int e = 0; e < 4; ++e) {
+    if (!(delta[e] - rho <= reach && he[e] > zb)) continue;
+    if (zc - he[e] > delta[e]) edge_top = fminf(edge_top, zb - he[e]);
+    else if (delta[e] - rho < dwall) { dwall = delta[e] - rho; wall = (e ^ 1) + 1; }
+  }
+  if (zb < h0) {
+    float pen = h0 - zb; int code = 0;   // inside its own cell's box: the ways out (codes 1..4: the normal is +e)
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (delta[e] < kFar && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = e + 1; }
-  if (code) { dtop = kFar; if (-pen < dwall) { dwall = -pen; wall = code; } }
+    for (int e = 0; e < 4; ++e)
+      if (delta[e] < kFar && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = e + 1; }
+    if (code) { dtop = kFar; if (-pen < dwall) { dwall = -pen; wall = code; } }
+  }
+  dtop = fminf(dtop, edge_top);
 }
 
 // Scratch of the collision stage, overlaid on the T..W region (free between steps)
@@ -722,14 +732,17 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     const V3 xp = ld3(s.xpos()[g_body]);
     V3 cw = mat_vec(R, bs);
     float dc = dot(n, cw) + dot(n, xp) - pd;
-    // Terrains: the ground under the geom is no higher than the highest cell its bounding sphere's footprint touches — a
-    // 3 x 3 sample of the height map at the centre +- radius is conservative (every cell is wider than a geom's radius).
+    // Terrains: the ground under the geom is no higher than the highest cell its bounding sphere's footprint touches.
     // Against the global maximum every leg segment dangling in a 2 mm gap passed the cull: 21 hull scans per step on the
     // gapped world instead of 4.
     // The cell under the centre comes first: most footprints lie inside it (cells are 1 mm and more, a leg segment's
-    // radius 0.1-0.3 mm) and need neither the other eight samples nor, later, a terrain probe per hull vertex.
+    // radius 0.1-0.3 mm) and need neither another look-up nor, later, a terrain probe per hull vertex.  Otherwise the
+    // footprint's cells are walked along x from its low end — each cell's own high boundary leads to the next, so a cell
+    // of any width is met (round 3 sampled 3 x 3 points a footprint radius apart and could step over a raised piece
+    // narrower than that, e.g. where a stripe of the mixed terrain cuts a block) — and every one is read at three
+    // heights of y, which meets all the blocks' rows unless a row is narrower than the radius (then: the global maximum).
     float ttop = terrain_top;
-    if (rough) {
+    if (rough && dc - bs_r - terrain_top <= g_margin) {
       // (the footprint is widened by the margin: a face within the margin of a vertex belongs to a cell it touches)
       const float cx = cw.x + xp.x, cy = cw.y + xp.y, fr = bs_r + g_margin;
       float cb[4];
@@ -737,11 +750,20 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       const float clear = fminf(fminf(cb[1] - cx, cx - cb[0]), fminf(cb[3] - cy, cy - cb[2])) - fr;
       one_cell = clear > kOneCell;
       if (!(clear > 0.f)) {
-#pragma unroll
-        for (int a = -1; a <= 1; ++a)
-#pragma unroll
-          for (int bb = -1; bb <= 1; ++bb)
-            if (a != 0 || bb != 0) ttop = fmaxf(ttop, terrain_height(terrain_type, tpar, cx + (float)a * fr, cy + (float)bb * fr));
+        if (terrain_type >= 2 && tpar[0] < fr) ttop = terrain_top;
+        else {
+          float xs = cx - fr;
+          bool open = true;             // the walk has not reached the footprint's high end yet
+#pragma unroll 1
+          for (int k = 0; k < 8 && open; ++k) {
+            float wb[4];
+            ttop = fmaxf(ttop, terrain_cell(terrain_type, tpar, xs, cy, wb));
+            ttop = fmaxf(ttop, fmaxf(terrain_height(terrain_type, tpar, xs, cy - fr), terrain_height(terrain_type, tpar, xs, cy + fr)));
+            open = wb[1] <= cx + fr;
+            xs = wb[1] + kProbeEps;
+          }
+          if (open) ttop = terrain_top; // more cells than the walk takes: no local bound
+        }
       }
       g_ttop = ttop;
     }
@@ -1309,11 +1331,14 @@ __device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
 template <class TP> struct DualFactors;
 template <class TP> __device__ __forceinline__ DualFactors<TP>& dual_factors(FlyLds<TP>& s);
 
-template <class TP, bool WELD>
+// WITHK_ (leg-chain kernels that have the contact-space solve): the contact stiffness rows are compiled into the solve at all
+// — only the primal Newton loop's instantiation has them, so the two solves of an ordinary step (smooth, Euler) run a function
+// two thirds the size: the step's hot path has to share a 64 KB instruction cache.  Elsewhere one instantiation serves all.
+template <class TP, bool WELD, bool WITHK_ = true>
 __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool withK, float hdamp,
                           const GModel& m, int lane, bool store = false, bool withF = false) {
   if constexpr (!TP::kStar) { tree_aba_solve<TP, WELD>(s, tau_id, x_id, withK, hdamp, m, lane); return; } else {
-  withK = __builtin_amdgcn_readfirstlane((int)withK) != 0;          // wave-uniform: scalar branches, no exec masking
+  withK = WITHK_ && __builtin_amdgcn_readfirstlane((int)withK) != 0;          // wave-uniform: scalar branches, no exec masking
   // store: keep the factors (U / sqrt D, 1 / sqrt D per hinge and root axis) in LDS for the contact-space solve (nmf_dual.h)
   store = kDual<TP> && __builtin_amdgcn_readfirstlane((int)store) != 0;
   // withF: the contact wrenches in c_w act on their bodies as external forces (the Euler step's solve after a contact-space
@@ -1886,7 +1911,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // ---- unconstrained acceleration
   // contact-space solve (nmf_dual.h) for steps with 1..kDualMaxCon contacts: the smooth solve keeps its factors for it
   const bool dual = kDual<TP> && !WELD && ncon > 0 && ncon <= kDualMaxCon && !(m.solver_flags & 1);
-  aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane, dual);
+  aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane, dual);
   contact_reload(c, s, lane);
   STAGE(7);
 
@@ -2170,11 +2195,11 @@ __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane, bool
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   wrenches = __builtin_amdgcn_readfirstlane((int)wrenches) != 0;
-  if (wrenches) aba_solve<TP, WELD>(s, V_QFRC_SMOOTH, V_B, false, h, m, lane, false, true);
+  if (wrenches) aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_B, false, h, m, lane, false, true);
   else {
     for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
     WSYNC();
-    aba_solve<TP, WELD>(s, V_A, V_B, false, h, m, lane);
+    aba_solve<TP, WELD, !kDual<TP>>(s, V_A, V_B, false, h, m, lane);
   }
   for (int j = lane; j < s.nv(); j += kWave) s.qvel[j] += h * s.vB[j];
   WSYNC();
@@ -2221,13 +2246,22 @@ __device__ __forceinline__ float ld_tagged(const unsigned long long* p, unsigned
   ok = ok && (unsigned int)(g >> 32) == want;
   return __uint_as_float((unsigned int)g);
 }
+// the same granules carrying raw 32-bit payloads (counters, bit masks): never through a float register
+__device__ __forceinline__ void st_tagged_u(unsigned long long* p, unsigned int v, unsigned int tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int ld_tagged_u(const unsigned long long* p, unsigned int want, bool& ok) {
+  const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ok = ok && (unsigned int)(g >> 32) == want;
+  return (unsigned int)g;
+}
 
 // `final`: this item ends the launch.  Pure outputs (plain stores: qacc, stats — like the pose / sensor / force outputs of
 // the last step) are written by the final item only: an earlier chunk's plain store, sitting in another XCD's L2, could
 // otherwise reach memory after the final one's.
 template <class TP>
 __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st, int w, int lane, float time, bool final,
-                              unsigned int tag = 0u, float carry = 0.f) {
+                              unsigned int tag = 0u, unsigned int carry = 0u) {
   lane = opaque(lane);     // once per item: keep its address arithmetic out of the registers the steps live in
   if (!final) {            // an inner chunk of a chunked launch: the state goes to the world's next item as tagged granules
     unsigned long long* hb = st.handoff + (size_t)w * st.handoff_stride;
@@ -2235,10 +2269,10 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
     for (int i = lane; i < nq; i += kWave) st_tagged(&hb[i], s.qpos[i], tag);
     for (int i = lane; i < nv; i += kWave) { st_tagged(&hb[nq + i], s.qvel[i], tag); st_tagged(&hb[nq + nv + i], s.qacc[i], tag); }
     for (int i = lane; i < m.nu; i += kWave) st_tagged(&hb[nq + 2 * nv + i], s.ctrl[i], tag);
-    // lanes 0..5: the clock and what the world's items have accumulated so far (steps, contacts, iterations, overflow steps —
-    // as integer bit patterns — and cycles): one store; the launch's final item adds them to the world's counters
-    if (lane < 6) st_tagged(&hb[nq + 2 * nv + m.nu + lane], lane == 0 ? time : carry, tag);
-    if constexpr (kDual<TP>) { if (lane < (m.ng + 1) / 2) st_tagged(&hb[nq + 2 * nv + m.nu + 6 + lane], __uint_as_float(s.act_hist[lane]), tag); }
+    // lanes 0..5: the clock (float bits) and what the world's items have accumulated so far (steps, contacts, iterations,
+    // overflow steps: unsigned integers; cycles: float bits): one store; the launch's final item adds them to the world's counters
+    if (lane < 6) st_tagged_u(&hb[nq + 2 * nv + m.nu + lane], lane == 0 ? __float_as_uint(time) : carry, tag);
+    if constexpr (kDual<TP>) { if (lane < (m.ng + 1) / 2) st_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + lane], s.act_hist[lane], tag); }
     return;
   }
   if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < (m.ng + 1) / 2 ? s.act_hist[lane] : 0u; }
@@ -2426,7 +2460,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (st.sched && lane == 0) atomicMin(&st.sched->t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     float time;
-    float carry = 0.f;       // lanes 1..5: what the world's earlier items of this launch accumulated (steps, contacts, iterations, overflow steps, cycles)
+    unsigned int carry = 0u; // lanes 1..4: what the world's earlier items of this launch accumulated (steps, contacts, iterations, overflow steps); lane 5: their cycles (float bits)
     unsigned int sum_con = 0u, sum_it = 0u, sum_of = 0u;     // running sums over the steps of this item (wave-uniform)
     {
       // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
@@ -2448,12 +2482,12 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           for (int i = ln; i < nq; i += kWave) s.qpos[i] = ld_tagged(&hb[i], want, ok);
           for (int i = ln; i < nv; i += kWave) { s.qvel[i] = ld_tagged(&hb[nq + i], want, ok); s.qacc[i] = ld_tagged(&hb[nq + nv + i], want, ok); }
           for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_tagged(&hb[nq + 2 * nv + i], want, ok);
-          carry = lane < 6 ? ld_tagged(&hb[nq + 2 * nv + m.nu + ln], want, ok) : 0.f;     // lane 0: the clock; 1..5: running sums
-          if constexpr (kDual<TP>) { s.act_hist[lane] = lane < (m.ng + 1) / 2 ? __float_as_uint(ld_tagged(&hb[nq + 2 * nv + m.nu + 6 + ln], want, ok)) : 0u; }
+          carry = lane < 6 ? ld_tagged_u(&hb[nq + 2 * nv + m.nu + ln], want, ok) : 0u;     // lane 0: the clock; 1..5: running sums
+          if constexpr (kDual<TP>) { s.act_hist[lane] = lane < (m.ng + 1) / 2 ? ld_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + ln], want, ok) : 0u; }
           if (!__any(!ok)) break;            // wave-uniform: every granule carried the expected tag
           __builtin_amdgcn_s_sleep(8);
         }
-        time = readlane_f(carry, 0);
+        time = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)carry, 0));
       } else {
         for (int i = ln; i < s.nq(); i += kWave) s.qpos[i] = ld_state(&st.qpos[(size_t)w * s.nq() + i]);
         for (int i = ln; i < s.nv(); i += kWave) {
@@ -2498,13 +2532,13 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       // is 7e8 steps of one world between two resets)
       const unsigned int own = lane == 1 ? (unsigned int)(step1 - step0) : lane == 2 ? sum_con : lane == 3 ? sum_it : sum_of;
       const float cyc = (float)(__builtin_amdgcn_s_memtime() - t_begin);
-      if (lane >= 1 && lane <= 4) carry = __uint_as_float(__float_as_uint(carry) + own);
-      if (lane == 5) carry += cyc;
+      if (lane >= 1 && lane <= 4) carry += own;
+      if (lane == 5) carry = __float_as_uint(__uint_as_float(carry) + cyc);
       const bool final = step1 == n_steps;
       write_outputs(s, m, st, w, lane, time, final, epoch * 32u + (unsigned int)(chunk + 1), carry);
       if (final) {
-        if (lane >= 1 && lane <= 4) add_count(&st.stats_sum[4 * (size_t)w + opaque(lane) - 1], __float_as_uint(carry));
-        if (lane == 5) st_state(&st.cost[w], carry);     // the world's cycles over the whole launch
+        if (lane >= 1 && lane <= 4) add_count(&st.stats_sum[4 * (size_t)w + opaque(lane) - 1], carry);
+        if (lane == 5) st_state(&st.cost[w], __uint_as_float(carry));     // the world's cycles over the whole launch
       }
       if (st.sched && lane == 0) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }

@@ -578,13 +578,19 @@ static void terrain_probe(const omodel* m, const real* pw, real zc, real rho, re
   he[2] = b[3] < NMF_FAR ? terrain_height(m, x, b[3] + NMF_PROBE_EPS) : h0;
   he[3] = b[2] > -NMF_FAR ? terrain_height(m, x, b[2] - NMF_PROBE_EPS) : h0;
   static const int facing[4] = {2, 1, 4, 3}, leaving[4] = {1, 2, 3, 4};
-  for (int e = 0; e < 4; e++)          /* side faces that look at the probe */
-    if (delta[e] < NMF_FAR && he[e] > zb && delta[e] - rho < *dwall) { *dwall = delta[e] - rho; *wall = facing[e]; }
-  if (zb >= h0) return;
-  real pen = h0 - zb; int code = 0;    /* inside its own cell's box: the ways out */
-  for (int e = 0; e < 4; e++)
-    if (delta[e] < NMF_FAR && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = leaving[e]; }
-  if (code) { *dtop = NMF_FAR; if (-pen < *dwall) { *dwall = -pen; *wall = code; } }
+  real edge_top = NMF_FAR;
+  for (int e = 0; e < 4; e++) {        /* neighbours that reach above the probe's lowest point */
+    if (!(delta[e] < NMF_FAR && he[e] > zb)) continue;
+    if (zc - he[e] > delta[e]) { if (zb - he[e] < edge_top) edge_top = zb - he[e]; }   /* over its top edge, nearer the top: that top carries the sphere */
+    else if (delta[e] - rho < *dwall) { *dwall = delta[e] - rho; *wall = facing[e]; }  /* its side face */
+  }
+  if (zb < h0) {
+    real pen = h0 - zb; int code = 0;  /* inside its own cell's box: the ways out */
+    for (int e = 0; e < 4; e++)
+      if (delta[e] < NMF_FAR && he[e] <= zb && delta[e] + rho < pen) { pen = delta[e] + rho; code = leaving[e]; }
+    if (code) { *dtop = NMF_FAR; if (-pen < *dwall) { *dwall = -pen; *wall = code; } }
+  }
+  if (edge_top < *dtop) *dtop = edge_top;
 }
 
 /* hull vertex v (body frame) against the terrain: its distance to the top of its cell (NMF_FAR when a side face owns it) */

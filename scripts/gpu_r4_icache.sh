@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for V in "$@"; do
   export NMF_HIP_LIB=$GRAFT_REPO_ROOT/build/libnmf_$V.so
   OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_ic_$V; rm -rf $OUT; mkdir -p $OUT
-  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o q -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-counters --steps 20 --warmup 5 > $OUT/bench.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o q -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-live-counters --steps 20 --warmup 5 $BENCH_EXTRA > $OUT/bench.log 2>&1 )
   python - "$V" <<'P'
 import csv, glob, os, sys
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + f"/gpurun_out/prof_ic_{sys.argv[1]}/**/*counter_collection.csv", recursive=True)[0]

@@ -171,3 +171,53 @@ def test_noslip_pass_of_the_cpu_flavour(torch_mod, oracle_lib):
         changed = max(changed, np.abs(refs["noslip"].arr("qacc") - refs["plain"].arr("qacc")).max() / scale)
     assert worst < 2e-3 and changed > 10 * worst, (worst, changed)
     assert int(batch.field("stats_sum")[0, 3].item()) == 0         # no step fell outside the contact-space solve
+
+
+def test_cells_narrower_than_a_hulls_footprint(torch_mod, oracle_lib):
+    """The collision stage's cull takes the highest top under a geom's footprint.  Round 3 read it from 3 x 3 samples a
+    footprint radius apart, which is a bound only while no raised cell is narrower than that radius; the terrain classes
+    accept any widths, and the thorax / abdomen hulls' footprints (0.7 mm) are wider than the blocks of this world
+    (0.5 mm blocks, 0.3 mm gaps): all three samples of a row can land in gaps.  The walk along the cells (round 4) meets
+    every cell.  A fly dropped on its side onto that terrain: states of the float64 oracle's fall in which the body's hulls
+    touch, one step from each on the engine — the same contacts, the same accelerations."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.utils.math import Rotation3D
+
+    fly = make_model(joints_preset="legs_only")[0]
+    world = C.GappedTerrainWorld(block_width=0.5, gap_width=0.3)
+    world.add_fly(fly, (0.1, 0, 0.9), Rotation3D("quat", (0.7071, 0.7071, 0, 0)))       # on its side: it comes down on thorax and head
+    model = world.compile_model()
+    blob = model.to_blob()
+    big = np.nonzero(np.asarray(model["geom_bsphere"]).reshape(-1, 4)[:, 3] > 0.5)[0].tolist()
+    assert big, "no wide hull in the contact set"
+    o = oracle_lib.Oracle(blob, "f64")
+    states = []
+    for k in range(1500):
+        o.step(1)
+        g = o.ints()["con_geom"]
+        if any(x in big for x in g) and (not states or k - states[-1][0] >= 20):
+            states.append((k, o.qpos.copy(), o.qvel.copy(), o.ctrl.copy(), o.arr("qacc_warmstart").copy()))
+        if len(states) == 8:
+            break
+    assert len(states) >= 3, "the body never reached the ground"
+    n = len(states)
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    for name, idx in (("qpos", 1), ("qvel", 2), ("ctrl", 3), ("qacc_warmstart", 4)):
+        sim.field(name)[:] = torch.as_tensor(np.stack([s[idx] for s in states]), dtype=torch.float32, device=sim.device)
+    sim.step(1)
+    torch.cuda.synchronize()
+    qacc, stats, geom = sim.field("qacc").cpu().numpy(), sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+    wide = 0
+    for w, st in enumerate(states):
+        r = oracle_lib.Oracle(blob, "f64")
+        r.qpos[:] = st[1]; r.qvel[:] = st[2]; r.ctrl[:] = st[3]; r.arr("qacc_warmstart")[:] = st[4]
+        r.step(1)
+        nc = int(stats[w, 0])
+        assert nc == r.ints()["ncon"], f"state {w}: engine {geom[w, :nc].astype(int).tolist()}, oracle {r.ints()['con_geom']}"
+        assert geom[w, :nc].astype(int).tolist() == r.ints()["con_geom"]
+        scale = np.abs(r.arr("qacc")).max()
+        assert np.abs(qacc[w] - r.arr("qacc")).max() < 5e-3 * scale, f"state {w}"
+        wide += sum(1 for x in r.ints()["con_geom"] if x in big)
+    assert wide >= 2

@@ -88,6 +88,12 @@ def test_terrain_probe_known_answers():
     d = terrain_probe(*b, (1.29, 0.5, 0.1), 0.05)                                             # low cell, raised neighbour at x > 1.3
     assert d[0] == pytest.approx(0.05) and d[1] == pytest.approx(-0.04) and d[2] == 2
     assert terrain_probe(*b, (1.29, 0.5, 0.45), 0.05)[1:] == (inf, 0)                         # above the neighbour's top: no face
+    # a sphere rolling off the raised cell [1.3, 2.6) x [0, 1.3): over the edge its top still carries it, further out its face
+    assert terrain_probe(*b, (2.599, 0.5, 0.379), 0.03) == (pytest.approx(-0.001), inf, 0)
+    d = terrain_probe(*b, (2.6001, 0.5, 0.379), 0.03)                                         # centre 29 um above the edge, 0.1 um out
+    assert d[0] == pytest.approx(-0.001) and d[1] == pytest.approx(0.47) and d[2] == 3        # (the only face in sight: the raised cell at y < 0)
+    d = terrain_probe(*b, (2.6295, 0.5, 0.379), 0.03)                                         # 29.5 um out: nearer the face than the top
+    assert d[0] == pytest.approx(0.349) and d[1] == pytest.approx(-0.0005) and d[2] == 1
     d = terrain_probe(*b, (1.0, 1.299, 0.2))                                                  # y faces: raised cell at y > 1.3
     assert d[1] == pytest.approx(1e-3) and d[2] == 4
     m = TERRAINS["mixed"]
@@ -96,6 +102,38 @@ def test_terrain_probe_known_answers():
     d = terrain_probe(*m, (7.999, 0.65, 0.2))      # end of the gapped stripe (x < 8), the blocks stripe's first square is raised?
     h_next = float(np.asarray(__import__("flygym_amd.compose.world", fromlist=["x"])._terrain_height(3, m[1], np.float64(8.0001), np.float64(0.65))))
     assert (d[2] == 2 and d[1] == pytest.approx(1e-3)) == (h_next > 0.2)
+
+
+@pytest.mark.parametrize("name", ["gapped", "blocks", "mixed"])
+def test_probe_depth_is_continuous_across_cell_edges(name):
+    """A sphere carried along straight lines over the terrain (above, at and below the tops; along x, y and a diagonal):
+    the deepest penetration the rule reports moves by no more than the sphere does — no jump when its centre crosses a
+    cell's edge (round 3's rule jumped by about rho there).  Lines that pass INSIDE a box are left out: there the rule's
+    way out changes from one face to another by design."""
+    from flygym_amd.compose.world import terrain_probe
+
+    t = TERRAINS[name]
+    rho, step = 0.03, 5e-4
+    tops = {"gapped": (0.0,), "blocks": (0.0, 0.35), "mixed": (0.0, 0.35)}[name]
+    worst = 0.0
+    for top in tops:
+        for dz in (-0.004, -0.001, 0.0, 0.01, 0.029):                # lowest point from 4 um inside a top to just below the centre's level
+            z = top + rho + dz
+            for (x0, y0, ux, uy) in ((-1.0, 0.5, 1.0, 0.0), (0.65, -1.0, 0.0, 1.0), (-1.0, -0.9, 0.8, 0.6), (3.5, 0.2, 1.0, 0.0)):
+                prev = None
+                for k in range(int(6.0 / step)):
+                    x, y = x0 + ux * k * step, y0 + uy * k * step
+                    h_here = float(np.asarray(__import__("flygym_amd.compose.world", fromlist=["x"])._terrain_height(t[0], t[1], np.float64(x), np.float64(y))))
+                    if z - rho < h_here - 0.005:                      # the line runs inside this box: not this test's subject
+                        prev = None
+                        continue
+                    dtop, dwall, _ = terrain_probe(*t, (x, y, z), rho)
+                    depth = min(dtop, dwall, 0.0)                  # penetration only: clear of everything reads 0
+                    if prev is not None:
+                        worst = max(worst, abs(depth - prev))
+                        assert abs(depth - prev) <= step * 1.0001 + 1e-12, (name, x, y, z, prev, depth)
+                    prev = depth
+    assert worst > 0.0
 
 
 @pytest.mark.parametrize("name", ["gapped", "blocks", "mixed"])
