@@ -102,6 +102,8 @@ def lib():
             "nmf_batch_create": (vp, [vp, ci, ci]),
             "nmf_batch_destroy": (None, [vp]),
             "nmf_batch_n_worlds": (ci, [vp]),
+            "nmf_model_contact_bound": (ci, [vp]),
+            "nmf_batch_set_contact_capacity": (ci, [vp, ci]),
             "nmf_reset": (ci, [vp, vp]),
             "nmf_reset_worlds": (ci, [vp, vp, vp]),
             "nmf_step": (ci, [vp, ci, vp]),
@@ -131,6 +133,13 @@ def lib():
 def check(rc: int) -> None:
     if rc != 0:
         raise NativeError(lib().nmf_last_error().decode() or "libnmf_hip call failed")
+
+
+def check_count(rc: int) -> int:
+    """For entry points that return a count (>= 0) or a negative error code."""
+    if rc < 0:
+        raise NativeError(lib().nmf_last_error().decode() or "libnmf_hip call failed")
+    return int(rc)
 
 
 def exported_symbols() -> list[str]:

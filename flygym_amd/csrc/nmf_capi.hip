@@ -165,6 +165,30 @@ extern "C" nmf_model* nmf_model_create(const void* blob, size_t nbytes) {
 
 extern "C" void nmf_model_destroy(nmf_model* model) { delete model; }
 
+// Most contacts the model's contact set can make in one step: a capsule touches with its two end spheres (and, over a
+// terrain with side faces, each of them with one face as well), a hull with up to sem_max_hull_contacts vertices (plus
+// one face).  The engine keeps nmf::kMaxCon of them.
+extern "C" int nmf_model_contact_bound(const nmf_model* m) {
+  if (!m) return fail("nmf_model_contact_bound: null model");
+  const HostArray* gt = m->find("geom_type"); const HostArray* so = m->find("sem_options"); const HostArray* tt = m->find("terrain_type");
+  if (!gt || !gt->is_int) return fail("nmf_model_contact_bound: model without geom_type");
+  const int per_hull = so && so->is_int && so->i.size() > 3 && so->i[3] >= 1 && so->i[3] <= 4 ? so->i[3] : 4;
+  const bool faces = tt && tt->is_int && !tt->i.empty() && tt->i[0] != 0 && so && so->i.size() > 4 && so->i[4] != 0;
+  int bound = 0;
+  for (int t : gt->i) bound += t == nmf::GEOM_CAPSULE ? (faces ? 4 : 2) : per_hull + (faces ? 1 : 0);
+  return bound;
+}
+
+extern "C" int nmf_batch_set_contact_capacity(nmf_batch* b, int max_contacts) {
+  if (!b) return fail("nmf_batch_set_contact_capacity: null batch");
+  if (max_contacts < 1) return fail("nmf_batch_set_contact_capacity: max_contacts must be at least 1");
+  const int cap = max_contacts > nmf::kMaxCon ? nmf::kMaxCon : max_contacts;
+  HIP_OK(hipSetDevice(b->device));
+  b->dm.max_contacts = cap;
+  HIP_OK(hipMemcpy(reinterpret_cast<char*>(b->dm_dev) + offsetof(nmf::DevModel, max_contacts), &cap, sizeof(int), hipMemcpyHostToDevice));
+  return cap;
+}
+
 extern "C" int nmf_model_dims(const nmf_model* m, int32_t out[10]) {
   if (!m) return fail("nmf_model_dims: null model");
   out[0] = m->nq; out[1] = m->nv; out[2] = m->nu; out[3] = m->nb; out[4] = m->nseg; out[5] = m->ng;
@@ -452,6 +476,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   }
   d.noslip_iter = 0;
   if (const HostArray* os2 = model->find("opt_solver")) { if (os2->i.size() > 1) d.noslip_iter = os2->i[1]; }
+  d.max_contacts = nmf::kMaxCon;
   d.solver_flags = 0;
   if (const char* e = getenv("NMF_SOLVER")) {      // diagnostics: primal | nohist (default: contact-space solve with the active-set history)
     const std::string v(e);

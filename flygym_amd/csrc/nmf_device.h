@@ -142,6 +142,9 @@ struct DevModel {
   // option/noslip_iterations of the CPU flavour (reference mujoco_globals.yaml:15): sweeps of the friction-only post-pass after the
   // Newton solve (contact-space solve only, nmf_dual.h); 0 on the batched path, as the reference's GPU class sets it
   int noslip_iter;
+  // contacts kept per world and step (nmf_batch_set_contact_capacity; HIPSimulation's max_contacts, reference
+  // warp/simulation.py:50-56): 1..kMaxCon.  Contacts beyond it — in geom order — are dropped and the step is counted as overflowed.
+  int max_contacts;
   const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
   const NMF_G float *key_qpos, *key_ctrl;
   const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;

@@ -1025,8 +1025,9 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     const int slot = geom_slot0[info & 0xff] + ((info >> 8) & 0xf);
     if (slot < kMaxCon) { s.c_info[slot] = info_pack(info & 0xff, -1, (info >> 12) & 0xff, 0) | (((info >> 20) & 7) << 24); s.c_D[slot] = X.dist[lane]; st3(s.c_r[slot], ld3(X.r[lane])); }
   }
-  const int ncon = total > kMaxCon ? kMaxCon : total;
-  if (lane == 0) { s.ncon = ncon; s.overflow = total > kMaxCon ? 1 : 0; }
+  const int cap = m.max_contacts;      // <= kMaxCon (nmf_batch_set_contact_capacity)
+  const int ncon = total > cap ? cap : total;
+  if (lane == 0) { s.ncon = ncon; s.overflow = total > cap ? 1 : 0; }
   WSYNC();
   {   // contacts with a terrain side face (their own frames): the stages that follow take the general path only if there are any
     if constexpr (rough) {

@@ -28,15 +28,21 @@ class HIPSimulation:
     Args:
         world: a configured :class:`~flygym_amd.compose.BaseWorld` with one fly.
         n_worlds: number of parallel worlds on this GPU.
-        max_constraints, max_contacts: accepted for signature compatibility with
-            ``GPUSimulation`` (``warp/simulation.py:50-56``).  The engine keeps up to 48 contacts
-            (192 constraint rows) per world in registers/LDS; overflow is reported through
-            :meth:`get_solver_stats` instead of being silently dropped.
+        max_contacts: contacts kept per world and step, as ``GPUSimulation``'s ``max_contacts`` sizes MJWarp's
+            contact arrays (``warp/simulation.py:50-56``) — up to the engine's 48 (lane = contact; 192 pyramid rows in
+            registers / LDS): ``contact_capacity = min(max_contacts, 48)``.  Contacts beyond the capacity, in geom
+            order, are dropped and the step counts as overflowed (:meth:`get_solver_stats` column 2;
+            :meth:`overflow_steps`); MJWarp drops them too but only prints.  ``contact_bound`` is the most contacts
+            the model's contact set can make at once: a model with ``contact_bound <= contact_capacity`` cannot
+            overflow; ``strict_contacts=True`` refuses any other model up front.
+        max_constraints: accepted for signature compatibility (four pyramid rows per kept contact + the tether's six).
+        strict_contacts: raise at construction if the model can make more contacts than the engine keeps.
         device: CUDA/HIP device index (one process per GPU for multi-GPU runs).
     """
 
     def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
-                 max_contacts: int = 500, device: int | None = None, _cpu_flavour: bool = False) -> None:
+                 max_contacts: int = 500, device: int | None = None, strict_contacts: bool = False,
+                 _cpu_flavour: bool = False) -> None:
         import torch
 
         if len(world.fly_lookup) == 0:
@@ -66,6 +72,13 @@ class HIPSimulation:
             self._batch_h = self._lib.nmf_batch_create(self._model_h, self.n_worlds, self.device_index)
         if not self._batch_h:
             raise _native.NativeError(self._lib.nmf_last_error().decode())
+        if int(max_contacts) < 1:
+            raise ValueError(f"max_contacts must be at least 1, got {max_contacts}")
+        self.contact_bound = _native.check_count(self._lib.nmf_model_contact_bound(self._model_h))
+        self.contact_capacity = _native.check_count(self._lib.nmf_batch_set_contact_capacity(self._batch_h, int(max_contacts)))
+        if strict_contacts and self.contact_bound > self.contact_capacity:
+            raise ValueError(f"this model's contact set can make {self.contact_bound} contacts in one step; the engine keeps "
+                             f"{self.contact_capacity} per world (max_contacts={max_contacts}, engine limit 48)")
         self._views = {}
         self._build_index_maps()
         # the MuJoCo attributes reference code reads most often (the reference's GPUSimulation keeps a CPU mj_model /
@@ -319,6 +332,11 @@ class HIPSimulation:
     def get_solver_stats(self):
         """``(n_worlds, 4)``: contacts, Newton iterations, contact-overflow flag, constraint rows."""
         return self.field("stats").clone()
+
+    def overflow_steps(self) -> int:
+        """Steps since the last reset, summed over the worlds, in which a world made more contacts than
+        ``contact_capacity`` and the surplus (highest geom indices) was dropped.  Synchronises."""
+        return int(self.field("stats_sum")[:, 3].sum().item())
 
     def set_actuator_inputs(self, fly_name: str, actuator_type, inputs) -> None:
         ids = self._ids_by_fly[fly_name]["actuators"][ActuatorType(actuator_type)]

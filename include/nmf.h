@@ -62,11 +62,21 @@ void nmf_model_destroy(nmf_model* model);
 /* out[0..9] = nq, nv, nu, nbody, nseg, ngeom, nsite, max_contacts, nsensordata, is_star */
 int nmf_model_dims(const nmf_model* model, int32_t out[10]);
 
+/* The most contacts the model's contact set can make in one step (capsules: two end spheres, hulls: up to four vertices;
+ * over a terrain with side faces one face contact more per probe).  The engine keeps at most 48 per world (out[7] of
+ * nmf_model_dims).  Negative on error. */
+int nmf_model_contact_bound(const nmf_model* model);
+
 /* Allocate the state of n_worlds identical worlds on `device` and reset them to the model's
  * "neutral" keyframe.  Replaces: mjw.put_data(nworld=...)  (warp/simulation.py:418-424). */
 nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device);
 void nmf_batch_destroy(nmf_batch* batch);
 int nmf_batch_n_worlds(const nmf_batch* batch);
+
+/* Contacts kept per world and step: min(max_contacts, 48); returns the capacity in effect (negative on error).  Contacts
+ * beyond it, in geom order, are dropped and the step counts as overflowed (stats column 2, nmf_stats overflow steps).
+ * Call between launches (synchronous).  Replaces: the nconmax of mjw.put_data  (warp/simulation.py:50-56, 418-424). */
+int nmf_batch_set_contact_capacity(nmf_batch* batch, int max_contacts);
 
 /* Reset every world to the neutral keyframe (qpos, ctrl from the keyframe; qvel = 0; time = 0)
  * and refresh the pose outputs.  Replaces GPUSimulation.reset (warp/simulation.py:64-71). */

@@ -178,6 +178,7 @@ typedef struct {
    * 1: MuJoCo-documented rules only — gradient / improvement against `tolerance`, line search iterated to its fixed
    *    point — kept untouched by kernel work so that the converged solution has an independent anchor */
   int noslip_on;                       /* 1: run the model's noslip_iter sweeps (the CPU class); 0: the batched class strips them */
+  int max_contacts;                    /* contacts kept per step (<= NMF_MAXCON; HIPSimulation's max_contacts): later ones, in geom order, are dropped and the step flagged */
   int solver_mode;
   /* scratch */
   real *w1, *w2, *w3, *w4, *w5, *H;
@@ -270,6 +271,7 @@ EXPORT void SFX(nmfo_model_dims)(const void* mv, int* out) {
 EXPORT void* SFX(nmfo_data_create)(const void* mv) {
   const omodel* m = (const omodel*)mv;
   odata* d = (odata*)calloc(1, sizeof(odata));
+  d->max_contacts = NMF_MAXCON;
   int nv = m->nv, nb = m->nb;
   d->qpos = ALLOC(m->nq); d->qvel = ALLOC(nv); d->ctrl = ALLOC(m->nu); d->qacc_warmstart = ALLOC(nv);
   d->xpos = ALLOC(nb * 3); d->xquat = ALLOC(nb * 4); d->xmat = ALLOC(nb * 9);
@@ -500,7 +502,7 @@ static void make_frame(real* frame, const real* n) {
 }
 
 static void add_contact(const omodel* m, odata* d, int g, real dist, const real* pos_surface, const real* n) {
-  if (d->ncon >= NMF_MAXCON) { d->overflow = 1; return; }
+  if (d->ncon >= d->max_contacts) { d->overflow = 1; return; }
   int c = d->ncon++;
   d->con_geom[c] = g; d->con_dist[c] = dist;
   for (int k = 0; k < 3; k++) d->con_pos[c][k] = pos_surface[k] - (real)0.5 * dist * n[k];
@@ -1194,6 +1196,7 @@ EXPORT void* SFX(nmfo_ptr)(const void* mv, void* dv, const char* name, int* coun
 
 EXPORT void SFX(nmfo_set_solver_mode)(void* dv, int mode) { ((odata*)dv)->solver_mode = mode; }
 EXPORT void SFX(nmfo_set_noslip)(void* dv, int on) { ((odata*)dv)->noslip_on = on; }
+EXPORT void SFX(nmfo_set_max_contacts)(void* dv, int n) { ((odata*)dv)->max_contacts = n < 1 ? 1 : (n > NMF_MAXCON ? NMF_MAXCON : n); }
 
 EXPORT void SFX(nmfo_ints)(const void* mv, void* dv, int* out, int* con_geom) {
   (void)mv; odata* d = (odata*)dv;

@@ -44,6 +44,7 @@ def _lib(precision: str):
             ("nmfo_ptr", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
             ("nmfo_set_solver_mode", None, [ctypes.c_void_p, ctypes.c_int]),
             ("nmfo_set_noslip", None, [ctypes.c_void_p, ctypes.c_int]),
+            ("nmfo_set_max_contacts", None, [ctypes.c_void_p, ctypes.c_int]),
             ("nmfo_ints", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
         ]:
             fn = getattr(lib, name + sfx)
@@ -75,6 +76,10 @@ class Oracle:
         self.cpu_flavour = bool(cpu_flavour)
         self._call("nmfo_set_noslip", self._d, int(self.cpu_flavour))
         self.reset()
+
+    def set_max_contacts(self, n: int):
+        """Contacts kept per step (``HIPSimulation(max_contacts=...)``; at most the engine's 48): later ones, in geom order, are dropped."""
+        self._call("nmfo_set_max_contacts", self._d, int(n))
 
     def _call(self, name, *args):
         return getattr(self._lib, name + self._sfx)(*args)

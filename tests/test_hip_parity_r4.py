@@ -221,3 +221,40 @@ def test_cells_narrower_than_a_hulls_footprint(torch_mod, oracle_lib):
         assert np.abs(qacc[w] - r.arr("qacc")).max() < 5e-3 * scale, f"state {w}"
         wide += sum(1 for x in r.ints()["con_geom"] if x in big)
     assert wide >= 2
+
+
+def test_max_contacts_is_the_contact_capacity(torch_mod, oracle_lib):
+    """``HIPSimulation(max_contacts=...)`` sizes the contact list as the reference's argument sizes MJWarp's
+    (``warp/simulation.py:50-56``), up to the engine's 48.  A standing fly makes 6-12 contacts: with a capacity of 4 the
+    engine keeps the four with the lowest geom indices, solves with those — like the oracle given the same capacity — and
+    counts the step as overflowed; the default capacity keeps them all.  ``strict_contacts`` refuses a model whose contact
+    set could exceed the capacity."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation, make_model
+
+    fly, world, _ = make_model()
+    full = HIPSimulation(world, n_worlds=2, device=0)
+    assert full.contact_capacity == 48 and full.contact_bound > 48 and full.max_contacts == 500
+    full.step(400)
+    state = {k: full.field(k)[0].cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    n_full = int(full.get_solver_stats()[0, 0].item())
+    assert n_full >= 6 and full.overflow_steps() == 0
+    sim = HIPSimulation(make_model()[1], n_worlds=2, max_contacts=4, device=0)
+    assert sim.contact_capacity == 4
+    for k, v in state.items(): sim.field(k)[:] = torch.as_tensor(v, dtype=torch.float32, device=sim.device)[None]
+    sim.step(1)
+    torch.cuda.synchronize()
+    stats = sim.get_solver_stats().cpu().numpy()
+    assert stats[0, 0] == 4 and stats[0, 2] == 1 and sim.overflow_steps() == 2
+    r = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+    r.set_max_contacts(4)
+    for k, v in state.items(): r.arr(k)[:] = v
+    r.step(1)
+    assert r.ints()["ncon"] == 4 and r.ints()["overflow"] == 1
+    assert sim.field("contact_geom")[0, :4].cpu().numpy().astype(int).tolist() == r.ints()["con_geom"]
+    a = r.arr("qacc")
+    assert np.abs(sim.field("qacc")[0].cpu().numpy() - a).max() < 2e-3 * np.abs(a).max()
+    with pytest.raises(ValueError, match="contacts in one step"):
+        HIPSimulation(make_model()[1], n_worlds=2, device=0, strict_contacts=True)
+    with pytest.raises(ValueError):
+        HIPSimulation(make_model()[1], n_worlds=2, device=0, max_contacts=0)

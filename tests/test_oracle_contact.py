@@ -206,3 +206,21 @@ def test_adhesion_acts_through_the_adhesion_segments_own_geom(oracle_lib):
     m2, geoms2, expected2, measured2 = _adhesion_pull_check(oracle_lib, "fused_body")
     np.testing.assert_allclose(measured2, expected2, rtol=1e-9, atol=1e-12)
     assert np.abs(expected - expected2).max() > 1e-3 * np.abs(expected).max()     # the two readings differ here
+
+
+def test_contact_capacity_drops_the_highest_geoms(settled):
+    """``set_max_contacts`` (HIPSimulation's ``max_contacts``): the contact list is cut in geom order and the step is
+    flagged; the kept contacts are the uncut list's first ones, and they alone carry the fly (so each is loaded more)."""
+    _, o = settled
+    o = o.clone_data()
+    o.forward()
+    geoms, ncon = o.ints()["con_geom"], o.ints()["ncon"]
+    assert ncon >= 6 and o.ints()["overflow"] == 0
+    cut = o.clone_data()
+    cut.set_max_contacts(4)
+    cut.forward()
+    assert cut.ints()["ncon"] == 4 and cut.ints()["overflow"] == 1 and cut.ints()["con_geom"] == geoms[:4]
+    np.testing.assert_array_equal(cut.arr("con_dist"), o.arr("con_dist")[:4])
+    cut.set_max_contacts(500)                                         # beyond the engine's 48: 48
+    cut.forward()
+    assert cut.ints()["ncon"] == ncon and cut.ints()["overflow"] == 0
