@@ -152,7 +152,7 @@ def test_abi_model_parse_and_loud_failure_without_gpu(bench_model):
     dims = (ctypes.c_int32 * 10)()
     assert L.nmf_model_dims(h, dims) == 0
     assert list(dims)[:7] == [73, 72, 48, 49, 69, 55, 0] and dims[9] == 1
-    # the most contacts the contact set can make at once: 30 tarsal capsules x 2 end spheres + 25 hulls x 4 vertices
+    # the most contacts the contact set can make at once: 6 capsules x 2 end spheres + 49 hulls x 4 vertices = 208
     gt = np.asarray(m["geom_type"]).ravel()
     assert L.nmf_model_contact_bound(h) == int(2 * (gt == 0).sum() + 4 * (gt == 1).sum()) > dims[7] == 48
     assert L.nmf_batch_set_contact_capacity(None, 10) < 0 and b"null batch" in L.nmf_last_error()
