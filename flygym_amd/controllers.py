@@ -37,17 +37,26 @@ class TripodCPG:
         self.timestep = float(timestep)
         self.frequency = float(frequency)
         self.n_bins = int(n_phase_bins)
-        clip = MotionSnippet().get_joint_angles(timestep, self.actuated_dofs)          # (T, 42) at the sim timestep
+        # (T, n) at the sim timestep.  Dofs the walking clip does not have (ALL_POSSIBLE's extra axes of the leg joints) are
+        # held at zero, their neutral angle.
+        snippet = MotionSnippet()
+        in_clip = [(d.parent.link, d.child.link, d.axis.value) in snippet.dofs_per_leg for d in self.actuated_dofs]
+        known = [d for d, k in zip(self.actuated_dofs, in_clip) if k]
+        part = snippet.get_joint_angles(timestep, known)
+        clip = np.zeros((part.shape[0], len(self.actuated_dofs)), dtype=part.dtype)
+        clip[:, np.nonzero(in_clip)[0]] = part
         self.leg_of_dof = np.array([LEGS.index(d.child.pos) for d in self.actuated_dofs])
         self.cycle = np.zeros((self.n_bins, len(self.actuated_dofs)), dtype=np.float32)
         for leg in range(6):
             cols = np.where(self.leg_of_dof == leg)[0]
-            self.cycle[:, cols] = self._step_cycle(clip[:, cols])
+            knee = [i for i, c in enumerate(cols) if (self.actuated_dofs[c].parent.link, self.actuated_dofs[c].child.link,
+                                                      self.actuated_dofs[c].axis.value) == ("trochanterfemur", "tibia", "pitch")]
+            self.cycle[:, cols] = self._step_cycle(clip[:, cols], knee[0] if knee else min(5, len(cols) - 1))
 
-    def _step_cycle(self, angles: np.ndarray) -> np.ndarray:
-        """One periodic stride of a leg: stance/swing onsets from the femur-tibia (4th actuated) angle's
+    def _step_cycle(self, angles: np.ndarray, key_col: int) -> np.ndarray:
+        """One periodic stride of a leg: stance/swing onsets from the trochanterfemur-tibia pitch angle's
         upward mean crossings, strides resampled to ``n_bins`` phase bins and averaged."""
-        key = angles[:, min(5, angles.shape[1] - 1)]
+        key = angles[:, key_col]
         centred = key - key.mean()
         onsets = np.where((centred[:-1] < 0) & (centred[1:] >= 0))[0]
         onsets = onsets[np.diff(onsets, prepend=-10 ** 9) > int(0.02 / self.timestep)]   # debounce 20 ms

@@ -26,22 +26,19 @@
 
 namespace nmf {
 
-template <class TP>
-struct DualFactors {
-  float leg[TP::NLEG * TP::NDL][8];     // per leg hinge: U / sqrt(D) (6), 1 / sqrt(D), pad
-  float root[6][8];                     // the six root axes in elimination order (angular z, y, x, linear z, y, x)
-};
-template <class TP>
-__device__ __forceinline__ DualFactors<TP>& dual_factors(FlyLds<TP>& s) {
-  static_assert(sizeof(DualFactors<TP>) <= sizeof(float) * 12 * kMaxCon, "articulated-body factors do not fit c_w + c_m3");
-  return *reinterpret_cast<DualFactors<TP>*>(&s.c_w[0][0]);
-}
-// A's lower triangle, row i at i (i + 1) / 2: over Ib..W (+ dual_pad)
+// (the factors' homes: dual_leg / dual_root / dual_aref / dual_acc in nmf_step.hip)
+// A's lower triangle, row i at i (i + 1) / 2: over Ib..W (+ dual_pad); hybrid kernels: over T..W (Ib is their one copy of
+// the inertias)
 template <class TP>
 __device__ __forceinline__ float* dual_a(FlyLds<TP>& s) {
-  static_assert(sizeof(float) * (4 * kDualMaxCon) * (4 * kDualMaxCon + 1) / 2 <= sizeof(s.Ib) + sizeof(s.T) + sizeof(s.W) + sizeof(s.dual_pad),
-                "A does not fit Ib..W");
-  return &s.Ib[0][0];
+  constexpr size_t need = sizeof(float) * (4 * kDualMaxCon<TP>) * (4 * kDualMaxCon<TP> + 1) / 2;
+  if constexpr (kDualH<TP>) {
+    static_assert(!kDualH<TP> || need <= sizeof(s.T) + sizeof(s.W), "A does not fit T..W");
+    return &s.T[0][0];
+  } else {
+    static_assert(kDualH<TP> || need <= sizeof(s.Ib) + sizeof(s.T) + sizeof(s.W) + sizeof(s.dual_pad), "A does not fit Ib..W");
+    return &s.Ib[0][0];
+  }
 }
 __device__ __forceinline__ float quad_sum(float v) {
   v += NMF_DPP(v, 0xB1);
@@ -105,8 +102,10 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   lane = opaque(lane);
   ncon = __builtin_amdgcn_readfirstlane(ncon);
   walls = __builtin_amdgcn_readfirstlane((int)walls) != 0;
+  constexpr bool kWarm = kDualS<TP>;      // warm-start term c e and the active-set history (see kDualS / kDualH)
   const Frame fr0 = ld_frame(s, m);
-  DualFactors<TP>& DF = dual_factors(s);
+  float (*const DFleg)[8] = dual_leg(s);
+  float (*const DFroot)[8] = dual_root(s);
   float* const At = dual_a(s);
   const int n4 = 4 * ncon;
   const bool on = lane < n4;
@@ -133,34 +132,49 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // this step's result
   const int hist_g = info_geom(info);
   int hist_slot = 0;
+  unsigned int hist_nib = 0u;
+  bool hist_any = false;
 #pragma unroll
   for (int o = 1; o <= 3; ++o) hist_slot += (cc >= o && info_geom(s.c_info[cc >= o ? cc - o : 0]) == hist_g) ? 1 : 0;
-  const unsigned int hist_nib = on && hist_slot < 4 ? (s.act_hist[hist_g >> 1] >> ((hist_g & 1) * 16 + 4 * hist_slot)) & 0xfu : 0u;
-  const bool hist_any = __ballot(hist_nib != 0u) != 0ull;
+  if constexpr (kDualS<TP>) hist_nib = on && hist_slot < 4 ? (s.act_hist[hist_g >> 1] >> ((hist_g & 1) * 16 + 4 * hist_slot)) & 0xfu : 0u;
+  else {       // the list of the last solved step's contacts (kHistLds): the entry of the same geom and ordinal
+    const unsigned int key = 0x4000u | (unsigned int)hist_g | ((unsigned int)hist_slot << 8);
+#pragma unroll
+    for (int i = 0; i < kHistLds<TP>; ++i) {
+      const unsigned int wd = s.act_hist[i];
+      if ((wd & 0x43ffu) == key) hist_nib = (wd >> 10) & 0xfu;
+      if (((wd >> 16) & 0x43ffu) == key) hist_nib = (wd >> 26) & 0xfu;
+    }
+    if (!(on && hist_slot < 4)) hist_nib = 0u;
+  }
+  hist_any = __ballot(hist_nib != 0u) != 0ull;
   WSYNC();
-  if (lane < kActHistWords) s.act_hist[lane] = 0u;
+  if (lane < kHistLds<TP>) s.act_hist[lane] = 0u;
 
   // ---- j0 = J qacc_smooth - aref (the smooth solve left twists(qacc_smooth) in T); warm start e = qacc_ws - qacc_smooth:
   // je = J e, eMe = e.M e
   float j0 = 0.f, je = 0.f;
-  if (on) j0 = dot(wrow, ldsv(s.T[body])) - s.vB[lane];
-  for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qacc[j] - s.qacc_smooth[j];
-  WSYNC();
-  sweep_twists(s, s.vA, s.T, m, lane);
+  if (on) j0 = dot(wrow, ldsv(s.T[body])) - dual_aref(s)[lane];
   float eMe = 0.f;
-  if (on) je = dot(wrow, ldsv(s.T[body]));
-  for (int b = lane; b < TP::NB; b += kWave) { const SV tb = ldsv(s.T[b]); eMe += dot(tb, inert_mul(s.Ib[b], tb)); }
-  for (int j = lane; j < TP::NV; j += kWave) eMe += s.arm[j] * s.vA[j] * s.vA[j];
   float c_ws;      // the scalar c: 1 = warm start, 0 = unconstrained acceleration
   float gauss, ccost;
-  {
+  if constexpr (kWarm) {
+    for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qacc[j] - s.qacc_smooth[j];
+    WSYNC();
+    sweep_twists(s, s.vA, s.T, m, lane);
+    if (on) je = dot(wrow, ldsv(s.T[body]));
+    for (int b = lane; b < TP::NB; b += kWave) { const SV tb = ldsv(s.T[b]); eMe += dot(tb, inert_mul(s.Ib[b], tb)); }
+    for (int j = lane; j < TP::NV; j += kWave) eMe += s.arm[j] * s.vA[j] * s.vA[j];
     const float x1 = j0 + je;
     const float v_ws = on && x1 < 0.f ? 0.5f * D * x1 * x1 : 0.f, v_sm = on && j0 < 0.f ? 0.5f * D * j0 * j0 : 0.f;
     eMe = wave_sum(eMe);
     const float cost_ws = 0.5f * eMe + wave_sum(v_ws), cost_sm = wave_sum(v_sm);
     if (cost_sm < cost_ws) { c_ws = 0.f; gauss = 0.f; ccost = cost_sm; } else { c_ws = 1.f; gauss = 0.5f * eMe; ccost = cost_ws - 0.5f * eMe; }
+  } else {       // start from the unconstrained acceleration
+    c_ws = 0.f; gauss = 0.f;
+    ccost = wave_sum(on && j0 < 0.f ? 0.5f * D * j0 * j0 : 0.f);
   }
-  WSYNC();       // T, Ib are free from here: A goes there
+  WSYNC();       // T (and, for the stars, Ib) are free from here: A goes there
   STAGE(8);
 
   // ---- responses of the unit forces, lane = (contact, direction n / t1 / t2)
@@ -170,7 +184,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const V3 tq = cross(r, dm);
     float w[6] = {tq.x, tq.y, tq.z, dm.x, dm.y, dm.z};
     const lds_cptr Sl = lds_pinned(&s.S[TP::LD0 + legA * NDL][0]);
-    const lds_cptr Fl = lds_pinned(&DF.leg[legA * NDL][0]);
+    const lds_cptr Fl = lds_pinned(&DFleg[legA * NDL][0]);
     static_for<NDL>([&](auto DD) {
       constexpr int d = NDL - 1 - decltype(DD)::value;
       float sj[6], f[7];
@@ -190,7 +204,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       constexpr int i = decltype(II)::value, e = dual_root_axis(i);
       float f[7];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) f[q] = DF.root[i][q];
+      for (int q = 0; q < 7; ++q) f[q] = DFroot[i][q];
       const float u = w[e] * f[6];
       ur[i] = u;
 #pragma unroll
@@ -345,17 +359,20 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // the final active set, for the next step
   {
     const unsigned long long fin = __ballot(on && jar < 0.f);
-    if (on && k == 0 && hist_slot < 4) {
-      const unsigned int nib = (unsigned int)(fin >> (4 * cc)) & 0xfu;
-      atomicOr(&s.act_hist[hist_g >> 1], nib << ((hist_g & 1) * 16 + 4 * hist_slot));
+    const unsigned int nib = (unsigned int)(fin >> (4 * cc)) & 0xfu;
+    if constexpr (kDualS<TP>) {
+      if (on && k == 0 && hist_slot < 4) atomicOr(&s.act_hist[hist_g >> 1], nib << ((hist_g & 1) * 16 + 4 * hist_slot));
+    } else {     // entry of contact cc in half (cc & 1) of word cc / 2: lane 8 i packs contacts 2 i and 2 i + 1
+      const unsigned int entry = on && k == 0 && hist_slot < 4 ? 0x4000u | (unsigned int)hist_g | ((unsigned int)hist_slot << 8) | (nib << 10) : 0u;
+      const unsigned int other = (unsigned int)__builtin_amdgcn_ds_bpermute(((lane + 4) & 63) << 2, (int)entry);
+      if (on && (lane & 7) == 0) s.act_hist[lane >> 3] = entry | (other << 16);
     }
   }
   STAGE(9);
 
   // ---- qacc = qacc_smooth + c e + M^-1 J^T lambda: the rows' responses summed per hinge (root axes: wave sums; leg hinges:
   // LDS adds, the rows of a leg are few), then root-to-leaf over the factors
-  float* const acc = s.vB;                       // [NLEG * NDL leg hinges | 6 root axes]
-  static_assert(NLEG * NDL + 6 <= 3 * TP::NV, "hinge sums do not fit vB..vD");
+  float* const acc = dual_acc(s);                // [NLEG * NDL leg hinges | 6 root axes]
   for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
   WSYNC();
   {
@@ -380,21 +397,30 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     float a = 0.f, xw[6];
     static_for<6>([&](auto II) {
       constexpr int i = 5 - decltype(II)::value, e = dual_root_axis(i);
-      const float xe = DF.root[i][6] * (acc[NLEG * NDL + i] - grp8_sum(L.mask * DF.root[i][L.rr] * a));
+      const float xe = DFroot[i][6] * (acc[NLEG * NDL + i] - grp8_sum(L.mask * DFroot[i][L.rr] * a));
       xw[e] = xe;
       a = L.rr == e ? a + xe : a;
     });
     if (lane < 3) {
-      s.qacc[lane] = s.qacc_smooth[lane] + c_ws * s.vA[lane] + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
-      s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + c_ws * s.vA[3 + lane] + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
+      s.qacc[lane] = s.qacc_smooth[lane] + (kWarm ? c_ws * s.vA[lane] : 0.f) + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
+      s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + (kWarm ? c_ws * s.vA[3 + lane] : 0.f) + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
     }
     const int jb = TP::LD0 + L.lg * NDL;
     static_for<NDL>([&](auto DD) {
       constexpr int d = decltype(DD)::value;
-      const float xj = DF.leg[L.lg * NDL + d][6] * (acc[L.lg * NDL + d] - grp8_sum(L.mask * DF.leg[L.lg * NDL + d][L.rr] * a));
-      s.qacc[jb + d] = s.qacc_smooth[jb + d] + c_ws * s.vA[jb + d] + xj;
+      const float xj = DFleg[L.lg * NDL + d][6] * (acc[L.lg * NDL + d] - grp8_sum(L.mask * DFleg[L.lg * NDL + d][L.rr] * a));
+      s.qacc[jb + d] = s.qacc_smooth[jb + d] + (kWarm ? c_ws * s.vA[jb + d] : 0.f) + xj;
       a = fmaf(xj, s.S[jb + d][L.rr], a);
     });
+    if constexpr (kDualH<TP>) {
+      // the rest of the body follows the root: its accelerations are the unconstrained ones + the response of the smooth
+      // solve's cached factors to the root's change (one root-to-leaf pass, as at the end of the primal loop's reduced problem)
+      WSYNC();       // (A, in T..W, is dead)
+      if (lane < 6) s.T[0][lane] = lane == 0 ? xw[0] : lane == 1 ? xw[1] : lane == 2 ? xw[2] : lane == 3 ? xw[3] : lane == 4 ? xw[4] : xw[5];
+      WSYNC();
+      if (m.rest_fast) rest_levels<TP, true, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 3, true>(s, nd, s.qacc, L); });
+      else rest_levels<TP, false, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 0, true>(s, nd, s.qacc, L); });
+    }
   }
   WSYNC();      // the factors are dead: c_w takes the contact wrenches again
   STAGE(14);

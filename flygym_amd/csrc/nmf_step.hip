@@ -158,17 +158,48 @@ constexpr int conflict_free_width(int rows_per_leg, int nleg) {
 }
 template <class TP> constexpr int row_width_s() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NDL, TP::NLEG) : 6; else return 6; }
 template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6; else return 6; }
-// Star kernels without a rest-of-body tree solve the constraints in contact space (nmf_dual.h) while a step has at most
-// kDualMaxCon contacts (A's triangle in LDS).  NMF_NO_DUAL: development switch, every step on the primal loop.
-constexpr int kDualMaxCon = 12;
+// Leg-chain kernels solve the constraints in contact space (nmf_dual.h) while a step has at most kDualMaxCon<TP> contacts
+// (A's triangle in LDS).  Two flavours:
+//  * kDualS — stars without a rest-of-body tree (LEGS_ONLY, LEGS_ACTIVE_ONLY): factors on c_w + c_m3, A on Ib..W (the
+//    inertias live a second time in Isym), warm start blended in, previous step's active set as first guess (act_hist);
+//  * kDualH — hybrid kernels whose leg factors fit the four solver vectors (ALL_BIOLOGICAL): no LDS to spare, so the
+//    leg factors go to vA..vD, the root's, the rows' reference accelerations and the hinge sums to c_w, A to T..W only
+//    (Ib is the one copy of the inertias), no warm-start term and no history.  Steps with a contact on the rest of the
+//    body take the primal loop.
+// NMF_NO_DUAL: development switch, every step on the primal loop.
+template <class TP> constexpr bool dual_hybrid() {
+  if constexpr (TP::kStar) return TP::REST_B > 0 && 4 * TP::NV >= TP::NLEG * TP::NDL * 8; else return false;
+}
 #ifdef NMF_NO_DUAL
-template <class TP> inline constexpr bool kDual = false;
+template <class TP> inline constexpr bool kDualS = false;
+template <class TP> inline constexpr bool kDualH = false;
 #else
-template <class TP> inline constexpr bool kDual = has_cm3<TP>();
+template <class TP> inline constexpr bool kDualS = has_cm3<TP>();
+#ifdef NMF_NO_DUAL_HYBRID
+template <class TP> inline constexpr bool kDualH = false;
+#else
+template <class TP> inline constexpr bool kDualH = dual_hybrid<TP>();
 #endif
+#endif
+template <class TP> inline constexpr bool kDual = kDualS<TP> || kDualH<TP>;
+template <class TP> constexpr int dual_max_con() {
+  if constexpr (kDualH<TP>) {      // the rows whose triangle fits T..W
+    int n = 0;
+    while (n < 12 && (4 * (n + 1)) * (4 * (n + 1) + 1) / 2 <= 2 * TP::NB * 6) ++n;
+    return n;
+  } else return 12;
+}
+template <class TP> inline constexpr int kDualMaxCon = dual_max_con<TP>();
+// LDS words of the active-set history (the contact-space solve's first guess, DevState::act_hist).  kDualS: a table by geom,
+// 16 bits per geom (4 contacts x 4 rows); kDualH (32 bytes of LDS to spare): a list, one 16-bit entry per contact of the
+// last solved step — geom (8) | ordinal within the geom (2) | active rows (4) | valid (1) — which the rows search.
+template <class TP> inline constexpr int kHistLds = kDualS<TP> ? kActHistWords : kDualH<TP> ? (kDualMaxCon<TP> + 1) / 2 : 0;
+template <class TP, class M> __device__ __forceinline__ int hist_words(const M& m) {      // ... of them in use
+  if constexpr (kDualS<TP>) return (m.ng + 1) / 2; else return kHistLds<TP>;
+}
 template <class TP> constexpr int dual_pad_floats() {
-  if constexpr (kDual<TP>) {
-    constexpr int need = (4 * kDualMaxCon) * (4 * kDualMaxCon + 1) / 2;      // A's lower triangle (nmf_dual.h)
+  if constexpr (kDualS<TP>) {
+    constexpr int need = (4 * kDualMaxCon<TP>) * (4 * kDualMaxCon<TP> + 1) / 2;      // A's lower triangle (nmf_dual.h)
     constexpr int have = TP::NB * 11 + 2 * TP::NB * (TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6);
     return need > have ? need - have : 0;
   } else return 0;
@@ -215,7 +246,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // floats apart where LDS allows: lane = body loops then hit 32 different banks (stride 10: bodies b and b + 16 collide)
   float Isym[kHasIsym<TP> ? TP::NB : 1][kHasIsym<TP> ? 21 : 1];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
   // (Ib, T, W are contiguous and 16-byte aligned: the contact-space solve (nmf_dual.h) keeps its per-contact response vectors there)
-  alignas(kDual<TP> ? 16 : 4) float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
+  alignas(kDualS<TP> ? 16 : 4) float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
   static_assert(7 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
   __device__ __forceinline__ float (*xmat())[9] { return reinterpret_cast<float(*)[9]>(&xmat_root[0]); }
@@ -232,7 +263,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   float dlt[kHasCm3<TP> ? TP::NV : 1];   // armature + timestep * damping: the diagonal term of the Euler step's solve (star kernels)
   float c_r[kMaxCon][3], c_D[kMaxCon], c_mu[kMaxCon];   // c_D holds the distance until setup
   int c_info[kMaxCon];                  // geom | (leg sensor + 1) << 8 | body << 12 | active-row mask << 20
-  alignas(kDual<TP> ? 16 : 4) float xpos_pad_[kDual<TP> ? 1 : 0];
+  alignas(kDualS<TP> ? 16 : 4) float xpos_pad_[kDualS<TP> ? 1 : 0];
   float xpos_root[3];
   // (c_w, c_m3 are contiguous and 16-byte aligned: between the smooth solve and the end of the contact-space solve they hold
   // the articulated-body factors of the mass matrix, DualFactors)
@@ -266,7 +297,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
     } else return this->slot[k];
   }
   // the constraint solver's second warm start (DevState::act_hist), carried from step to step: 16 bits per geom
-  unsigned int act_hist[kDual<TP> ? kActHistWords : 0];
+  unsigned int act_hist[kHistLds<TP>];
   int ncon, overflow, iters;
   int nwall;                            // contacts of this step that touch a terrain side face (frame id != 0)
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
@@ -1329,8 +1360,45 @@ __device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
   return q;
 }
 
-template <class TP> struct DualFactors;
-template <class TP> __device__ __forceinline__ DualFactors<TP>& dual_factors(FlyLds<TP>& s);
+// Where the contact-space solve (nmf_dual.h) keeps its data — all overlays of buffers that are dead between the smooth
+// solve and the end of the constraint solve.  Per leg hinge / root axis a factor row of 8 floats: U / sqrt(D) (6),
+// 1 / sqrt(D), pad; the root's six axes in elimination order (angular z, y, x, linear z, y, x).
+//   kDualS: factors on c_w + c_m3, the rows' reference accelerations and later the hinge sums on vB;
+//   kDualH: leg factors on vA..vD, the root's + reference accelerations + hinge sums on c_w (its rest hand-off slots are
+//           consumed before the root is eliminated).
+template <class TP> __device__ __forceinline__ float (*dual_leg(FlyLds<TP>& s))[8] {
+  if constexpr (kDualH<TP>) {
+    static_assert(!kDualH<TP> || 4 * TP::NV >= TP::NLEG * TP::NDL * 8, "leg factors do not fit vA..vD");
+    return reinterpret_cast<float(*)[8]>(&s.vA[0]);
+  } else {
+    static_assert(sizeof(float) * 8 * (TP::NLEG * TP::NDL + 6) <= sizeof(float) * 12 * kMaxCon, "articulated-body factors do not fit c_w + c_m3");
+    return reinterpret_cast<float(*)[8]>(&s.c_w[0][0]);
+  }
+}
+template <class TP> __device__ __forceinline__ float (*dual_root(FlyLds<TP>& s))[8] {
+  if constexpr (kDualH<TP>) return reinterpret_cast<float(*)[8]>(&s.c_w[0][0]);
+  else return dual_leg(s) + TP::NLEG * TP::NDL;
+}
+template <class TP> __device__ __forceinline__ float* dual_aref(FlyLds<TP>& s) {
+  if constexpr (kDualH<TP>) return &s.c_w[0][0] + 48; else return s.vB;
+}
+// the contact wrenches Euler's solve applies as body forces: c_w, except in the hybrid kernels, whose solves use c_w for
+// the rest's hand-off slots — physics_integrate copies them to vC first
+template <class TP> __device__ __forceinline__ float (*dual_wrench(FlyLds<TP>& s))[7] {
+  if constexpr (kDualH<TP>) {
+    static_assert(!kDualH<TP> || 7 * kDualMaxCon<TP> <= TP::NV, "contact wrenches do not fit vC");
+    return reinterpret_cast<float(*)[7]>(&s.vC[0]);
+  } else return s.c_w;
+}
+template <class TP> __device__ __forceinline__ float* dual_acc(FlyLds<TP>& s) {       // [NLEG * NDL leg hinges | 6 root axes]
+  if constexpr (kDualH<TP>) {
+    static_assert(!kDualH<TP> || 96 + TP::NLEG * TP::NDL + 6 <= 7 * kMaxCon, "hinge sums do not fit c_w");
+    return &s.c_w[0][0] + 96;
+  } else {
+    static_assert(TP::NLEG * TP::NDL + 6 <= 3 * TP::NV, "hinge sums do not fit vB..vD");
+    return s.vB;
+  }
+}
 
 // WITHK_ (leg-chain kernels that have the contact-space solve): the contact stiffness rows are compiled into the solve at all
 // — only the primal Newton loop's instantiation has them, so the two solves of an ordinary step (smooth, Euler) run a function
@@ -1412,13 +1480,16 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 #pragma unroll
         for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
         if constexpr (kDual<TP>) {
-          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= s.c_w[c][L.rr];
+          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
         }
         if (withK) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
         add6(IA, row);
       } else {
         add_inertia_row(IA, s, b, IM);
-        for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr, L.rr, walls);
+        if constexpr (kDual<TP>) {
+          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
+        }
+        if (withK) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr, L.rr, walls);
       }
     }
     float sj[6];
@@ -1432,7 +1503,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (kDual<TP>) {
       if (store) {      // rows 0..5: U / sqrt D; lanes 6, 7 of the group: 1 / sqrt D
         const float rs = __builtin_sqrtf(invDraw);
-        dual_factors(s).leg[L.lg * TP::NDL + d][L.r < 6 ? L.r : 6] = L.r < 6 ? Uraw * rs : rs;
+        dual_leg(s)[L.lg * TP::NDL + d][L.r < 6 ? L.r : 6] = L.r < 6 ? Uraw * rs : rs;
       }
     }
   });
@@ -1461,7 +1532,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     }
     pA = 0.f;
     if constexpr (kDual<TP>) {
-      if (withF) for (int c = cs_root0; c < cs_root1; ++c) pA -= s.c_w[c][L.rr];
+      if (withF) for (int c = cs_root0; c < cs_root1; ++c) pA -= dual_wrench(s)[c][L.rr];
     }
 #pragma unroll
     for (int k = 0; k < TP::NLEG; ++k) {
@@ -1517,7 +1588,7 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       if constexpr (kDual<TP>) {
         if (store) {
           const float rs = __builtin_sqrtf(invD);
-          dual_factors(s).root[i][L.r < 6 ? L.r : 6] = L.r < 6 ? U * rs : rs;
+          dual_root(s)[i][L.r < 6 ? L.r : 6] = L.r < 6 ? U * rs : rs;
         }
       }
     });
@@ -1911,7 +1982,8 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   STAGE(6);
   // ---- unconstrained acceleration
   // contact-space solve (nmf_dual.h) for steps with 1..kDualMaxCon contacts: the smooth solve keeps its factors for it
-  const bool dual = kDual<TP> && !WELD && ncon > 0 && ncon <= kDualMaxCon && !(m.solver_flags & 1);
+  bool dual = kDual<TP> && !WELD && ncon > 0 && ncon <= kDualMaxCon<TP> && !(m.solver_flags & 1);
+  if constexpr (kDualH<TP>) dual = dual && __builtin_amdgcn_readfirstlane(s.body_cstart[TP::LB0] == s.body_cstart[1] ? 1 : 0) != 0;     // no contact on the rest of the body
   aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane, dual);
   contact_reload(c, s, lane);
   STAGE(7);
@@ -1923,14 +1995,14 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     if (dual) {
       if (c.on) {      // reference accelerations of the rows: lane = row from here on
 #pragma unroll
-        for (int k = 0; k < 4; k++) s.vB[4 * lane + k] = c.aref[k];
+        for (int k = 0; k < 4; k++) dual_aref(s)[4 * lane + k] = c.aref[k];
       }
       WSYNC();
-      iters = dual_solve<TP, kDualMaxCon>(s, m, lane, ncon, walls STAGE_PASS);
+      iters = dual_solve<TP, kDualMaxCon<TP>>(s, m, lane, ncon, walls STAGE_PASS);
       solved = true;
     }
   }
-  if constexpr (kDual<TP>) { if (!solved && lane < kActHistWords) s.act_hist[lane] = 0u; }      // nothing known for the next step
+  if constexpr (kDual<TP>) { if (!solved && lane < kHistLds<TP>) s.act_hist[lane] = 0u; }      // nothing known for the next step
   // a step the contact-space solve cannot take has no noslip pass: flagged with the overflow counter, never silent
   if (m.noslip_iter > 0 && !solved && ncon > 0 && lane == 0) s.overflow = 1;
   if (solved) {
@@ -2196,7 +2268,16 @@ __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane, bool
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   wrenches = __builtin_amdgcn_readfirstlane((int)wrenches) != 0;
-  if (wrenches) aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_B, false, h, m, lane, false, true);
+  if (wrenches) {
+    if constexpr (kDualH<TP>) {      // (see dual_wrench)
+      if (lane < s.ncon) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dual_wrench(s)[lane][i] = s.c_w[lane][i];
+      }
+      WSYNC();
+    }
+    aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_B, false, h, m, lane, false, true);
+  }
   else {
     for (int j = lane; j < s.nv(); j += kWave) s.vA[j] = s.qfrc_smooth[j] + s.vD[j];
     WSYNC();
@@ -2273,10 +2354,10 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
     // lanes 0..5: the clock (float bits) and what the world's items have accumulated so far (steps, contacts, iterations,
     // overflow steps: unsigned integers; cycles: float bits): one store; the launch's final item adds them to the world's counters
     if (lane < 6) st_tagged_u(&hb[nq + 2 * nv + m.nu + lane], lane == 0 ? __float_as_uint(time) : carry, tag);
-    if constexpr (kDual<TP>) { if (lane < (m.ng + 1) / 2) st_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + lane], s.act_hist[lane], tag); }
+    if constexpr (kDual<TP>) { if (lane < hist_words<TP>(m)) st_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + lane], s.act_hist[lane], tag); }
     return;
   }
-  if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < (m.ng + 1) / 2 ? s.act_hist[lane] : 0u; }
+  if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < hist_words<TP>(m) ? s.act_hist[lane < kHistLds<TP> ? lane : 0] : 0u; }
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
@@ -2484,7 +2565,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           for (int i = ln; i < nv; i += kWave) { s.qvel[i] = ld_tagged(&hb[nq + i], want, ok); s.qacc[i] = ld_tagged(&hb[nq + nv + i], want, ok); }
           for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_tagged(&hb[nq + 2 * nv + i], want, ok);
           carry = lane < 6 ? ld_tagged_u(&hb[nq + 2 * nv + m.nu + ln], want, ok) : 0u;     // lane 0: the clock; 1..5: running sums
-          if constexpr (kDual<TP>) { s.act_hist[lane] = lane < (m.ng + 1) / 2 ? ld_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + ln], want, ok) : 0u; }
+          if constexpr (kDual<TP>) { const unsigned int hw = lane < hist_words<TP>(m) ? ld_tagged_u(&hb[nq + 2 * nv + m.nu + 6 + ln], want, ok) : 0u; if (lane < kHistLds<TP>) s.act_hist[lane] = hw; }
           if (!__any(!ok)) break;            // wave-uniform: every granule carried the expected tag
           __builtin_amdgcn_s_sleep(8);
         }
@@ -2496,7 +2577,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           s.qacc[i] = ld_state(&st.qacc_ws[(size_t)w * s.nv() + i]);
         }
         for (int i = ln; i < m.nu; i += kWave) s.ctrl[i] = ld_state(&st.ctrl[(size_t)w * m.nu + i]);
-        if constexpr (kDual<TP>) { if (lane < kActHistWords) s.act_hist[lane] = st.act_hist[(size_t)w * kActHistWords + ln]; }
+        if constexpr (kDual<TP>) { if (lane < kHistLds<TP>) s.act_hist[lane] = st.act_hist[(size_t)w * kActHistWords + ln]; }
         time = ld_state(&st.time[w]);
       }
       WSYNC();
