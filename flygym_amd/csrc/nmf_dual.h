@@ -318,7 +318,11 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const float improvement = (ccost - newccost) - dgauss;
     gauss += dgauss; ccost = newccost;
     STAGE(13);
-    if (!was_guess && (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
+    // MuJoCo's rule — stop when the cost no longer improves by the tolerance.  (Rounds 1-3 also stopped as soon as the
+    // improvement was below the float32 rounding floor of the cost, 8 eps |cost|: that test fires while Newton steps still
+    // move the solution — the tail of the one-step error, up to 1e-2 of max |qacc|, were such exits — and is kept as a
+    // guard against cycling between two sign patterns only, from the ninth elimination on.  The regular end is the KKT test.)
+    if (!was_guess && (scale * improvement < m.tolerance || (iter >= 8 && improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost)))) break;
     mask = __ballot(on && jar < 0.f);
   }
   // the rows' forces

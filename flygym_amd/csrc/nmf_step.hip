@@ -2191,7 +2191,8 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       STAGE(13);
       const float improvement = (ccost - newccost) - dgauss;
       gauss += dgauss; ccost = newccost;
-      if (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost)) break;
+      // (the rounding-floor test on the improvement: a guard against cycling from the ninth iteration on — see nmf_dual.h)
+      if (scale * improvement < m.tolerance || (iter >= 8 && improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
     }
     STAGE(9);
     // constraint forces

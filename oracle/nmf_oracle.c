@@ -991,7 +991,9 @@ static void solve_constraints(const omodel* m, odata* d) {
     real improvement = cost - newcost;
     cost = newcost;
     if (scale * improvement < m->tolerance) break;
-    if (d->solver_mode == 0 && improvement <= NMF_NOISE_FACTOR * R_EPS * R_FABS(cost)) break;
+    /* (shared with the kernel: the rounding-floor test on the improvement only guards against cycling, from the ninth
+       iteration on — applied from the first it stopped float32 solves that were still moving, round 4) */
+    if (d->solver_mode == 0 && iter >= 8 && improvement <= NMF_NOISE_FACTOR * R_EPS * R_FABS(cost)) break;
   }
   d->solver_cost = cost;
   for (int i = 0; i < nefc; i++) {

@@ -2,7 +2,7 @@
 # the workload table of DESIGN.md §3: batch-size sweep under the reference protocol + the other configurations
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --no-live-counters"
+B="python bench.py --no-cpu-baseline --no-live-counters --no-other-configs"
 line() { grep '^{"metric"' | python -c "
 import sys, json
 for l in sys.stdin:
@@ -16,6 +16,9 @@ timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 2>/dev/null | line "conf
 timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 --worlds-per-gpu 128 2>/dev/null | line "config5 mixed+odor+adhesion 128"
 timeout 300 $B --joint-preset legs_active_only 2>/dev/null | line "legs_active_only"
 timeout 300 $B --joint-preset all_biological 2>/dev/null | line "all_biological"
+timeout 300 $B --joint-preset all_possible 2>/dev/null | line "all_possible"
+timeout 300 $B --joint-preset all_biological --terrain mixed 2>/dev/null | line "all_biological, mixed terrain"
+timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 --worlds-per-gpu 1024 2>/dev/null | line "config5 mixed+odor+adhesion 1024"
 timeout 300 $B --steps-per-launch 250 2>/dev/null | line "cpg 250-step launches"
 timeout 300 $B --steps 20 --warmup 5 2>/dev/null | line "cpg 20-step launches (driver args)"
 timeout 300 $B --workload replay --steps 20 --warmup 5 2>/dev/null | line "replay 20-step launches"

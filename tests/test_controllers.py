@@ -67,3 +67,31 @@ def test_cpg_driven_adhesion_columns(bench_model, oracle_lib):
     adh_ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == "adhesion"]
     o.step_replay(t[0], np.array(pos_ids + adh_ids), 0, 2500)
     assert np.isfinite(o.qpos).all() and o.qpos[0] - x0 > 0.5
+
+
+def test_cpg_holds_dofs_the_clip_does_not_have():
+    """ALL_POSSIBLE actuates all three axes of every leg joint; the walking clip (reference
+    ``assets/behavior/single_steps_untethered.npz`` behind ``MotionSnippet``) has the 42 biological ones.  The CPG's table
+    drives those exactly as for LEGS_ONLY and holds the others at zero, their neutral angle."""
+    from flygym_amd import make_model
+    from flygym_amd.compose import ActuatorType
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.replay import MotionSnippet
+
+    tables, orders = {}, {}
+    for preset in ("legs_only", "all_possible"):
+        fly = make_model(joints_preset=preset)[0]
+        orders[preset] = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
+        tables[preset] = TripodCPG(orders[preset], 1e-4).targets(2, 400)
+    key = lambda d: (d.child.pos, d.parent.link, d.child.link, d.axis.value)
+    col = {key(d): i for i, d in enumerate(orders["legs_only"])}
+    clip_dofs = MotionSnippet().dofs_per_leg
+    assert len(orders["legs_only"]) == 42 and len(orders["all_possible"]) == 72
+    n_held = 0
+    for j, d in enumerate(orders["all_possible"]):
+        if (d.parent.link, d.child.link, d.axis.value) in clip_dofs:
+            np.testing.assert_array_equal(tables["all_possible"][:, :, j], tables["legs_only"][:, :, col[key(d)]])
+        else:
+            assert not tables["all_possible"][:, :, j].any()
+            n_held += 1
+    assert n_held == 30
