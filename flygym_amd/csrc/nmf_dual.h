@@ -102,7 +102,11 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   lane = opaque(lane);
   ncon = __builtin_amdgcn_readfirstlane(ncon);
   walls = __builtin_amdgcn_readfirstlane((int)walls) != 0;
-  constexpr bool kWarm = kDualS<TP>;      // warm-start term c e and the active-set history (see kDualS / kDualH)
+#ifdef NMF_DUAL_NOWARM
+  constexpr bool kWarm = false;
+#else
+  constexpr bool kWarm = kDualS<TP>;      // warm-start term c e (see kDualS / kDualH)
+#endif
   const Frame fr0 = ld_frame(s, m);
   float (*const DFleg)[8] = dual_leg(s);
   float (*const DFroot)[8] = dual_root(s);
@@ -256,6 +260,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // pattern mispredicts exactly the rows that matter; the previous solution's set is right about nine times in ten, and then
   // one elimination proves it.  A guess that does not even give a descent direction falls back to the start point's pattern.
   bool guessed = hist_any && !(m.solver_flags & 2);
+  int stalls = 0;
   unsigned long long mask = guessed ? __ballot(on && (hist_nib ? ((hist_nib >> k) & 1) != 0 : jar < 0.f)) : __ballot(on && jar < 0.f);
   for (int iter = 0; iter < m.max_iter; ++iter) {
     iters = iter + 1;
@@ -306,9 +311,17 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     }
     STAGE(12);
     if (alpha <= 0.f) {
-      if (!guessed) break;
-      guessed = false; mask = __ballot(on && jar < 0.f);
-      continue;
+      if (guessed) { guessed = false; mask = __ballot(on && jar < 0.f); continue; }
+      // No descent the line search can measure.  In float32 the slope at alpha = 0 is a difference of sums of force x
+      // acceleration products, reliable to ~1e-6 of the cost — and a cost that flat still leaves the accelerations of light
+      // distal dofs open by per cent (round 4: 2.7e-2 of max |qacc| on a config-5 state where the oracle's 5th iteration was
+      // this solve's missing one).  The Newton target itself does not depend on the cost: go towards it as far as the first
+      // row that changes sign (the active-set step; a hair beyond it, so that the row's new state is what the next
+      // elimination sees).  At most three such steps per solve.
+      if (++stalls > 3) break;
+      const bool flips = on && ((jar < 0.f) != (jar_t < 0.f)) && jv != 0.f;
+      const float ai = flips ? -jar / jv : 1.f;
+      alpha = fminf(1.f, wave_min(ai) * 1.001f + 1e-6f);
     }
     const bool was_guess = guessed;      // a step towards a guessed set's target is not a Newton step: its size says nothing about convergence
     guessed = false;
@@ -318,11 +331,17 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const float improvement = (ccost - newccost) - dgauss;
     gauss += dgauss; ccost = newccost;
     STAGE(13);
-    // MuJoCo's rule — stop when the cost no longer improves by the tolerance.  (Rounds 1-3 also stopped as soon as the
-    // improvement was below the float32 rounding floor of the cost, 8 eps |cost|: that test fires while Newton steps still
-    // move the solution — the tail of the one-step error, up to 1e-2 of max |qacc|, were such exits — and is kept as a
-    // guard against cycling between two sign patterns only, from the ninth elimination on.  The regular end is the KKT test.)
-    if (!was_guess && (scale * improvement < m.tolerance || (iter >= 8 && improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost)))) break;
+    // The regular end of this loop is the KKT test above (exact) or a line search that finds no descent.  MuJoCo's rule — stop
+    // when an iteration improves the cost by less than the tolerance — is a guard here, from the sixth elimination on (ties: a
+    // row whose residual rounds to either sign), together with the float32 rounding floor of the cost: earlier it ends solves
+    // that are still moving.  A step the line search cuts short at a row's sign change improves the cost by next to nothing —
+    // in float32 by less than the cost's rounding — yet the very next elimination, with that row's new state, may go all the
+    // way (round 4: the worst one-step errors, up to 4e-2 of max |qacc| under 20x adhesion, were such exits).
+#ifndef NMF_DUAL_EXIT_FROM
+#define NMF_DUAL_EXIT_FROM 5
+#endif
+    if (!was_guess && iter >= NMF_DUAL_EXIT_FROM &&
+        (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
     mask = __ballot(on && jar < 0.f);
   }
   // the rows' forces

@@ -1804,7 +1804,8 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // hybrid kernels: per-lane addresses are rebuilt every step instead of living across the item loop — hoisted, they left
   // the 132-dof kernel 19 spilled registers and a dozen scratch reloads per step (the 72-dof kernels have the registers to
   // keep them: recomputing costs those 2 %)
-  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
+  // (the leg-chain terrain kernels likewise: their per-contact frames take the registers the flat kernels keep the addresses in)
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0 || TP::kTerrain) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) { if (lane == 0) s.reduced = 0; } }
   stage_kinematics(s, m, lane);
@@ -2265,7 +2266,9 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 
 template <class TP, bool WELD>
 __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane, bool wrenches STAGE_ARG) {
-  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0) lane = opaque(lane); }
+  // (per-lane addresses of this stage are rebuilt every step where the allocator otherwise parks them in scratch from the
+  // kernel's prologue on: the hybrid kernels and the leg-chain terrain kernels, 11 reloads per step each a memory round trip)
+  if constexpr (TP::kStar) { if constexpr (TP::REST_B > 0 || TP::kTerrain) lane = opaque(lane); }
   const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
   const float h = m.timestep;
   wrenches = __builtin_amdgcn_readfirstlane((int)wrenches) != 0;
