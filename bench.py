@@ -91,6 +91,9 @@ def parse_args(argv=None):
                          "(seeded noise over a checker floor) through the retina kernel — the HBM-bound kernel of the path; "
                          "render: the eye views are ray-cast on the GPU, fused with the resample (no raw frames in HBM)")
     ap.add_argument("--vision-every", type=int, default=20, help="physics steps per vision tick (20 = 500 Hz)")
+    ap.add_argument("--eye-rays", type=int, choices=[0, 16], default=0,
+                    help="--vision render: rays per ommatidium; 0 = every pixel of the raw frame inside the lattice (readings = "
+                         "resampling the rendered frame, bit for bit), 16 = the sampled mode (an approximation, 15 x fewer rays)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-counters", action="store_true",
@@ -412,10 +415,12 @@ def run(args, primary=True):
     elif args.vision == "render":
         from flygym_amd.vision import EyeRenderer, Scene
 
-        eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(8.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]))
+        eyes = EyeRenderer(sim, fly.name, Scene(spheres=[(8.0, 3.0, 1.5, 1.0)], sphere_rgb=[(0.05, 0.05, 0.05)]), rays_per_ommatidium=args.eye_rays)
         see = lambda: eyes.render()
-        # rays cast per eye view: the 16-pixel chunks of the raw image that touch an ommatidium (the rest of the frame is never rendered)
-        EYE_RAYS_PER_VIEW = int((eyes.retina.id_map.reshape(-1, 16) > 0).any(axis=1).sum()) * 16
+        # rays cast per eye view: the 16-pixel chunks of the raw image that touch an ommatidium (the rest of the frame is never
+        # rendered) — or, in the sampled mode, 16 per ommatidium
+        EYE_RAYS_PER_VIEW = (eyes.retina.num_ommatidia * args.eye_rays if args.eye_rays else
+                             int((eyes.retina.id_map.reshape(-1, 16) > 0).any(axis=1).sum()) * 16)
     order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
     if args.workload == "replay":
         table_steps = 1000  # clip partitions of 1000 steps, as in the reference benchmark
@@ -667,6 +672,8 @@ def run(args, primary=True):
                 out["roofline"]["algorithmic_flop_per_ray"] = EYE_FLOP_PER_RAY
             out["config"]["vision"] = {"mode": args.vision, "every_steps": args.vision_every, "kernel_ms_per_tick": vis_ms,
                                        "physics_kernel_ms_per_tick": ms}
+            if args.vision == "render":
+                out["config"]["vision"]["rays_per_ommatidium"] = args.eye_rays or "every pixel of the cell (pixel-exact)"
         if primary and not args.no_cpu_baseline and world_size == 1:   # reported at N=1 only
             n_rows = min(n_local, host_cores())
             rows = np.ascontiguousarray(table[:n_rows, :, :42].cpu().numpy())
@@ -686,6 +693,7 @@ OTHER_CONFIGS = (
     ("config 1: 1 fly, flat, kinematic replay, one step per launch", dict(worlds_per_gpu=1, workload="replay", steps_per_launch=1, steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, raw frames resampled", dict(vision="resample", steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast", dict(vision="render", steps=200)),
+    ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast, 16 rays per ommatidium (sampled mode: an approximation)", dict(vision="render", eye_rays=16, steps=200)),
     ("config 4: 4096 flies per GPU, gapped terrain", dict(terrain="gapped", steps=200)),
     ("config 4: 4096 flies per GPU, blocks terrain", dict(terrain="blocks", steps=200)),
     ("config 5: 1024 flies, mixed terrain + odor sensors + gait-driven adhesion", dict(worlds_per_gpu=1024, terrain="mixed", odor=True, cpg_adhesion=20.0, steps=200)),
@@ -701,7 +709,7 @@ def other_configs(args):
         a = argparse.Namespace(**vars(args))
         a.gpus, a.scaling, a.warmup, a.repeats, a.no_cpu_baseline, a.no_live_counters = 1, "weak", 0, 0, True, True
         a.workload, a.terrain, a.odor, a.cpg_adhesion, a.vision, a.worlds_per_gpu, a.steps_per_launch = "cpg", "flat", False, 0.0, "off", 4096, 50
-        a.joint_preset, a.simplify_geom = "legs_only", False
+        a.joint_preset, a.simplify_geom, a.eye_rays = "legs_only", False, 0
         for k, v in over.items():
             setattr(a, k, v)
         try:

@@ -91,7 +91,7 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned long long* handoff_buf = nullptr;   // chunk hand-off granules (nmf_step_kernel); allocated with the batch
   // eye renderer: the visit plan of the last id map it was called with ([0] chunks that touch an ommatidium, [1] all chunks)
-  struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0; float fov = 0.f; int n_groups[2] = {0, 0}; int* visit[2] = {nullptr, nullptr}; float* cones[2] = {nullptr, nullptr}; float* chunk_cones[2] = {nullptr, nullptr}; } eye_plan;
+  struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0, n_omm = 0; float fov = 0.f; int n_groups[3] = {0, 0, 0}; int* visit[3] = {nullptr, nullptr, nullptr}; float* cones[3] = {nullptr, nullptr, nullptr}; float* chunk_cones[3] = {nullptr, nullptr, nullptr}; int* slot_omm = nullptr; } eye_plan;      // [0] chunks that feed an ommatidium, [1] all chunks (frames), [2] sampled mode: pixels
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
@@ -758,9 +758,9 @@ extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 // Visit plan of the eye renderer: the chunks (16 consecutive raw pixels) to render, sorted by 32 x 32-pixel tile and cut
 // into groups of 64 (one wave's turn), each group with the bounding cone of its rays in the camera frame (axis, cos and
 // sin of the half-angle) — so that a wave can decide per group what it can see at all.  Built on the host once per id map.
-static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w, float fov_deg) {
+static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w, float fov_deg, int n_omm) {
   auto& P = b->eye_plan;
-  if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg) return 0;
+  if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg && P.n_omm == n_omm) return 0;
   const int n_pix = h * w, n_chunk = n_pix / 16;
   std::vector<int16_t> ids((size_t)n_pix);
   HIP_OK(hipMemcpy(ids.data(), id_map_dev, sizeof(int16_t) * (size_t)n_pix, hipMemcpyDeviceToHost));
@@ -829,7 +829,52 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w,
     HIP_OK(hipMemcpy(pcc, ccones.data(), sizeof(float) * ccones.size(), hipMemcpyHostToDevice));
     P.visit[mode] = (int*)pv; P.cones[mode] = (float*)pc; P.chunk_cones[mode] = (float*)pcc; P.n_groups[mode] = n_groups;
   }
-  P.id_map = id_map_dev; P.h = h; P.w = w; P.fov = fov_deg;
+  {
+    // Sampled mode (nmf_eye_params::rays_per_ommatidium = 16): per ommatidium i the pixels of its cell in raster order,
+    // P_0 .. P_{n-1}, and of those the 16 at indices floor((2 j + 1) n / 32), j = 0..15 (oracle/sensors_oracle.py::
+    // sampled_pixels).  One lane per ray, an ommatidium's 16 rays in one DPP row.  The ommatidia are visited in 64 x 64
+    // pixel tiles of their cells' centres, 16 (a 4 x 4 patch of the lattice) to a group: one bounding cone and one culling
+    // for the group's 256 rays.  slot_omm[s] = the ommatidium in slot s.
+    constexpr int K = nmf::kEyeRays, S = nmf::kEyeSlots;
+    std::vector<std::vector<int>> cell((size_t)n_omm);
+    for (int i = 0; i < n_pix; ++i) { const int id = ids[(size_t)i] & 0x7fff; if (id > 0 && id <= n_omm) cell[(size_t)id - 1].push_back(i); }
+    std::vector<int> order((size_t)n_omm);
+    std::vector<long long> keyv((size_t)n_omm);
+    for (int o = 0; o < n_omm; ++o) {
+      order[(size_t)o] = o;
+      double r = 0, c = 0;
+      for (int i : cell[(size_t)o]) { r += i / w; c += i % w; }
+      const double n = std::max<size_t>(cell[(size_t)o].size(), 1);
+      const int row = (int)(r / n), col = (int)(c / n);
+      keyv[(size_t)o] = ((long long)(row / 64) << 40) | ((long long)(col / 64) << 28) | ((long long)row << 12) | col;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return keyv[(size_t)a] < keyv[(size_t)c]; });
+    const int n_groups = (n_omm + S - 1) / S;
+    std::vector<int> visit((size_t)n_groups * S * K, -1), slots((size_t)n_groups * S, 0);
+    for (int sl = 0; sl < n_omm; ++sl) {
+      const int o = order[(size_t)sl];
+      slots[(size_t)sl] = o;
+      const long long n = (long long)cell[(size_t)o].size();
+      for (int j = 0; j < K && n > 0; ++j) visit[(size_t)sl * K + j] = cell[(size_t)o][(size_t)(((2 * j + 1) * n) / (2 * K))];
+    }
+    std::vector<float> cones((size_t)n_groups * 12, 0.f);
+    for (int g = 0; g < n_groups; ++g) {
+      std::vector<size_t> gp;
+      for (int l = 0; l < S * K; ++l) if (visit[(size_t)g * S * K + l] >= 0) gp.push_back((size_t)visit[(size_t)g * S * K + l]);
+      cone_of(gp, 1e-4, &cones[(size_t)g * 12]);
+      cones[(size_t)g * 12 + 9] = lens_ok ? 1.f : 0.f;
+    }
+    void* pv = nullptr; void* pc = nullptr; void* ps = nullptr;
+    if (hipMalloc(&pv, sizeof(int) * visit.size()) != hipSuccess || hipMalloc(&pc, sizeof(float) * cones.size()) != hipSuccess ||
+        hipMalloc(&ps, sizeof(int) * slots.size()) != hipSuccess)
+      return fail("nmf_eye_render: out of device memory for the sampling plan");
+    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(ps);
+    HIP_OK(hipMemcpy(pv, visit.data(), sizeof(int) * visit.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pc, cones.data(), sizeof(float) * cones.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ps, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice));
+    P.visit[2] = (int*)pv; P.cones[2] = (float*)pc; P.chunk_cones[2] = P.chunk_cones[0]; P.n_groups[2] = n_groups; P.slot_omm = (int*)ps;
+  }
+  P.id_map = id_map_dev; P.h = h; P.w = w; P.fov = fov_deg; P.n_omm = n_omm;
   return 0;
 }
 
@@ -877,13 +922,19 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
     A.rgb[3][c] = c < 3 ? p->wall_rgb[c] : 0; A.rgb[4][c] = c < 3 ? p->body_rgb[c] : 0;
     for (int s = 0; s < nmf::kMaxSpheres; ++s) A.rgb[5 + s][c] = c < 3 ? p->sphere_rgb[s][c] : 0;
   }
-  if (build_eye_plan(b, id_map_dev, p->height, p->width, p->fov_deg) != 0) return -1;
-  const int mode = frames_out_dev ? 1 : 0;
-  hipLaunchKernelGGL(nmf::nmf_eye_kernel, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A,
-                     b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,
-                     capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),
-                     b->eye_plan.visit[mode], b->eye_plan.cones[mode], reinterpret_cast<const float4*>(b->eye_plan.chunk_cones[mode]), b->eye_plan.n_groups[mode],
-                     id_map_dev, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev);
+  if (p->rays_per_ommatidium != 0 && p->rays_per_ommatidium != nmf::kEyeRays) return fail("nmf_eye_render: rays_per_ommatidium must be 0 (every pixel) or 16");
+  if (p->rays_per_ommatidium != 0 && frames_out_dev) return fail("nmf_eye_render: the sampled mode renders no frames (rays_per_ommatidium = 0 does)");
+  A.sampled = p->rays_per_ommatidium;
+  if (build_eye_plan(b, id_map_dev, p->height, p->width, p->fov_deg, n_ommatidia) != 0) return -1;
+  const int mode = A.sampled ? 2 : frames_out_dev ? 1 : 0;
+#define NMF_EYE_LAUNCH(SAMPLED)                                                                                                      \
+  hipLaunchKernelGGL(nmf::nmf_eye_kernel<SAMPLED>, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A, \
+                     b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,                           \
+                     capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),                               \
+                     b->eye_plan.visit[mode], b->eye_plan.cones[mode], reinterpret_cast<const float4*>(b->eye_plan.chunk_cones[mode]), b->eye_plan.n_groups[mode], \
+                     id_map_dev, b->eye_plan.slot_omm, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev)
+  if (A.sampled) NMF_EYE_LAUNCH(true); else NMF_EYE_LAUNCH(false);
+#undef NMF_EYE_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -26,6 +26,8 @@ namespace nmf {
 __device__ unsigned long long g_eye_stats[8];
 #endif
 constexpr int kEyeThreads = 256;
+constexpr int kEyeRays = 16;        // rays per ommatidium of the sampled mode: one DPP row of lanes
+constexpr int kEyeSlots = 16;       // ommatidia per group of the sampled mode (a 4 x 4 patch of the lattice: one culling for 256 rays)
 constexpr int kMaxSpheres = 8;
 constexpr int kMaxCaps = 64;            // capsules of the fly's own body an eye can see
 constexpr int kMaxTerrainCells = 64;    // cells a ray is followed through the relief before the far field is taken as flat
@@ -43,6 +45,7 @@ struct EyeArgs {
   int terrain_kind;                  // 0 flat plane, 1 gapped, 2 blocks, 3 mixed (flygym_amd/compose/world.py)
   float terrain[5];                  // its parameters + highest level
   int n_caps;                        // body capsules (cap_seg / cap_geom)
+  int sampled;                       // 0: every pixel that feeds an ommatidium; kEyeRays: that many rays per ommatidium (see nmf_eye_render)
   unsigned char rgb[5 + kMaxSpheres][4];   // materials: 0 sky, 1 ground A, 2 ground B, 3 terrain side wall, 4 own body, 5.. spheres
 };
 
@@ -92,11 +95,14 @@ __device__ __forceinline__ V3 eye_ray(int row, int col, float cx, float cy, floa
 #ifndef NMF_EYE_WAVES
 #define NMF_EYE_WAVES 7
 #endif
-__global__ void __launch_bounds__(kEyeThreads) __attribute__((amdgpu_waves_per_eu(NMF_EYE_WAVES, NMF_EYE_WAVES)))
+// SAMPLED: the sampled mode (nmf_eye_params::rays_per_ommatidium = 16) as an instantiation of its own — the pixel-exact kernel
+// keeps its register allocation, this one has few live values and takes eight waves per SIMD.
+template <bool SAMPLED>
+__global__ void __launch_bounds__(kEyeThreads) __attribute__((amdgpu_waves_per_eu(SAMPLED ? 8 : NMF_EYE_WAVES, SAMPLED ? 8 : NMF_EYE_WAVES)))
 nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __restrict__ seg_xquat, int nseg,
                const float* __restrict__ spheres, const int* __restrict__ cap_seg, const float* __restrict__ cap_geom,
                const u32x4* __restrict__ plan, const int* __restrict__ visit, const float* __restrict__ cones, const float4* __restrict__ chunk_cones, int n_groups,
-               const int16_t* __restrict__ id_map,
+               const int16_t* __restrict__ id_map, const int* __restrict__ slot_omm,
                const uint8_t* __restrict__ pale, const float* __restrict__ inv_norm, int n_omm,
                uint8_t* __restrict__ frames_out, float* __restrict__ omm_out) {
   __shared__ unsigned int acc[kMaxOmmatidia];
@@ -184,7 +190,8 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   // the lattice) in groups of 64, one group per wave and turn
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int grp = wave; grp < n_groups; grp += kEyeThreads / 64) {
-    const int ch = visit[grp * 64 + lane];
+    // (sampled mode: a group is kEyeSlots ommatidia = kEyeSlots / 4 turns of 64 rays under one culling; `ch` is the first turn's pixel)
+    const int ch = visit[(SAMPLED ? grp * (kEyeSlots / 4) : grp) * 64 + lane];
     // the group's cone(s), world axes: one, or — groups of chunks that wrap to the next image row — one per piece
     const float* cn = cones + (size_t)__builtin_amdgcn_readfirstlane(grp) * 12;
     const bool two = cn[8] != 0.f;
@@ -212,16 +219,19 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     const unsigned int grp_sph = (unsigned int)__ballot(lane < A.n_spheres && cone_sees(sphc[lane < A.n_spheres ? lane : 0][0], sphc[lane < A.n_spheres ? lane : 0][1],
                                                                                       sphc[lane < A.n_spheres ? lane : 0][2], sphc[lane < A.n_spheres ? lane : 0][3], sphc[lane < A.n_spheres ? lane : 0][4]));
     const bool grp_ground = gw[0].z < g_sin[0] + 1e-3f || (two && gw[1].z < g_sin[1] + 1e-3f);          // some ray of the group points below the horizon
-    if (ch < 0) continue;
-    const u32x4 pl = plan[ch];
+    constexpr bool sampled = SAMPLED;         // the visit list holds PIXELS, kEyeRays per ommatidium, one ray per lane
+    if (!sampled && ch < 0) continue;
+    const int chunk = sampled ? (ch < 0 ? 0 : ch >> 4) : ch;
+    const u32x4 pl = plan[chunk];
     const bool planned = !(pl.y & 0x10000u);
-    int row = (ch * 16) / A.width, col = ch * 16 - row * A.width;
+    int row = (chunk * 16) / A.width, col = chunk * 16 - row * A.width;
     unsigned int tot = 0u, sA = 0u, sAB = 0u;
     // body capsules this chunk can see: its rays lie in a cone about the mean of its first and last ray — two cones for
     // a chunk that wraps to the next image row (one per row piece).  A capsule is a candidate if its bounding sphere's
     // angular disc reaches into a cone.
     unsigned long long cand = 0ull, ucand = 0ull;         // this chunk's candidates / the union over the wave's chunks
-    if (grp_caps) {
+    if (sampled) { cand = grp_caps; ucand = grp_caps; }   // single rays: the group's candidates as they are
+    else if (grp_caps) {
       V3 cw[2]; float c_cos[2], c_sin[2];
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
@@ -317,6 +327,60 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       }
       return mat;
     };
+    if constexpr (SAMPLED) {
+      // Sampled mode: a lane's ray is a pixel of the raw frame — computed exactly as the pixel-exact mode computes that pixel
+      // (same lens branch for its chunk: the polynomials inside a row, eye_ray for a chunk that wraps or is unplanned), so its
+      // colour is the frame's.  The kEyeRays lanes of an ommatidium form one DPP row: their chosen colour bytes are summed
+      // across the row and the row's last lane adds them to the ommatidium.
+      const float hf2 = A.half_fov * A.half_fov;
+#pragma unroll 1
+      for (int turn = 0; turn < kEyeSlots / 4; ++turn) {
+        const int slot = (grp * (kEyeSlots / 4) + turn) * 4 + (lane >> 4);
+        const int px = turn == 0 ? ch : visit[(grp * (kEyeSlots / 4) + turn) * 64 + lane];
+        const int omm = slot < n_omm ? slot_omm[slot] : 0;
+        unsigned int val = 0u;
+        if (px >= 0) {
+          const int pchunk = px >> 4;
+          const int prow = px / A.width, pcol = px - prow * A.width;
+          const bool wraps = (pchunk * 16) / A.width != (pchunk * 16 + 15) / A.width;
+          const bool pplanned = !(reinterpret_cast<const unsigned int*>(plan)[4 * pchunk + 1] & 0x10000u);
+          int mat;
+          if (!wraps && pplanned && cn[9] != 0.f) {
+            const float vv = ((float)prow + 0.5f - cy) * inv_half_h;
+            const float v2 = vv * vv;
+            const V3 rowv = v3(-vv * R[1], -vv * R[4], -vv * R[7]);
+            const float u = ((float)pcol + 0.5f - cx) * inv_half_h;
+            const float x = fmaf(u, u, v2) * hf2;
+            float sc = -1.0f / 1307674368000.f;
+            sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
+            sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
+            float cs = 1.0f / 20922789888000.f;
+            cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
+            cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
+            const float s1 = sc * A.half_fov;
+            const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
+            mat = scene(d);
+          } else {
+            float theta;
+            const V3 dc = eye_ray(prow, pcol, cx, cy, inv_half_h, A.half_fov, theta);
+            const float dx = dc.x, dy = dc.y, dz = dc.z;
+            const V3 d = v3(R[0] * dx + R[1] * dy + R[2] * dz, R[3] * dx + R[4] * dy + R[5] * dz, R[6] * dx + R[7] * dy + R[8] * dz);
+            mat = scene(d);
+            mat = theta > 3.14159265f ? -1 : mat;
+          }
+          const unsigned int rgbw = mats[mat + 1];
+          val = pale[omm] ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
+        }
+        // sum over the 16 lanes of the row (row_shr 8, 4, 2, 1 with zero fill: the row's last lane ends up with the total)
+        int v = (int)val;
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+        if ((lane & 15) == 15 && slot < n_omm) atomicAdd(&acc[omm], (unsigned int)v);
+      }
+      continue;
+    }
     if (!two && planned && cn[9] != 0.f) {
       // The common case — a chunk inside one image row, three or fewer runs, the whole image within the lens polynomials' range
       // (cn[9]; both are properties of the chunk / the lens, so a pixel takes the same path whatever the call renders) — on a diet: the row's part of the ray is hoisted, sin(theta) / rho and cos(theta) are polynomials in
@@ -404,7 +468,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   if (omm_out) {
     float* dst = omm_out + (size_t)blockIdx.x * n_omm * 2;
     for (int i = threadIdx.x; i < n_omm; i += kEyeThreads) {
-      const float vv = (float)acc[i] * inv_norm[i];
+      const float vv = (float)acc[i] * (SAMPLED ? 1.0f / (255.0f * (float)kEyeRays) : inv_norm[i]);
       const bool pp = pale[i] != 0;
       dst[2 * i] = pp ? 0.f : vv;
       dst[2 * i + 1] = pp ? vv : 0.f;

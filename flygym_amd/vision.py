@@ -43,7 +43,7 @@ class _EyeParams(ctypes.Structure):
         ("sky_rgb", ctypes.c_uint8 * 4), ("ground_rgb", (ctypes.c_uint8 * 4) * 2), ("sphere_rgb", (ctypes.c_uint8 * 4) * 8),
         ("n_spheres", ctypes.c_int32), ("spheres_per_world", ctypes.c_int32),
         ("wall_rgb", ctypes.c_uint8 * 4), ("body_rgb", ctypes.c_uint8 * 4),
-        ("n_capsules", ctypes.c_int32), ("terrain_relief", ctypes.c_int32),
+        ("n_capsules", ctypes.c_int32), ("terrain_relief", ctypes.c_int32), ("rays_per_ommatidium", ctypes.c_int32),
     ]
 
 
@@ -113,8 +113,15 @@ class EyeRenderer:
     """Renders both compound eyes of every fly in a ``HIPSimulation`` from the poses of the last step."""
 
     def __init__(self, sim, fly_name: str, scene: Scene | None = None, retina: Retina | None = None,
-                 fov_deg: float = FOVY_PER_EYE_DEG):
+                 fov_deg: float = FOVY_PER_EYE_DEG, rays_per_ommatidium: int = 0):
+        """``rays_per_ommatidium``: 0 (default) casts every pixel of the raw frame that lies in an ommatidium's cell — the
+        readings are those of resampling the rendered frame, bit for bit; 16 casts sixteen of each cell's pixels (one in
+        fifteen: ``oracle/sensors_oracle.py::sampled_pixels`` is the specification) and reports their mean — an
+        approximation of the cell mean at a fifteenth of the rays.  :meth:`render_frames` needs 0."""
         import torch
+
+        if rays_per_ommatidium not in (0, 16):
+            raise ValueError("rays_per_ommatidium must be 0 (every pixel) or 16")
 
         self.sim, self.scene, self.retina = sim, scene or Scene(), retina or Retina()
         fly = sim.world.fly_lookup[fly_name]
@@ -139,6 +146,7 @@ class EyeRenderer:
                 p.sphere_rgb[s][i] = c[i]
         p.n_spheres, p.spheres_per_world = len(self.scene.spheres), 0
         p.terrain_relief = int(self.scene.terrain_relief)
+        p.rays_per_ommatidium = int(rays_per_ommatidium)
         self.capsule_seg, self.capsule_geom = body_capsules(fly) if self.scene.own_body else (np.zeros(0, np.int32), np.zeros((0, 7), np.float32))
         p.n_capsules = len(self.capsule_seg)
         self._cap_seg = torch.as_tensor(self.capsule_seg, device=sim.device) if p.n_capsules else None
@@ -185,6 +193,8 @@ class EyeRenderer:
     def render_frames(self, with_readings: bool = False):
         """Raw eye frames ``(n_worlds, 2, height, width, 3)`` uint8 (and the readings if asked)."""
         t = self.sim._torch
+        if self._params.rays_per_ommatidium:
+            raise ValueError("the sampled mode renders no frames: build the EyeRenderer with rays_per_ommatidium=0")
         frames = t.empty((self.sim.n_worlds, 2, self.retina.height, self.retina.width, 3), dtype=t.uint8, device=self.sim.device)
         omm = t.empty((self.sim.n_worlds, 2, self.retina.num_ommatidia, 2), dtype=t.float32, device=self.sim.device) if with_readings else None
         self._call(frames, omm)

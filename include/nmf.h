@@ -171,6 +171,10 @@ typedef struct nmf_eye_params {
   int32_t n_capsules;           /* 0..64 capsules of the fly's own body (capsule_seg_dev / capsule_geom_dev)            */
   int32_t terrain_relief;       /* 1: the ground is the height map the batch's physics collides with (gapped / blocks /
                                    mixed worlds: constant-height cells with side walls); 0: the flat checker plane      */
+  int32_t rays_per_ommatidium;  /* 0: every pixel of the raw frame that lies in an ommatidium's cell is cast (readings =
+                                   resampling the rendered frame, bit for bit); 16: sixteen of each cell's pixels — at
+                                   indices floor((2 j + 1) n / 32) of its n pixels in raster order — and the reading is
+                                   their mean: 15 x fewer rays, an approximation of the cell mean (no frames in this mode) */
 } nmf_eye_params;
 
 /* sizeof(nmf_eye_params) as this library was compiled: lets a foreign-language binding verify its struct layout. */

@@ -26,6 +26,43 @@ def retina_resample(images: np.ndarray, id_map: np.ndarray, pale_mask: np.ndarra
     return out.reshape(lead + (n_omm, 2))
 
 
+def sampled_pixels(id_map: np.ndarray, n_ommatidia: int, rays: int = 16) -> np.ndarray:
+    """The eye renderer's sampled mode (``nmf_eye_params.rays_per_ommatidium = 16``): for every ommatidium the pixels of
+    its cell in raster order, P_0 .. P_{n-1}, and of those the ones at indices floor((2 j + 1) n / (2 rays)), j = 0 .. rays - 1
+    (evenly spread over the cell, repeated where a cell has fewer pixels than rays).  Returns ``(n_ommatidia, rays)`` flat
+    pixel indices, -1 for an ommatidium without pixels."""
+    ids = id_map.ravel().astype(np.int64) & 0x7FFF
+    out = np.full((n_ommatidia, rays), -1, dtype=np.int64)
+    order = np.argsort(ids, kind="stable")
+    counts = np.bincount(ids, minlength=n_ommatidia + 1)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    j = np.arange(rays)
+    for o in range(n_ommatidia):
+        n = int(counts[o + 1])
+        if n:
+            out[o] = order[starts[o + 1] + ((2 * j + 1) * n) // (2 * rays)]
+    return out
+
+
+def retina_sampled(images: np.ndarray, id_map: np.ndarray, pale_mask: np.ndarray, rays: int = 16) -> np.ndarray:
+    """images (..., H, W, 3) uint8 -> (..., n_omm, 2) float32: the mean of the sampled pixels' colour byte (green for
+    yellow-type ommatidia, blue for pale ones) / 255 — integer sum, one float32 multiply by 1 / (255 rays)."""
+    n_omm = int(pale_mask.shape[0])
+    px = sampled_pixels(id_map, n_omm, rays)
+    lead = images.shape[:-3]
+    flat = images.reshape((-1, id_map.size, 3))
+    chan = np.where(pale_mask != 0, 2, 1)
+    out = np.zeros((flat.shape[0], n_omm, 2), dtype=np.float32)
+    scale = np.float32(1.0) / (np.float32(255.0) * np.float32(rays))
+    for k in range(flat.shape[0]):
+        vals = flat[k][np.maximum(px, 0), chan[:, None]].astype(np.int64)
+        sums = np.where(px >= 0, vals, 0).sum(axis=1).astype(np.uint32)
+        reading = sums.astype(np.float32) * scale
+        out[k, :, 0] = np.where(pale_mask != 0, 0.0, reading)
+        out[k, :, 1] = np.where(pale_mask != 0, reading, 0.0)
+    return out.reshape(lead + (n_omm, 2))
+
+
 def quat_to_mat(q):
     w, x, y, z = q
     return np.array([

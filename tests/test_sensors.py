@@ -296,3 +296,65 @@ def test_eye_renderer_matches_oracle_and_resample(bench_model):
     assert np.array_equal(fr2[0], fr[0]) and not np.array_equal(fr2[1], fr[1])
     with pytest.raises(ValueError):
         eyes.set_spheres(np.zeros((5, 4)))
+
+
+def test_sampled_pixels_specification():
+    """The sampled mode's choice of rays (oracle/sensors_oracle.py::sampled_pixels): 16 pixels of every ommatidium's own
+    cell, in raster order, evenly spread over the cell's pixel list — one pixel in fifteen of the lattice."""
+    import sensors_oracle as so
+    from flygym_amd.sensors import Retina
+
+    r = Retina()
+    px = so.sampled_pixels(r.id_map, r.num_ommatidia, 16)
+    ids = r.id_map.ravel()
+    assert px.shape == (721, 16) and (px >= 0).all()
+    assert (ids[px] == np.arange(1, 722)[:, None]).all()                     # every ray inside its own cell
+    assert (np.diff(px, axis=1) > 0).all()                                   # raster order, no pixel twice (cells have > 16 pixels)
+    counts = np.bincount(ids, minlength=722)[1:]
+    assert counts.min() > 16 and 13.0 < counts.sum() / px.size < 16.0        # 170 k lattice pixels (230-242 per cell), 11.5 k rays
+    first = np.array([np.flatnonzero(ids == i + 1)[0] for i in range(5)])
+    rank = [np.searchsorted(np.flatnonzero(ids == i + 1), px[i]) for i in range(5)]
+    for i in range(5):
+        np.testing.assert_array_equal(rank[i], ((2 * np.arange(16) + 1) * counts[i]) // 32)
+    assert (px[:5, 0] >= first).all()
+    # a flat image reads the same in both modes; a vertical edge through a cell reads within 1 / 16 + the cell's own granularity
+    img = np.full((512, 450, 3), 200, dtype=np.uint8)
+    full = so.retina_resample(img, r.id_map, r.pale_mask, r.inv_norm)
+    samp = so.retina_sampled(img, r.id_map, r.pale_mask)
+    np.testing.assert_allclose(samp, full, atol=1e-6)
+    img[:, 225:] = 40
+    full = so.retina_resample(img, r.id_map, r.pale_mask, r.inv_norm)
+    samp = so.retina_sampled(img, r.id_map, r.pale_mask)
+    assert np.abs(samp - full).max() < 0.08 and np.abs(samp - full).mean() < 2e-3
+
+
+@pytest.mark.gpu
+def test_eye_renderer_sampled_mode(bench_model):
+    """``EyeRenderer(rays_per_ommatidium=16)``: the kernel casts the specification's 16 pixels per ommatidium and nothing else.
+    Its readings equal the specification applied to the frames the pixel-exact mode renders of the same poses — bit for bit
+    (integer sums of the same pixels' colours) — and approximate the pixel-exact readings as a 16-point mean does."""
+    import torch
+    import sensors_oracle as so
+    from flygym_amd import HIPSimulation
+    from flygym_amd.vision import EyeRenderer, Scene
+
+    fly, world, _ = bench_model
+    n = 4
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    sim.field("qvel")[:, :6] = torch.as_tensor(np.random.default_rng(7).normal(0, 20, (n, 6)), dtype=torch.float32, device=sim.device)
+    sim.step(60)
+    scene = Scene(spheres=[(6.0, 4.0, 1.5, 1.0), (5.0, -6.0, 0.8, 0.8)], sphere_rgb=[(0.05, 0.05, 0.05), (0.9, 0.2, 0.1)])      # own body on
+    exact = EyeRenderer(sim, fly.name, scene)
+    sampled = EyeRenderer(sim, fly.name, scene, rays_per_ommatidium=16)
+    frames, full = exact.render_frames(with_readings=True)
+    got = sampled.render()
+    assert got.shape == full.shape == (n, 2, 721, 2)
+    want = so.retina_sampled(frames.cpu().numpy(), exact.retina.id_map, exact.retina.pale_mask)
+    assert np.array_equal(got.cpu().numpy(), want)
+    err = (got - full).abs()
+    assert float(err.max()) < 0.35 and float(err.mean()) < 6e-3              # a 16-point mean of cells of ~240 pixels
+    assert torch.equal(got, sampled.render())                                 # deterministic
+    with pytest.raises(ValueError):
+        sampled.render_frames()
+    with pytest.raises(ValueError):
+        EyeRenderer(sim, fly.name, scene, rays_per_ommatidium=8)
