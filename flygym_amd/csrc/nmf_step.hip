@@ -773,24 +773,31 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
     // narrower than that, e.g. where a stripe of the mixed terrain cuts a block) — and every one is read at three
     // heights of y, which meets all the blocks' rows unless a row is narrower than the radius (then: the global maximum).
     float ttop = terrain_top;
+    const V3 p0 = mat_vec(R, l0) + xp, p1 = mat_vec(R, l1) + xp;
     if (rough && dc - bs_r - terrain_top <= g_margin) {
-      // (the footprint is widened by the margin: a face within the margin of a vertex belongs to a cell it touches)
-      const float cx = cw.x + xp.x, cy = cw.y + xp.y, fr = bs_r + g_margin;
+      // The footprint: the bounding sphere's box cut with the box of the bounding cylinder / the capsule itself (p0, p1, rad) —
+      // a thin tarsal segment covers a strip, not the disc of its bounding sphere (round 4: on the blocks far fewer hulls
+      // "straddle" a cell boundary, i.e. more take the one-cell path and fewer see a raised neighbour's top) — widened by
+      // the margin: a face within the margin of a vertex belongs to a cell the footprint touches.
+      const float cx = cw.x + xp.x, cy = cw.y + xp.y, fr = bs_r + g_margin, fc = rad + g_margin;
+      const float fx0 = fmaxf(cx - fr, fminf(p0.x, p1.x) - fc), fx1 = fminf(cx + fr, fmaxf(p0.x, p1.x) + fc);
+      const float fy0 = fmaxf(cy - fr, fminf(p0.y, p1.y) - fc), fy1 = fminf(cy + fr, fmaxf(p0.y, p1.y) + fc);
+      const float mx = 0.5f * (fx0 + fx1), my = 0.5f * (fy0 + fy1);
       float cb[4];
-      ttop = terrain_cell(terrain_type, tpar, cx, cy, cb);
-      const float clear = fminf(fminf(cb[1] - cx, cx - cb[0]), fminf(cb[3] - cy, cy - cb[2])) - fr;
+      ttop = terrain_cell(terrain_type, tpar, mx, my, cb);
+      const float clear = fminf(fminf(cb[1] - fx1, fx0 - cb[0]), fminf(cb[3] - fy1, fy0 - cb[2]));
       one_cell = clear > kOneCell;
       if (!(clear > 0.f)) {
-        if (terrain_type >= 2 && tpar[0] < fr) ttop = terrain_top;
+        if (terrain_type >= 2 && tpar[0] < 0.5f * (fy1 - fy0)) ttop = terrain_top;
         else {
-          float xs = cx - fr;
+          float xs = fx0;
           bool open = true;             // the walk has not reached the footprint's high end yet
 #pragma unroll 1
           for (int k = 0; k < 8 && open; ++k) {
             float wb[4];
-            ttop = fmaxf(ttop, terrain_cell(terrain_type, tpar, xs, cy, wb));
-            ttop = fmaxf(ttop, fmaxf(terrain_height(terrain_type, tpar, xs, cy - fr), terrain_height(terrain_type, tpar, xs, cy + fr)));
-            open = wb[1] <= cx + fr;
+            ttop = fmaxf(ttop, terrain_cell(terrain_type, tpar, xs, my, wb));
+            ttop = fmaxf(ttop, fmaxf(terrain_height(terrain_type, tpar, xs, fy0), terrain_height(terrain_type, tpar, xs, fy1)));
+            open = wb[1] <= fx1;
             xs = wb[1] + kProbeEps;
           }
           if (open) ttop = terrain_top; // more cells than the walk takes: no local bound
@@ -799,7 +806,6 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       g_ttop = ttop;
     }
     near = dc - bs_r - ttop <= g_margin;
-    const V3 p0 = mat_vec(R, l0) + xp, p1 = mat_vec(R, l1) + xp;
     const float z0 = dot(n, p0) - pd, z1 = dot(n, p1) - pd;      // heights over the ground plane
     float d0 = z0 - rad, d1 = z1 - rad;
     // hulls: (p0, p1, rad) is the hull's bounding cylinder — a thin tarsal segment hovering inside its bounding sphere's

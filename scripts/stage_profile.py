@@ -28,7 +28,11 @@ sim = HIPSimulation(world, n_worlds=n, device=0)
 L = _native.lib()
 L.nmf_debug_stage_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 order = fly.get_actuated_jointdofs_order(ActuatorType.POSITION)
-table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_worlds(n, 1000), device=sim.device)
+if preset == "all_possible":      # the walking clip has no angles for this skeleton's extra axes: the CPG holds them at zero
+    from flygym_amd.controllers import TripodCPG
+    table = TripodCPG(order, 1e-4).targets(n, 1000, device=sim.device)
+else:
+    table = torch.as_tensor(ReplayTargetData(1e-4, order).make_target_angles_all_worlds(n, 1000), device=sim.device)
 ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
 sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 sim.step(500); torch.cuda.synchronize()
