@@ -1,0 +1,77 @@
+"""numpy statement of the engine's contact-space constraint solve (flygym_amd/csrc/nmf_dual.h).  TEST INFRASTRUCTURE.
+
+Not a restatement of the reference — MuJoCo's Newton solver works on the accelerations, and oracle/nmf_oracle.c restates
+that — but of the algorithm the kernel runs instead, so that its claims can be checked on the CPU against the oracle's
+optimum: every iterate is  qacc = qacc_smooth + c e + M^-1 J^T lambda;  per iteration ONE elimination of [R + A | j0] with
+the active rows as pivots; the target's own sign pattern = the pivot set  <=>  the KKT conditions hold; otherwise an exact
+line search towards the target, or — where the search finds no descent — the active-set step to the first row that changes
+sign; the previous step's final active set as the first guess."""
+import numpy as np
+
+
+def solve(M, J, aref, D, a_smooth, a_warm, guess=None, dtype=np.float64, max_iter=50, warm=True):
+    """Returns (qacc, final active rows, eliminations, line searches, active-set steps)."""
+    f = dtype
+    M, J, aref, D, a_s, a_w = (np.asarray(x, dtype=np.float64).astype(f) for x in (M, J, aref, D, a_smooth, a_warm))
+    n = len(D)
+    MiJt = np.linalg.solve(M.astype(np.float64), J.T.astype(np.float64)).astype(f)      # (the kernel: leaf-to-root responses through the smooth solve's factors)
+    A = (J @ MiJt).astype(f)
+    R = (f(1) / D).astype(f)
+    e = (a_w - a_s).astype(f) if warm else np.zeros_like(a_s)
+    j0 = (J @ a_s - aref).astype(f)
+    je = (J @ e).astype(f)
+    eMe = f(e @ (M @ e))
+    ccost = lambda x: f(0.5) * np.sum(np.where(x < 0, D * x * x, f(0))).astype(f)
+    c = f(0) if (not warm or ccost(j0) < f(0.5) * eMe + ccost(j0 + je)) else f(1)      # the better of the two start points
+    jar = (j0 + c * je).astype(f)
+    lam = np.zeros(n, f)
+    guessed = guess is not None
+    mask = np.asarray(guess, dtype=bool).copy() if guessed else jar < 0
+    elim = searches = stalls = 0
+    for it in range(max_iter):
+        elim += 1
+        idx = np.nonzero(mask)[0]
+        lam_t = np.zeros(n, f)
+        if len(idx):
+            lam_t[idx] = -np.linalg.solve((A[np.ix_(idx, idx)] + np.diag(R[idx])).astype(f), j0[idx]).astype(f)
+        jar_t = (j0 + A @ lam_t).astype(f)
+        jar_t[idx] = -R[idx] * lam_t[idx]
+        if np.array_equal(jar_t < 0, mask):            # KKT: the optimum, exactly
+            lam, jar, c = lam_t, jar_t, f(0)
+            break
+        jv, dlam, dc = (jar_t - jar).astype(f), (lam_t - lam).astype(f), -c
+        Alam, Adlam = jar - j0 - c * je, jv - dc * je
+        g1 = c * dc * eMe + dc * (je @ lam) + c * (je @ dlam) + dlam @ Alam
+        g2 = dc * dc * eMe + 2 * dc * (je @ dlam) + dlam @ Adlam
+        alpha, lo, hi = f(0), f(0), f(-1)
+        searches += 1
+        for ls in range(30):
+            x = jar + alpha * jv
+            m_ = x < 0
+            d1 = g1 + alpha * g2 + np.sum(D[m_] * x[m_] * jv[m_])
+            d2 = g2 + np.sum(D[m_] * jv[m_] ** 2)
+            if d2 <= 0 or d1 == 0:
+                break
+            if d1 < 0: lo = alpha
+            else: hi = alpha
+            nxt, bis = alpha - d1 / d2, False
+            if hi >= 0 and (nxt <= lo or nxt >= hi):
+                nxt, bis = f(0.5) * (lo + hi), True
+            same = (not bis) and np.array_equal((jar + alpha * jv) < 0, (jar + nxt * jv) < 0)
+            change, alpha = abs(nxt - alpha), f(nxt)
+            if same or change <= 8 * np.finfo(f).eps * abs(nxt):
+                break
+        if alpha <= 0:
+            if guessed:                                 # the guessed set gave no descent: plain Newton from here
+                guessed, mask = False, jar < 0
+                continue
+            stalls += 1                                 # no measurable descent: the active-set step
+            if stalls > 3:
+                break
+            flips = ((jar < 0) != (jar_t < 0)) & (jv != 0)
+            alpha = f(min(1.0, float(np.min(np.where(flips, -jar / np.where(jv == 0, 1, jv), 1.0))) * 1.001 + 1e-6))
+        guessed = False
+        lam, c, jar = (lam + alpha * dlam).astype(f), f(c * (1 - alpha)), (jar + alpha * jv).astype(f)
+        mask = jar < 0
+    qacc = a_s + c * e + MiJt @ lam
+    return qacc.astype(np.float64), jar < 0, elim, searches, stalls
