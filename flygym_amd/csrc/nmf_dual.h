@@ -261,6 +261,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // one elimination proves it.  A guess that does not even give a descent direction falls back to the start point's pattern.
   bool guessed = hist_any && !(m.solver_flags & 2);
   int stalls = 0;
+  unsigned long long mask_p = ~0ull, mask_pp = ~0ull;      // the pivot sets of the last two eliminations (none yet)
   unsigned long long mask = guessed ? __ballot(on && (hist_nib ? ((hist_nib >> k) & 1) != 0 : jar < 0.f)) : __ballot(on && jar < 0.f);
   for (int iter = 0; iter < m.max_iter; ++iter) {
     iters = iter + 1;
@@ -271,11 +272,29 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const float lam_t = act ? -b * __builtin_amdgcn_rcpf(diag) : 0.f;
     const float jar_t = act ? -R * lam_t : b;
     const unsigned long long tmask = __ballot(on && jar_t < 0.f);
+#ifdef NMF_DUAL_DEBUG
+    {
+      const float dmin = wave_min(act ? diag : 1e30f), lmax = wave_max(on ? fabsf(lam_t) : 0.f), jmax = wave_max(on ? fabsf(jar_t) : 0.f);
+      const float amax = wave_max(on ? fabsf(At[lane * (lane + 1) / 2 + lane]) : 0.f);
+      if (blockIdx.x == 0 && lane == 0) printf("iter %d npiv %d mask %016llx tmask %016llx min pivot %g max|lam_t| %g max|jar_t| %g max diag A %g c %g\n", iter, __popcll(mask), mask, tmask, dmin, lmax, jmax, amax, c_ws);
+    }
+#endif
     STAGE(10);
     if (tmask == mask) {       // the target satisfies its own active set: the optimum
       lam = lam_t; jar = jar_t; c_ws = 0.f;
       break;
     }
+    // A tie: the pivot set of two eliminations ago again.  In exact arithmetic the cost falls with every step and no set
+    // returns; in float32 a row whose residual (or force) is zero to rounding flips back and forth, and from there on the line
+    // search works on differences of rounding errors (round 4's soak: a curvature of 4e-6 from two sums of 4e-5, a step of
+    // 4e8, a fly leaving the scene at 100 m/s — once in 40 M steps).  Both sets' targets are the optimum but for that row:
+    // this one is taken if what it violates is small against the rows' residuals.
+    if (iter >= 2 && mask == mask_pp) {
+      const bool off = on && (((tmask ^ mask) >> lane) & 1ull);
+      const float viol = wave_max(off ? fabsf(jar_t) : 0.f), all = wave_max(on ? fabsf(jar_t) : 0.f);
+      if (viol <= 1e-3f * all) { lam = lam_t; jar = jar_t; c_ws = 0.f; break; }
+    }
+    mask_pp = mask_p; mask_p = mask;
     // line search towards the target
     const float jv = jar_t - jar, dlam = lam_t - lam, dc = -c_ws;
     float g1, g2, s1, s2;
@@ -310,6 +329,9 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       if (same || change <= 8.f * 1.1920929e-07f * fabsf(next)) break;
     }
     STAGE(12);
+#ifdef NMF_DUAL_DEBUG
+    if (blockIdx.x == 0 && lane == 0) printf("   line search: alpha %g g1 %g g2 %g s1 %g s2 %g\n", alpha, g1, g2, s1, s2);
+#endif
     if (alpha <= 0.f) {
       if (guessed) { guessed = false; mask = __ballot(on && jar < 0.f); continue; }
       // No descent the line search can measure.  In float32 the slope at alpha = 0 is a difference of sums of force x
@@ -323,6 +345,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       const float ai = flips ? -jar / jv : 1.f;
       alpha = fminf(1.f, wave_min(ai) * 1.001f + 1e-6f);
     }
+    alpha = fminf(alpha, 4.f);           // (a minimiser far beyond the target is a quotient of rounding errors)
     const bool was_guess = guessed;      // a step towards a guessed set's target is not a Newton step: its size says nothing about convergence
     guessed = false;
     lam = fmaf(alpha, dlam, lam); c_ws = fmaf(alpha, dc, c_ws); jar = fmaf(alpha, jv, jar);

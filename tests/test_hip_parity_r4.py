@@ -262,3 +262,47 @@ def test_max_contacts_is_the_contact_capacity(torch_mod, oracle_lib):
         HIPSimulation(make_model()[1], n_worlds=2, device=0, strict_contacts=True)
     with pytest.raises(ValueError):
         HIPSimulation(make_model()[1], n_worlds=2, device=0, max_contacts=0)
+
+
+@pytest.mark.parametrize("state", ["solver_tie_state_0.npz", "solver_tie_state_1.npz"])
+def test_a_tie_row_does_not_send_the_solve_into_the_noise(torch_mod, oracle_lib, state):
+    """Two states from a 20 000-step soak of config 5 (mixed terrain, 20 x gait adhesion, 10 and 12 contacts) on which the
+    contact-space solve of this round's first versions blew up — once in 40 M steps, found by ``scripts/gpu_soak.py``, not by
+    any parity test: a row whose residual is zero to rounding flipped in and out of the active set, the loop went on past the
+    optimum, and two eliminations later the line search divided a slope by a curvature of 4e-6 that was the difference of two
+    sums of 4e-5 — a step of 4e8, accelerations of 3e9, a fly leaving the scene.  The loop now recognises the pivot set of two
+    eliminations ago (a tie) and takes that target, and no step goes further than four times the way to its target.  From the
+    saved state: the oracle's accelerations, on every solver variant."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.utils.math import Rotation3D
+
+    d = np.load(GOLD / state)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    ref = None
+    for solver in ("", "nohist", "primal"):
+        fly = make_model()[0]
+        world = C.MixedTerrainWorld()
+        world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+        old = os.environ.get("NMF_SOLVER")
+        if solver: os.environ["NMF_SOLVER"] = solver
+        else: os.environ.pop("NMF_SOLVER", None)
+        try:
+            sim = HIPSimulation(world, n_worlds=2, device=0)
+        finally:
+            if old is None: os.environ.pop("NMF_SOLVER", None)
+            else: os.environ["NMF_SOLVER"] = old
+        ids = sim.replay_ids(fly.name, with_adhesion=True)
+        rows = torch.as_tensor(d["rows"], device=sim.device)[None].repeat(2, 1, 1).contiguous()
+        for k in keys: sim.field(k)[:] = torch.as_tensor(d[k], device=sim.device)[None, :]
+        sim.step_replay(rows, ids, int(d["cur"]), 1)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = oracle_lib.Oracle(sim.model.to_blob(), "f64")
+            for k in keys: ref.arr(k)[:] = d[k].astype(np.float64)
+            ref.step_replay(d["rows"], ids.cpu().numpy(), int(d["cur"]), 1)
+        a = ref.arr("qacc")
+        qacc, stats = sim.field("qacc")[0].cpu().numpy(), sim.field("stats")[0].cpu().numpy()
+        assert int(stats[0]) == ref.ints()["ncon"] and stats[1] <= 8
+        assert np.abs(qacc - a).max() < 2e-3 * np.abs(a).max(), solver
