@@ -4,8 +4,9 @@ Not a restatement of the reference — MuJoCo's Newton solver works on the accel
 that — but of the algorithm the kernel runs instead, so that its claims can be checked on the CPU against the oracle's
 optimum: every iterate is  qacc = qacc_smooth + c e + M^-1 J^T lambda;  per iteration ONE elimination of [R + A | j0] with
 the active rows as pivots; the target's own sign pattern = the pivot set  <=>  the KKT conditions hold; otherwise an exact
-line search towards the target, or — where the search finds no descent — the active-set step to the first row that changes
-sign; the previous step's final active set as the first guess."""
+line search towards the target (never further than four times the way), or — where the search finds no descent — the
+active-set step to the first row that changes sign; a pivot set that returns after two eliminations is a tie and its target
+is taken; the previous step's final active set as the first guess."""
 import numpy as np
 
 
@@ -28,6 +29,7 @@ def solve(M, J, aref, D, a_smooth, a_warm, guess=None, dtype=np.float64, max_ite
     guessed = guess is not None
     mask = np.asarray(guess, dtype=bool).copy() if guessed else jar < 0
     elim = searches = stalls = 0
+    mask_p = mask_pp = None
     for it in range(max_iter):
         elim += 1
         idx = np.nonzero(mask)[0]
@@ -39,6 +41,12 @@ def solve(M, J, aref, D, a_smooth, a_warm, guess=None, dtype=np.float64, max_ite
         if np.array_equal(jar_t < 0, mask):            # KKT: the optimum, exactly
             lam, jar, c = lam_t, jar_t, f(0)
             break
+        if it >= 2 and mask_pp is not None and np.array_equal(mask, mask_pp):      # a tie: this set was the one of two eliminations ago
+            off = (jar_t < 0) != mask
+            if np.abs(jar_t[off]).max(initial=0) <= 1e-3 * np.abs(jar_t).max():
+                lam, jar, c = lam_t, jar_t, f(0)
+                break
+        mask_pp, mask_p = mask_p, mask.copy()
         jv, dlam, dc = (jar_t - jar).astype(f), (lam_t - lam).astype(f), -c
         Alam, Adlam = jar - j0 - c * je, jv - dc * je
         g1 = c * dc * eMe + dc * (je @ lam) + c * (je @ dlam) + dlam @ Alam
@@ -70,6 +78,7 @@ def solve(M, J, aref, D, a_smooth, a_warm, guess=None, dtype=np.float64, max_ite
                 break
             flips = ((jar < 0) != (jar_t < 0)) & (jv != 0)
             alpha = f(min(1.0, float(np.min(np.where(flips, -jar / np.where(jv == 0, 1, jv), 1.0))) * 1.001 + 1e-6))
+        alpha = f(min(float(alpha), 4.0))
         guessed = False
         lam, c, jar = (lam + alpha * dlam).astype(f), f(c * (1 - alpha)), (jar + alpha * jv).astype(f)
         mask = jar < 0
