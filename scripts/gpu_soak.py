@@ -35,7 +35,8 @@ for name, world_cls, preset, adhesion in (("flat LEGS_ONLY", None, "legs_only", 
     torch.cuda.synchronize()
     ss = sim.field("stats_sum").to(torch.int64)
     q = sim.field("qpos")
-    dx = (q[:, 0] - x0).cpu().numpy()
+    dx = (q[:, 0] - x0).cpu().numpy()          # (the open-loop tripod gait walks a circle of ~4 mm radius — in the oracle too — so this is a range check, not a distance)
+    speed = sim.field("qvel")[:, :2].norm(dim=1).cpu().numpy()
     print(f"{name:28s} {steps} steps x {n} worlds in {time.time() - t0:5.1f} s: finite {bool(torch.isfinite(q).all())} (non-finite samples {bad}), "
           f"overflow steps {int(ss[:, 3].sum())}, contacts/step {ss[:, 1].sum().item() / ss[:, 0].sum().item():.2f}, iterations/step {ss[:, 2].sum().item() / ss[:, 0].sum().item():.2f} "
-          f"(max seen at a sample {worst_it}), forward travel median {np.median(dx):.2f} mm (min {dx.min():.2f}, max {dx.max():.2f}), body height median {float(q[:, 2].median()):.3f}")
+          f"(max seen at a sample {worst_it}), x displacement median {np.median(dx):.2f} mm (min {dx.min():.2f}, max {dx.max():.2f}), ground speed median {np.median(speed):.1f} mm/s (max {speed.max():.1f}), body height median {float(q[:, 2].median()):.3f}")
