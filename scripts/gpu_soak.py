@@ -12,12 +12,17 @@ from flygym_amd.controllers import TripodCPG
 from flygym_amd.utils.math import Rotation3D
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 n = 4096
-for name, world_cls, preset, adhesion in (("flat LEGS_ONLY", None, "legs_only", 0.0), ("mixed + 20x gait adhesion", "MixedTerrainWorld", "legs_only", 20.0),
-                                          ("blocks", "BlocksTerrainWorld", "legs_only", 0.0), ("flat ALL_BIOLOGICAL", None, "all_biological", 0.0)):
+WORKLOADS = (("flat LEGS_ONLY", None, "legs_only", 0.0), ("mixed + 20x gait adhesion", "MixedTerrainWorld", "legs_only", 20.0),
+             ("blocks", "BlocksTerrainWorld", "legs_only", 0.0), ("flat ALL_BIOLOGICAL", None, "all_biological", 0.0),
+             # the wider set (second argument "all")
+             ("gapped", "GappedTerrainWorld", "legs_only", 0.0), ("flat LEGS_ACTIVE_ONLY", None, "legs_active_only", 0.0),
+             ("tethered", "TetheredWorld", "legs_only", 0.0), ("mixed ALL_BIOLOGICAL", "MixedTerrainWorld", "all_biological", 0.0),
+             ("blocks + 20x gait adhesion", "BlocksTerrainWorld", "legs_only", 20.0), ("flat ALL_POSSIBLE", None, "all_possible", 0.0))
+for name, world_cls, preset, adhesion in (WORKLOADS if len(sys.argv) > 2 and sys.argv[2] == "all" else WORKLOADS[:4]):
     fly, world, _ = make_model(joints_preset=preset)
     if world_cls:
         world = getattr(C, world_cls)()
-        world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+        world.add_fly(fly, (0, 0, 1.5 if world_cls == "TetheredWorld" else 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n, device=0)
     cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
     table = cpg.targets(n, 2500, device=sim.device, adhesion=(cpg.stance_bins(sim.model, fly), adhesion, 1.0) if adhesion else None)
