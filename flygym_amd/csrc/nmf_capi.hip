@@ -105,7 +105,7 @@ struct nmf_batch {
   bool order_valid = false;
   int order_policy = 3;          // 3 auto (default), 1 costliest first, 0 in order, 2 none, -1 the measured policy of rounds 1-2
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
-  double chunk_div = 2.0;
+  double chunk_div = 2.0;        // halving chunks; 1.6 (20 = 13 + 5 + 2, 50 = 32 + 12 + 4 + 2) for the leg-chain kernels on flat ground, see launch()
 };
 
 extern "C" const char* nmf_last_error(void) { return g_err.c_str(); }
@@ -267,7 +267,8 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds,
   // round 2: whole-launch items 32.0 / 31.9 M env-steps/s (20- / 50-step launches), 7 equal chunks 36.3 / 38.3 M, halving
   // chunks (chunk_div 2: 10 + 5 + 3 + 1 + 1 steps) 42.4 / 44.4 M; a last chunk of one step (min_chunk_steps 1) is worth
-  // +1.2 % on 50-step launches.
+  // +1.2 % on 50-step launches.  Round 4 (a step a quarter cheaper, the hand-over the same): fewer, longer chunks — chunk_div
+  // 1.4 / 1.5 / 1.6 / 1.7 / 1.8 / 2.0: 51.4 / 53.4 / 53.6 / 53.4 / 53.3 / 52.5 M on 20-step launches, 53.4 / 54.5 / 55.3 / 55.5 / 55.1 / 55.2 M on 50-step ones.
   const bool oversub = b->n_worlds > b->resident_waves;
   int n_chunks = 1;
   b->st.n_chunks = 1; b->st.csched = b->csched_buf; b->st.handoff = b->handoff_buf; b->st.handoff_stride = b->handoff_stride;
@@ -539,6 +540,9 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     }
     if (const char* e = getenv("NMF_ORDER_EVERY")) b->order_every = std::max(1, atoi(e));
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
+    // (flat ground, leg-chain skeleton: a world's cost varies least and a step is cheapest against the hand-over — fewer, longer
+    // chunks; terrains and the full-body skeletons keep the halving plan: blocks 34.2 vs 32.4 M, ALL_BIOLOGICAL 30.7 vs 30.2 M)
+    b->chunk_div = (b->dm.terrain_type == 0 && topo < 2) ? 1.6 : 2.0;
     if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
