@@ -105,6 +105,7 @@ struct nmf_batch {
   bool order_valid = false;
   int order_policy = 3;          // 3 auto (default), 1 costliest first, 0 in order, 2 none, -1 the measured policy of rounds 1-2
   int max_chunks = 8, min_chunk_steps = 1;   // NMF_MAX_CHUNKS (<= 16) / NMF_MIN_CHUNK_STEPS / NMF_CHUNK_DIV: tuning experiments
+  bool chunk_div_short = false;  // chunk_div applies to launches of up to 64 steps only (longer ones halve)
   double chunk_div = 2.0;        // halving chunks; 1.6 (20 = 13 + 5 + 2, 50 = 32 + 12 + 4 + 2) for the leg-chain kernels on flat ground, see launch()
 };
 
@@ -275,7 +276,7 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   if (oversub && b->chunking && b->csched_buf && b->handoff_buf && n_steps >= 2 * b->min_chunk_steps) {
     int start = 0, c = 0;
     while (start < n_steps && c < b->max_chunks) {
-      int len = (int)std::ceil((n_steps - start) / b->chunk_div);
+      int len = (int)std::ceil((n_steps - start) / (b->chunk_div_short && n_steps > 64 ? 2.0 : b->chunk_div));
       len = std::max(len, b->min_chunk_steps);
       if (c == b->max_chunks - 1 || n_steps - start - len < b->min_chunk_steps) len = n_steps - start;
       b->st.chunk_start[c++] = start;
@@ -542,8 +543,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
     if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     // (flat ground, leg-chain skeleton: a world's cost varies least and a step is cheapest against the hand-over — fewer, longer
     // chunks; terrains and the full-body skeletons keep the halving plan: blocks 34.2 vs 32.4 M, ALL_BIOLOGICAL 30.7 vs 30.2 M)
+    // (and launches of more than 64 steps: 250-step launches 56.1 M halving, 54.5 M with 1.6)
     b->chunk_div = (b->dm.terrain_type == 0 && topo < 2) ? 1.6 : 2.0;
-    if (const char* e = getenv("NMF_CHUNK_DIV")) b->chunk_div = std::max(1.0, atof(e));
+    b->chunk_div_short = true;
+    if (const char* e = getenv("NMF_CHUNK_DIV")) { b->chunk_div = std::max(1.0, atof(e)); b->chunk_div_short = false; }
     if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
