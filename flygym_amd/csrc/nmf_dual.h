@@ -1,27 +1,37 @@
-// nmf_dual.h — the constraint solve in contact space (star kernels: a free root + identical leg chains).
+// nmf_dual.h — the constraint solve in contact space (leg-chain kernels: a free root + identical leg chains; and the hybrid
+// kernels whose data fit, see kDualS / kDualH in nmf_step.hip).
 //
-// Same problem, same Newton iterates and same optimum as the primal loop in physics_forward (MuJoCo's Newton solver with
-// exact line search, reference src/flygym/assets/model/mujoco_globals.yaml:13-14 behind mujoco_warp.step,
-// src/flygym/warp/simulation.py:260-263) — but no iteration walks the kinematic tree.  Every Newton iterate has the form
+// Same problem and same optimum as the primal loop in physics_forward (MuJoCo's Newton solver with exact line search,
+// reference src/flygym/assets/model/mujoco_globals.yaml:13-14 behind mujoco_warp.step, src/flygym/warp/simulation.py:260-263)
+// — but no iteration walks the kinematic tree.  Every iterate has the form
 //     qacc = qacc_smooth + c (qacc_warmstart - qacc_smooth) + M^-1 J^T lambda
 // (a scalar c and one multiplier per pyramid row), so the loop lives on the rows, lane = row:
 //   * once per step: A = J M^-1 J^T as a Gram matrix.  The smooth solve's articulated-body factors (U / sqrt D, 1 / sqrt D
 //     per hinge and per root axis) are kept in LDS; lane (contact, direction) pushes its unit force leaf-to-root through them
 //     — u_j / sqrt(D_j) at every hinge of its leg and at the six root axes, 17 numbers — and
 //     A[row][row'] = <root parts> + [same leg] <leg parts>:  M^-1 = L^-T D^-1 L^-1, and legs meet at the root only.
-//     The vectors stay in registers (a row's vector reaches the other lanes through v_readlane); A's lower triangle goes
-//     to LDS, over Ib..W which are dead until the next step's inertia stage.
+//     The vectors stay in registers (a row's vector reaches the other lanes through ds_bpermute); A's lower triangle goes
+//     to LDS, over buffers that are dead until the next step's inertia stage.
 //   * per iteration: ONE Gauss-Jordan elimination of [R + A | j0] (R = 1 / D, j0 = J qacc_smooth - aref) with the active
-//     rows (J qacc - aref < 0) as pivots and every row taking part — see dual_eliminate.  It yields the Newton target
-//     directly: active rows lambda* = -x and residual -R lambda*, inactive rows the eliminated j0.  If the target's own sign
-//     pattern is the pivot set it is the optimum (KKT) and the loop ends; otherwise the exact line search towards it (rows
-//     in registers; the Gauss term's derivatives are row-space dot products) and the next iteration.
-//   * once at the end: qacc from the summed row responses (one root-to-leaf pass over the kept factors).
-// Steps with more than kDualMaxCon contacts (A's triangle no longer fits), tethered worlds and trees with more than
-// root + legs take the primal loop.
+//     rows as pivots and every row taking part — see dual_eliminate.  It yields the Newton target directly: active rows
+//     lambda* = -x and residual -R lambda*, inactive rows the eliminated j0.  If the target's own sign pattern is the pivot
+//     set it is the optimum (KKT) and the loop ends; otherwise the exact line search towards it (rows in registers; the Gauss
+//     term's derivatives are row-space dot products) and the next iteration.
+//   * the first pivot set is the previous step's final active set (act_hist) where one is known.
+//   * how it ends when not by the KKT test — float32 makes every cost-based test blind long before the accelerations of
+//     light distal dofs are settled, and lets a tie row flip for ever: a line search without measurable descent takes the
+//     active-set step (to the first row that changes sign, at most three times); the pivot set of two eliminations ago is a tie
+//     and its target is taken; no step is longer than four times the way to its target; MuJoCo's improvement test and the
+//     rounding floor of the cost are guards from the sixth elimination on (see the loop).
+//   * once at the end: qacc from the summed row responses (one root-to-leaf pass over the kept factors; hybrid kernels: the
+//     rest of the body follows the root through the smooth solve's cached factors).
+// Steps with more than kDualMaxCon<TP> contacts (A's triangle no longer fits), with a contact on the rest of the body (hybrid
+// kernels) and tethered worlds take the primal loop; so do ALL_POSSIBLE and the general-tree kernels altogether.
 // Code size matters here as much as instruction count: the step kernel's hot path fills the 64 KB instruction cache a pair
-// of CUs shares, so what runs once per row is a loop, and the elimination — unrolled, its multipliers live in registers — is
-// ordered so that only the blocks a step needs are ever fetched.
+// of CUs shares, so what runs once per row is a loop, and the elimination — unrolled by pivot ordinal, its multipliers live in
+// registers — is ordered so that only the blocks a step needs are ever fetched.
+// Development switches: NMF_DUAL_DEBUG (per-iteration printf of world 0), NMF_DUAL_NOWARM (no warm-start term),
+// NMF_DUAL_EXIT_FROM=<n> (first elimination at which the cost-based guards apply), NMF_NO_DUAL / NMF_NO_DUAL_HYBRID.
 #pragma once
 
 namespace nmf {
