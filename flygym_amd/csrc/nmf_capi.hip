@@ -184,7 +184,7 @@ extern "C" int nmf_batch_set_contact_capacity(nmf_batch* b, int max_contacts) {
   if (!b) return fail("nmf_batch_set_contact_capacity: null batch");
   if (max_contacts < 1) return fail("nmf_batch_set_contact_capacity: max_contacts must be at least 1");
   const int cap = max_contacts > nmf::kMaxCon ? nmf::kMaxCon : max_contacts;
-  HIP_OK(hipSetDevice(b->device));
+  DEVICE_GUARD(b);      // the caller's current device stays what it was
   b->dm.max_contacts = cap;
   HIP_OK(hipMemcpy(reinterpret_cast<char*>(b->dm_dev) + offsetof(nmf::DevModel, max_contacts), &cap, sizeof(int), hipMemcpyHostToDevice));
   return cap;
