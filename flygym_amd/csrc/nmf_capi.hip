@@ -94,6 +94,7 @@ struct nmf_batch {
   struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0, n_omm = 0; float fov = 0.f; int n_groups[3] = {0, 0, 0}; int* visit[3] = {nullptr, nullptr, nullptr}; float* cones[3] = {nullptr, nullptr, nullptr}; float* chunk_cones[3] = {nullptr, nullptr, nullptr}; int* slot_omm = nullptr; } eye_plan;      // [0] chunks that feed an ommatidium, [1] all chunks (frames), [2] sampled mode: pixels
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
+  bool wide = false;             // the batch steps on the nmf::Wide kernels (CPU flavour, see nmf_batch_create)
   bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
   // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = auto (default) | costliest | inorder |
   // none (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
@@ -303,8 +304,11 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
 #define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else if (terrain) NMF_LAUNCH(nmf::Terrain<TOPO>, false); else NMF_LAUNCH(TOPO, false); }
+  // the CPU flavour's LEGS_ONLY kernels (noslip pass on): 16 contacts in the contact-space solve (nmf::Wide)
+#define NMF_LAUNCH_WIDE(K, TOPO) if (b->topo == K) { if (terrain) NMF_LAUNCH(nmf::Terrain<nmf::Wide<TOPO>>, false); else NMF_LAUNCH(nmf::Wide<TOPO>, false); }
+  const bool wide = b->wide;
 #if NMF_HAS_TOPO(0)
-  NMF_LAUNCH_TOPO(0, nmf::FlyTopo)
+  if (wide) { NMF_LAUNCH_WIDE(0, nmf::FlyTopo) } else { NMF_LAUNCH_TOPO(0, nmf::FlyTopo) }
 #endif
 #if NMF_HAS_TOPO(1)
   NMF_LAUNCH_TOPO(1, nmf::FlyTopoActive)
@@ -322,6 +326,7 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   NMF_LAUNCH_TOPO(5, nmf::FlyTopoAll)
 #endif
 #undef NMF_LAUNCH_TOPO
+#undef NMF_LAUNCH_WIDE
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -565,7 +570,11 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       const void* fn = nullptr;
 #define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<TOPO>, false>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
 #if NMF_HAS_TOPO(0)
-      NMF_FN(0, nmf::FlyTopo)
+      // (the CPU flavour — noslip iterations on, LEGS_ONLY, untethered — steps on the kernels with room for 16 contacts)
+      b->wide = topo == 0 && !weld && b->dm.noslip_iter > 0 && !(b->dm.solver_flags & 1);
+      if (b->wide) { if (terrain) fn = reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<nmf::Wide<nmf::FlyTopo>>, false>);
+                     else fn = reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Wide<nmf::FlyTopo>, false>); }
+      else { NMF_FN(0, nmf::FlyTopo) }
 #endif
 #if NMF_HAS_TOPO(1)
       NMF_FN(1, nmf::FlyTopoActive)

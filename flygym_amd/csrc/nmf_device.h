@@ -34,6 +34,7 @@ template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
 struct HybridTopo {
   static constexpr bool kStar = true;
   static constexpr bool kTerrain = false;   // see Terrain<> below
+  static constexpr bool kWide = false;      // see Wide<> below
   // controls a kernel keeps in LDS: 48 for the leg skeletons, 64 for the full-body ones (nmf_batch_create sends models
   // with more actuators to the general-tree kernel, which holds one per dof)
   static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 64;
@@ -65,6 +66,7 @@ template <int NB_, int NV_>
 struct TreeTopoT {
   static constexpr bool kStar = false;
   static constexpr bool kTerrain = false;
+  static constexpr bool kWide = false;
   static constexpr int NB = NB_, NV = NV_, NQ = NV_ + 1;
   static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
   static constexpr int kFact0 = 0, kSlot0 = 1;      // every dof has articulated-body factors, every non-root body a hand-off slot
@@ -78,6 +80,14 @@ struct TreeTopoT {
 template <class TP>
 struct Terrain : TP {
   static constexpr bool kTerrain = true;
+};
+// The same skeleton with room for 16 contacts in the contact-space solve (nmf_dual.h) instead of 12 — 3.4 KB more LDS for
+// the triangle of A, i.e. six flies per CU instead of eight.  For the CPU flavour (flygym_amd.Simulation: one world, noslip
+// iterations on): its noslip pass lives in that solve, and 7 % of a walking fly's steps have 13-15 contacts.  The batched
+// class never runs these kernels.
+template <class TP>
+struct Wide : TP {
+  static constexpr bool kWide = true;
 };
 
 using TreeTopo = TreeTopoT<72, 216>;

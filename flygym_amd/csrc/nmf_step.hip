@@ -187,7 +187,7 @@ template <class TP> constexpr int dual_max_con() {
     int n = 0;
     while (n < 12 && (4 * (n + 1)) * (4 * (n + 1) + 1) / 2 <= 2 * TP::NB * 6) ++n;
     return n;
-  } else return 12;
+  } else return (TP::kWide && TP::NV >= 64) ? 16 : 12;      // (16 contacts = 64 rows = the wave; their reference accelerations take 64 floats of vB)
 }
 template <class TP> inline constexpr int kDualMaxCon = dual_max_con<TP>();
 // LDS words of the active-set history (the contact-space solve's first guess, DevState::act_hist).  kDualS: a table by geom,

@@ -431,8 +431,9 @@ class Simulation:
     (a single world is launch-latency bound: ≈ 0.1 ms per ``step()``; use ``step(n)`` to fuse steps).  Differences:
     no ``mj_model`` / ``mj_data`` (the engine arrays are reachable through ``batch.field(name)``), rendering handed off.
     The CPU class's noslip post-pass (``option/noslip_iterations = 5``, ``mujoco_globals.yaml:15``) runs here too — on the
-    leg-chain skeletons, where the contact-space solve has the matrix it needs; a step with more than 12 contacts cannot
-    take it and is counted in the overflow statistic.
+    LEGS_ONLY skeleton on every step (the class steps on kernels with room for 16 contacts in the contact-space solve, where
+    the pass lives; a walking fly makes up to 15); on LEGS_ACTIVE_ONLY a step with more than 12 contacts cannot take it and
+    is counted in the overflow statistic.
     """
 
     def __init__(self, world: BaseWorld, device: int | None = None) -> None:

@@ -306,3 +306,45 @@ def test_a_tie_row_does_not_send_the_solve_into_the_noise(torch_mod, oracle_lib,
         qacc, stats = sim.field("qacc")[0].cpu().numpy(), sim.field("stats")[0].cpu().numpy()
         assert int(stats[0]) == ref.ints()["ncon"] and stats[1] <= 8
         assert np.abs(qacc - a).max() < 2e-3 * np.abs(a).max(), solver
+
+
+def test_cpu_flavour_runs_the_noslip_pass_on_every_step(torch_mod, oracle_lib):
+    """7 % of a walking fly's steps have 13-15 contacts — more than the batched kernels' contact-space solve takes (12: the
+    triangle of A in LDS at eight flies per CU).  The CPU flavour steps on kernels with room for 16 (``nmf::Wide``, six flies
+    per CU — irrelevant for one world), so its noslip pass, which lives in that solve, runs on EVERY step.  256 walkers:
+    no step without the pass over 3000 steps although the contact count passes 12 on the way; steps with 13 contacts and more
+    against the oracle running the same pass."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.controllers import TripodCPG
+
+    n = 256
+    fly, world, _ = make_model()
+    sim = HIPSimulation(world, n_worlds=n, device=0, _cpu_flavour=True)
+    assert world.noslip_iterations == 5
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(n, 2500, device=sim.device)
+    ids = sim.replay_ids(fly.name)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    sim.warmup(); sim.step_replay(table, ids, 0, 850)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    blob = sim.model.to_blob()
+    cur, many, worst = 850, 0, 0.0
+    for k in range(40):
+        sim.step_replay(table, ids, cur, 49); cur += 49
+        state = {kk: sim.field(kk).clone() for kk in keys}
+        sim.step_replay(table, ids, cur, 1); cur += 1
+        torch.cuda.synchronize()
+        stats = sim.field("stats").cpu().numpy()
+        big = np.nonzero(stats[:, 0] >= 13)[0]
+        many += len(big)
+        for w in big[:2]:
+            r = oracle_lib.Oracle(blob, "f64", cpu_flavour=True)
+            for kk in keys: r.arr(kk)[:] = state[kk][w].cpu().numpy().astype(np.float64)
+            r.step_replay(table[w].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
+            if r.ints()["ncon"] != int(stats[w, 0]): continue
+            a = r.arr("qacc")
+            worst = max(worst, float(np.abs(sim.field("qacc")[w].cpu().numpy() - a).max() / np.abs(a).max()))
+    ss = sim.field("stats_sum").cpu().numpy()
+    assert many >= 20, many                                           # the walk does pass 12 contacts
+    assert int(ss[:, 3].sum()) == 0 and int(ss[:, 0].min()) == cur + 500      # ... and no step went without the pass
+    assert 0.0 < worst < 2e-3, worst
