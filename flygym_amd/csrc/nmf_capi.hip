@@ -570,10 +570,28 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       const void* fn = nullptr;
 #define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<TOPO>, false>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
 #if NMF_HAS_TOPO(0)
-      // (the CPU flavour — noslip iterations on, LEGS_ONLY, untethered — steps on the kernels with room for 16 contacts)
-      b->wide = topo == 0 && !weld && b->dm.noslip_iter > 0 && !(b->dm.solver_flags & 1);
-      if (b->wide) { if (terrain) fn = reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<nmf::Wide<nmf::FlyTopo>>, false>);
-                     else fn = reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Wide<nmf::FlyTopo>, false>); }
+      // The kernels with room for 16 contacts in the contact-space solve (nmf::Wide: six flies per CU instead of eight) for
+      //  * the CPU flavour (noslip iterations on, LEGS_ONLY, untethered): its noslip pass lives in that solve;
+      //  * batches that fit their residency (six per CU: 1536 flies): nothing is lost, and the 7 % of steps with 13-15 contacts
+      //    no longer take the primal loop, whose cost is the tail a launch of resident worlds waits for — CPG walking 1024
+      //    flies 17.0 -> 22.2 M env-steps/s, 1536 flies 24.6 -> 31.7 M, config 5 at 1024 / 128 flies 16.8 -> 18.4 / 2.49 -> 2.63 M,
+      //    replay protocol at 1024 flies 26.3 -> 27.3 M.  (Up to twice that size the CPG workload still gains — 2048 flies 31.7 ->
+      //    38.7 M: eight resident flies per CU cannot share work — but the replay protocol loses, 46.6 -> 40.0 M; beyond,
+      //    the two flies per CU count for more: 4096 flies 46.2 M wide, 55.6 M with eight per CU.)
+      // (Results of those rare steps then differ at tolerance level between a batch below and above that size: the same
+      // optimum reached by two solvers.)  NMF_WIDE=0 / 1 overrides.
+      {
+        const void* fw = terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<nmf::Wide<nmf::FlyTopo>>, false>)
+                                 : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Wide<nmf::FlyTopo>, false>);
+        int nw = 0, ncu = 256;
+        hipDeviceProp_t pw;
+        if (hipGetDeviceProperties(&pw, device) == hipSuccess) ncu = pw.multiProcessorCount;
+        const bool fits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, fw, nmf::kWave, 0) == hipSuccess && nw > 0 && n_worlds <= nw * ncu;
+        b->wide = topo == 0 && !weld && !(b->dm.solver_flags & 1) && (b->dm.noslip_iter > 0 || fits);
+        if (const char* e = getenv("NMF_WIDE")) b->wide = topo == 0 && !weld && atoi(e) != 0;
+        if (b->wide) fn = fw;
+      }
+      if (b->wide) {}
       else { NMF_FN(0, nmf::FlyTopo) }
 #endif
 #if NMF_HAS_TOPO(1)
