@@ -520,6 +520,11 @@ def run(args, primary=True):
     steps_seen = max(float(dsum[0].item()), 1.0)
     mean_contacts, mean_iters = float(dsum[1].item()) / steps_seen, float(dsum[2].item()) / steps_seen
     overflow_steps = int(dsum[3].item())
+    # how the steps' constraint solves ended (NMF_STATS_SUM columns 4..14), per million env-steps of the timed region
+    per_m = lambda k: float(dsum[k].item()) * 1e6 / steps_seen
+    solver_exits = {"unit": "per million env-steps", "contact_space": per_m(4), "kkt_exact": per_m(5), "tie_rule": per_m(6),
+                    "stalled_line_search": per_m(7), "cost_tests": per_m(8), "iteration_limit": per_m(9), "primal_loop": per_m(10),
+                    "fallback_resolves": per_m(11), "big_eliminations": per_m(12), "noslip_skipped": per_m(13), "no_contact": per_m(14)}
     finite = bool(flags[0].item() > 0)
     rccl_ranks = None
     if use_dist:
@@ -606,6 +611,7 @@ def run(args, primary=True):
                 "rccl_ranks": rccl_ranks,
                 "state_finite": finite, "contact_overflow_steps": overflow_steps,
                 "mean_contacts": mean_contacts, "mean_newton_iters": mean_iters,
+                "solver_exits": solver_exits,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -33,6 +33,28 @@ class NativeError(RuntimeError):
     pass
 
 
+class BatchOptions(ctypes.Structure):
+    """``nmf_batch_options`` of include/nmf.h (0 = the library's default)."""
+
+    _fields_ = [("struct_size", ctypes.c_int32), ("solver", ctypes.c_int32), ("sched", ctypes.c_int32), ("order", ctypes.c_int32),
+                ("max_chunks", ctypes.c_int32), ("min_chunk_steps", ctypes.c_int32), ("order_every", ctypes.c_int32),
+                ("rest_slow", ctypes.c_int32), ("chunk_div", ctypes.c_float)]
+
+    SOLVER = {"": 0, "default": 0, "primal": 1, "nohist": 2, "nofallback": 4}
+    SCHED = {"": 0, "chunks": 0, "plain": 1}
+    ORDER = {"": 0, "auto": 0, "inorder": 1, "costliest": 2, "none": 3, "policy": 4}
+
+    @classmethod
+    def make(cls, solver="", sched="", order="", max_chunks=0, min_chunk_steps=0, order_every=0, rest_slow=False, chunk_div=0.0):
+        return cls(ctypes.sizeof(cls), cls.SOLVER[solver], cls.SCHED[sched], cls.ORDER[order], int(max_chunks), int(min_chunk_steps),
+                   int(order_every), int(bool(rest_slow)), float(chunk_div))
+
+
+INFO_KEYS = ("kernel_family", "terrain_kernel", "tether_kernel", "contact_space_flavour", "contact_space_max_contacts", "flies_per_cu",
+             "resident_workgroups", "chunked", "max_chunks", "chunk_div_x1000", "order_policy", "solver_option_bits", "noslip_iterations",
+             "contact_capacity", "kernel_lds_bytes", "kernel_vgprs")
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [CSRC / "nmf_capi.hip", CSRC / "nmf_step.hip", CSRC / "nmf_sensors.hip", CSRC / "nmf_eyes.hip", CSRC / "nmf_replay.hip", CSRC / "nmf_device.h", CSRC / "nmf_tree.h", CSRC / "nmf_dual.h",
@@ -100,6 +122,9 @@ def lib():
             "nmf_model_destroy": (None, [vp]),
             "nmf_model_dims": (ci, [vp, ctypes.POINTER(ctypes.c_int32)]),
             "nmf_batch_create": (vp, [vp, ci, ci]),
+            "nmf_batch_create_ex": (vp, [vp, ci, ci, vp]),
+            "nmf_batch_info": (ci, [vp, ctypes.POINTER(ctypes.c_int32)]),
+            "nmf_step_record": (ci, [vp, vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
             "nmf_batch_destroy": (None, [vp]),
             "nmf_batch_n_worlds": (ci, [vp]),
             "nmf_model_contact_bound": (ci, [vp]),

@@ -94,8 +94,9 @@ struct nmf_batch {
   struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0, n_omm = 0; float fov = 0.f; int n_groups[3] = {0, 0, 0}; int* visit[3] = {nullptr, nullptr, nullptr}; float* cones[3] = {nullptr, nullptr, nullptr}; float* chunk_cones[3] = {nullptr, nullptr, nullptr}; int* slot_omm = nullptr; } eye_plan;      // [0] chunks that feed an ommatidium, [1] all chunks (frames), [2] sampled mode: pixels
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
-  bool wide = false;             // the batch steps on the nmf::Wide kernels (CPU flavour, see nmf_batch_create)
-  bool chunking = true;          // NMF_NO_CHUNKS=1 (diagnostic) keeps whole-launch work items
+  const void* step_fn = nullptr; // the stepping kernel this batch launches (nmf_batch_info)
+  int per_cu = 0;                // workgroups of it a CU holds
+  bool chunking = true;          // options.sched = 1 keeps whole-launch work items
   // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = auto (default) | costliest | inorder |
   // none (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
   // faster, the other re-tried every 32nd launch).  auto = costliest first for launches of up to 64 steps — the cost of the
@@ -262,8 +263,11 @@ int launch_reset(nmf_batch* b, const uint8_t* mask_dev, hipStream_t stream) {
   return 0;
 }
 
-int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t stream) {
+struct RingArgs { float* ring = nullptr; int stride = 0, every = 0, nj = 0, nact = 0; };
+
+int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t stream, const RingArgs& ring = RingArgs()) {
   DEVICE_GUARD(b);      // the caller's current device need not be the batch's, and stays what it was
+  b->st.ring = ring.ring; b->st.ring_stride = ring.stride; b->st.obs_every = ring.ring ? ring.every : 0; b->st.ring_nj = ring.nj; b->st.ring_nact = ring.nact;
   // More worlds than resident waves and a launch long enough to cut: chunks whose lengths shrink towards the end of the
   // launch ("guided" sizes: each takes 1 / chunk_div of what is left, at least min_chunk_steps, at most max_chunks chunks)
   // — long items while there is plenty of other work, short ones where they bound the tail.  Measured on 4096 worlds,
@@ -304,11 +308,8 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
 #define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
 #define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else if (terrain) NMF_LAUNCH(nmf::Terrain<TOPO>, false); else NMF_LAUNCH(TOPO, false); }
-  // the CPU flavour's LEGS_ONLY kernels (noslip pass on): 16 contacts in the contact-space solve (nmf::Wide)
-#define NMF_LAUNCH_WIDE(K, TOPO) if (b->topo == K) { if (terrain) NMF_LAUNCH(nmf::Terrain<nmf::Wide<TOPO>>, false); else NMF_LAUNCH(nmf::Wide<TOPO>, false); }
-  const bool wide = b->wide;
 #if NMF_HAS_TOPO(0)
-  if (wide) { NMF_LAUNCH_WIDE(0, nmf::FlyTopo) } else { NMF_LAUNCH_TOPO(0, nmf::FlyTopo) }
+  NMF_LAUNCH_TOPO(0, nmf::FlyTopo)
 #endif
 #if NMF_HAS_TOPO(1)
   NMF_LAUNCH_TOPO(1, nmf::FlyTopoActive)
@@ -326,7 +327,6 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   NMF_LAUNCH_TOPO(5, nmf::FlyTopoAll)
 #endif
 #undef NMF_LAUNCH_TOPO
-#undef NMF_LAUNCH_WIDE
 #undef NMF_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -334,8 +334,27 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
 
 }  // namespace
 
+namespace {
+template <class T> struct TopoTag { using type = T; };
+// Development overrides from the process environment — honoured only under NMF_ALLOW_ENV=1 (the one getenv gate of this
+// library): a stray NMF_* variable in a user's shell never changes what a batch runs.
+const char* dev_env(const char* name) {
+  static const bool allowed = [] { const char* e = getenv("NMF_ALLOW_ENV"); return e && atoi(e) != 0; }();
+  return allowed ? getenv(name) : nullptr;
+}
+}  // namespace
+
 extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device) {
+  return nmf_batch_create_ex(model, n_worlds, device, nullptr);
+}
+
+extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, int device, const nmf_batch_options* options) {
   g_err.clear();
+  nmf_batch_options opt{};
+  if (options) {
+    if (options->struct_size < (int32_t)sizeof(int32_t) || options->struct_size > (int32_t)sizeof(nmf_batch_options)) { fail("nmf_batch_create_ex: options->struct_size does not match this library"); return nullptr; }
+    memcpy(&opt, options, (size_t)options->struct_size);
+  }
   if (!model) { fail("nmf_batch_create: null model"); return nullptr; }
   if (n_worlds <= 0) { fail("nmf_batch_create: n_worlds must be positive"); return nullptr; }
   int topo = -1;
@@ -464,7 +483,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       const HostArray* da = model->find("body_dofadr");
       const int nl = (int)lvl_start.size() - 2;                 // levels below the root
       // NMF_DISABLE_REST_FAST: diagnostic switch, forces the table-driven level passes (tests cover both paths)
-      bool fast = da && nl <= nmf::kRestLevels && !getenv("NMF_DISABLE_REST_FAST");
+      bool fast = da && nl <= nmf::kRestLevels && !opt.rest_slow && !dev_env("NMF_DISABLE_REST_FAST");
       std::vector<int> pack((size_t)nmf::kRestLevels * 16, -1);
       for (int lv = 1; fast && lv <= nl; ++lv) {
         const int k0 = lvl_start[(size_t)lv], k1 = lvl_start[(size_t)lv + 1];
@@ -484,10 +503,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   d.noslip_iter = 0;
   if (const HostArray* os2 = model->find("opt_solver")) { if (os2->i.size() > 1) d.noslip_iter = os2->i[1]; }
   d.max_contacts = nmf::kMaxCon;
-  d.solver_flags = 0;
-  if (const char* e = getenv("NMF_SOLVER")) {      // diagnostics: primal | nohist (default: contact-space solve with the active-set history)
+  d.solver_flags = opt.solver & 7;
+  if (const char* e = dev_env("NMF_SOLVER")) {      // primal | nohist | nofallback (default: contact-space solve with the active-set history)
     const std::string v(e);
-    d.solver_flags = v == "primal" ? 1 : v == "nohist" ? 2 : 0;
+    d.solver_flags = v == "primal" ? 1 : v == "nohist" ? 2 : v == "nofallback" ? 4 : 0;
   }
   if (rc == 0) {
     void* p = nullptr;
@@ -507,10 +526,10 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
   rc |= alloc_field(b, NMF_ACTUATOR_FORCE, model->nu, &st.actuator_force);
   rc |= alloc_field(b, NMF_SENSORDATA, 96, &st.sensordata);
   rc |= alloc_field(b, NMF_TIME, 1, &st.time);
-  rc |= alloc_field(b, NMF_STATS, 4, &st.stats);
+  rc |= alloc_field(b, NMF_STATS, 8, &st.stats);
   rc |= alloc_field(b, NMF_QACC, model->nv, &st.qacc);
   rc |= alloc_field(b, NMF_COST, 1, &st.cost);
-  { float* p = nullptr; rc |= alloc_field(b, NMF_STATS_SUM, 4, &p); st.stats_sum = reinterpret_cast<unsigned int*>(p); }   // uint32 counters
+  { float* p = nullptr; rc |= alloc_field(b, NMF_STATS_SUM, 16, &p); st.stats_sum = reinterpret_cast<unsigned int*>(p); }   // uint32 counters
   rc |= alloc_field(b, NMF_CONTACT_GEOM, nmf::kMaxCon, &st.contact_geom);
   {
     void* p = nullptr;
@@ -538,21 +557,28 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       b->allocs.push_back(p); b->clock_probe_buf = (unsigned long long*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
     st.clock_probe = b->clock_probe_buf;
-    b->chunking = getenv("NMF_NO_CHUNKS") == nullptr;
-    if (const char* e = getenv("NMF_SCHED")) { if (std::string(e) == "plain") b->chunking = false; }
-    if (const char* e = getenv("NMF_ORDER")) {
-      const std::string v(e);
-      b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 3;
-    }
-    if (const char* e = getenv("NMF_ORDER_EVERY")) b->order_every = std::max(1, atoi(e));
-    if (const char* e = getenv("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
+    b->chunking = opt.sched != 1;
+    if (opt.order) b->order_policy = opt.order == 1 ? 0 : opt.order == 2 ? 1 : opt.order == 3 ? 2 : opt.order == 4 ? -1 : 3;
+    if (opt.order_every > 0) b->order_every = opt.order_every;
+    if (opt.max_chunks > 0) b->max_chunks = std::max(1, std::min(16, opt.max_chunks));
     // (flat ground, leg-chain skeleton: a world's cost varies least and a step is cheapest against the hand-over — fewer, longer
     // chunks; terrains and the full-body skeletons keep the halving plan: blocks 34.2 vs 32.4 M, ALL_BIOLOGICAL 30.7 vs 30.2 M)
     // (and launches of more than 64 steps: 250-step launches 56.1 M halving, 54.5 M with 1.6)
-    b->chunk_div = (b->dm.terrain_type == 0 && topo < 2) ? 1.6 : 2.0;
+    // (round 5, one contact-space solve for every walking step: 1.5 / 1.6 / 1.7 / 1.8 / 2.0 = 56.7 / 56.6 / 56.7 / 56.6 / 55.8 M on 20-step
+    // launches, 58.7 / 58.9 / 59.2 / 59.0 / 58.9 M on 50-step ones)
+    b->chunk_div = (b->dm.terrain_type == 0 && topo < 2) ? 1.7 : 2.0;
     b->chunk_div_short = true;
-    if (const char* e = getenv("NMF_CHUNK_DIV")) { b->chunk_div = std::max(1.0, atof(e)); b->chunk_div_short = false; }
-    if (const char* e = getenv("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
+    if (opt.chunk_div > 1.f) { b->chunk_div = opt.chunk_div; b->chunk_div_short = false; }
+    if (opt.min_chunk_steps > 0) b->min_chunk_steps = opt.min_chunk_steps;
+    if (const char* e = dev_env("NMF_SCHED")) b->chunking = std::string(e) != "plain";
+    if (const char* e = dev_env("NMF_ORDER")) {
+      const std::string v(e);
+      b->order_policy = v == "inorder" ? 0 : v == "costliest" ? 1 : v == "none" ? 2 : v == "policy" ? -1 : 3;
+    }
+    if (const char* e = dev_env("NMF_ORDER_EVERY")) b->order_every = std::max(1, atoi(e));
+    if (const char* e = dev_env("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = dev_env("NMF_CHUNK_DIV")) { b->chunk_div = std::max(1.0, atof(e)); b->chunk_div_short = false; }
+    if (const char* e = dev_env("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
       (void)hipMemset(p, 0, sizeof(nmf::SchedState));
@@ -570,29 +596,7 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
       const void* fn = nullptr;
 #define NMF_FN(K, TOPO) if (topo == K) fn = weld ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, true>) : terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<TOPO>, false>) : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<TOPO, false>);
 #if NMF_HAS_TOPO(0)
-      // The kernels with room for 16 contacts in the contact-space solve (nmf::Wide: six flies per CU instead of eight) for
-      //  * the CPU flavour (noslip iterations on, LEGS_ONLY, untethered): its noslip pass lives in that solve;
-      //  * batches that fit their residency (six per CU: 1536 flies): nothing is lost, and the 7 % of steps with 13-15 contacts
-      //    no longer take the primal loop, whose cost is the tail a launch of resident worlds waits for — CPG walking 1024
-      //    flies 17.0 -> 22.2 M env-steps/s, 1536 flies 24.6 -> 31.7 M, config 5 at 1024 / 128 flies 16.8 -> 18.4 / 2.49 -> 2.63 M,
-      //    replay protocol at 1024 flies 26.3 -> 27.3 M.  (Up to twice that size the CPG workload still gains — 2048 flies 31.7 ->
-      //    38.7 M: eight resident flies per CU cannot share work — but the replay protocol loses, 46.6 -> 40.0 M; beyond,
-      //    the two flies per CU count for more: 4096 flies 46.2 M wide, 55.6 M with eight per CU.)
-      // (Results of those rare steps then differ at tolerance level between a batch below and above that size: the same
-      // optimum reached by two solvers.)  NMF_WIDE=0 / 1 overrides.
-      {
-        const void* fw = terrain ? reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Terrain<nmf::Wide<nmf::FlyTopo>>, false>)
-                                 : reinterpret_cast<const void*>(&nmf::nmf_step_kernel<nmf::Wide<nmf::FlyTopo>, false>);
-        int nw = 0, ncu = 256;
-        hipDeviceProp_t pw;
-        if (hipGetDeviceProperties(&pw, device) == hipSuccess) ncu = pw.multiProcessorCount;
-        const bool fits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, fw, nmf::kWave, 0) == hipSuccess && nw > 0 && n_worlds <= nw * ncu;
-        b->wide = topo == 0 && !weld && !(b->dm.solver_flags & 1) && (b->dm.noslip_iter > 0 || fits);
-        if (const char* e = getenv("NMF_WIDE")) b->wide = topo == 0 && !weld && atoi(e) != 0;
-        if (b->wide) fn = fw;
-      }
-      if (b->wide) {}
-      else { NMF_FN(0, nmf::FlyTopo) }
+      NMF_FN(0, nmf::FlyTopo)
 #endif
 #if NMF_HAS_TOPO(1)
       NMF_FN(1, nmf::FlyTopoActive)
@@ -613,6 +617,8 @@ extern "C" nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int
 #undef NMF_FN
       int nblk = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, nmf::kWave, 0) == hipSuccess && nblk > 0) per_cu = nblk;
+      b->step_fn = fn;
+      b->per_cu = per_cu;
     }
     b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;
   }
@@ -633,6 +639,38 @@ extern "C" void nmf_batch_destroy(nmf_batch* b) {
 }
 
 extern "C" int nmf_batch_n_worlds(const nmf_batch* b) { return b ? b->n_worlds : 0; }
+
+extern "C" int nmf_batch_info(const nmf_batch* b, int32_t out[16]) {
+  if (!b || !out) return fail("nmf_batch_info: null argument");
+  const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
+  int flavour = 0, maxcon = 0;
+  auto dual_of = [&](auto topo_tag) {
+    using TP = typename decltype(topo_tag)::type;
+    if (!weld && !(b->dm.solver_flags & 1)) { flavour = nmf::kDualS<TP> ? 1 : nmf::kDualH<TP> ? 2 : 0; maxcon = flavour ? nmf::kDualMaxCon<TP> : 0; }
+  };
+  switch (b->topo) {
+#if NMF_HAS_TOPO(0)
+    case 0: dual_of(TopoTag<nmf::FlyTopo>{}); break;
+#endif
+#if NMF_HAS_TOPO(1)
+    case 1: dual_of(TopoTag<nmf::FlyTopoActive>{}); break;
+#endif
+#if NMF_HAS_TOPO(4)
+    case 4: dual_of(TopoTag<nmf::FlyTopoBio>{}); break;
+#endif
+#if NMF_HAS_TOPO(5)
+    case 5: dual_of(TopoTag<nmf::FlyTopoAll>{}); break;
+#endif
+    default: break;
+  }
+  out[0] = b->topo; out[1] = terrain ? 1 : 0; out[2] = weld ? 1 : 0; out[3] = flavour; out[4] = maxcon;
+  out[5] = b->per_cu; out[6] = b->resident_waves; out[7] = b->chunking ? 1 : 0; out[8] = b->max_chunks;
+  out[9] = (int32_t)std::lround(1000.0 * b->chunk_div); out[10] = b->order_policy; out[11] = b->dm.solver_flags;
+  out[12] = b->dm.noslip_iter; out[13] = b->dm.max_contacts; out[14] = 0; out[15] = 0;
+  hipFuncAttributes fa;
+  if (b->step_fn && hipFuncGetAttributes(&fa, b->step_fn) == hipSuccess) { out[14] = (int32_t)fa.sharedSizeBytes; out[15] = fa.numRegs; }
+  return 0;
+}
 
 extern "C" int nmf_reset(nmf_batch* b, void* stream) {
   if (!b) return fail("nmf_reset: null batch");
@@ -663,6 +701,25 @@ extern "C" int nmf_step_replay(nmf_batch* b, const float* table_dev, int table_s
   nmf::ReplayArgs rp{table_dev, act_ids_dev, table_steps, n_act, ((start % table_steps) + table_steps) % table_steps};
   b->steps += n_steps;
   return launch(b, rp, n_steps, (hipStream_t)stream);
+}
+
+extern "C" int nmf_step_record(nmf_batch* b, const float* table_dev, int table_steps, int n_act_table, const int32_t* act_ids_dev, int start,
+                               int n_steps, int obs_every, int n_joint, int n_act, float* ring_dev, int row_stride, void* stream) {
+  if (!b) return fail("nmf_step_record: null batch");
+  if (n_steps <= 0 || obs_every <= 0) return fail("nmf_step_record: n_steps and obs_every must be positive");
+  if (!ring_dev) return fail("nmf_step_record: null ring");
+  const nmf_model* m = b->model;
+  if (n_joint < 0 || n_joint > m->nv - 6 || n_act < 0 || n_act > m->nu || row_stride < 2 * n_joint + n_act + 96)
+    return fail("nmf_step_record: need 0 <= n_joint <= nv - 6, 0 <= n_act <= nu and row_stride >= 2 n_joint + n_act + 96");
+  nmf::ReplayArgs rp{nullptr, nullptr, 1, 0, 0};
+  if (table_dev) {
+    if (!act_ids_dev || table_steps <= 0 || n_act_table <= 0 || n_act_table > m->nu) return fail("nmf_step_record: bad replay table arguments");
+    rp = nmf::ReplayArgs{table_dev, act_ids_dev, table_steps, n_act_table, ((start % table_steps) + table_steps) % table_steps};
+  }
+  RingArgs ring;
+  ring.ring = ring_dev; ring.stride = row_stride; ring.every = obs_every; ring.nj = n_joint; ring.nact = n_act;
+  b->steps += n_steps;
+  return launch(b, rp, n_steps, (hipStream_t)stream, ring);
 }
 
 extern "C" float* nmf_field_ptr(nmf_batch* b, int field, int32_t* width) {

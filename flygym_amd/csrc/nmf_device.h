@@ -34,7 +34,6 @@ template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
 struct HybridTopo {
   static constexpr bool kStar = true;
   static constexpr bool kTerrain = false;   // see Terrain<> below
-  static constexpr bool kWide = false;      // see Wide<> below
   // controls a kernel keeps in LDS: 48 for the leg skeletons, 64 for the full-body ones (nmf_batch_create sends models
   // with more actuators to the general-tree kernel, which holds one per dof)
   static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 64;
@@ -66,7 +65,6 @@ template <int NB_, int NV_>
 struct TreeTopoT {
   static constexpr bool kStar = false;
   static constexpr bool kTerrain = false;
-  static constexpr bool kWide = false;
   static constexpr int NB = NB_, NV = NV_, NQ = NV_ + 1;
   static constexpr int kCtrl = NV_ + 8;      // every dof actuated + adhesion
   static constexpr int kFact0 = 0, kSlot0 = 1;      // every dof has articulated-body factors, every non-root body a hand-off slot
@@ -81,15 +79,6 @@ template <class TP>
 struct Terrain : TP {
   static constexpr bool kTerrain = true;
 };
-// The same skeleton with room for 16 contacts in the contact-space solve (nmf_dual.h) instead of 12 — 3.4 KB more LDS for
-// the triangle of A, i.e. six flies per CU instead of eight.  For the CPU flavour (flygym_amd.Simulation: one world, noslip
-// iterations on): its noslip pass lives in that solve, and 7 % of a walking fly's steps have 13-15 contacts.  The batched
-// class never runs these kernels.
-template <class TP>
-struct Wide : TP {
-  static constexpr bool kWide = true;
-};
-
 using TreeTopo = TreeTopoT<72, 216>;
 using TreeTopoSmall = TreeTopoT<72, 144>;
 
@@ -168,7 +157,7 @@ struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
       *sensordata, *time, *stats, *qacc;
-  unsigned int* stats_sum; // [n_worlds][4] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps
+  unsigned int* stats_sum; // [n_worlds][16] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps, 12 solve-report counters (include/nmf.h)
   float* contact_geom;     // [n_worlds][kMaxCon] geom index of contact c at the launch's last step (-1 beyond ncon)
   // [n_worlds][kActHistWords] the constraint solver's second warm start: the active pyramid rows (4 bits) of up to four contacts
   // per geom at the end of the last step the contact-space solve ran (nmf_dual.h); zero = nothing known
@@ -186,6 +175,11 @@ struct DevState {
   int n_chunks;               // chunked schedule: number of chunks
   unsigned long long* clock_probe;   // [2] shader cycles / 100 MHz ticks workgroup 0 spent in stepping launches (nmf_shader_clock)
   int sched_mode;             // 0 plain (one workgroup per world), 1 chunked (persistent workgroups, tickets): nmf_step_kernel
+  // observation ring of this launch (nmf_step_record; nullptr: none): after every obs_every-th step the world's observation
+  // block [joint angles ring_nj | joint velocities ring_nj | forces of the first ring_nact actuators | 96 contact-sensor floats]
+  // goes to ring[(step + 1) / obs_every - 1][world][.], rows ring_stride floats apart
+  float* ring;
+  int ring_stride, obs_every, ring_nj, ring_nact;
   int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 

@@ -6,12 +6,17 @@
 // — but no iteration walks the kinematic tree.  Every iterate has the form
 //     qacc = qacc_smooth + c (qacc_warmstart - qacc_smooth) + M^-1 J^T lambda
 // (a scalar c and one multiplier per pyramid row), so the loop lives on the rows, lane = row:
-//   * once per step: A = J M^-1 J^T as a Gram matrix.  The smooth solve's articulated-body factors (U / sqrt D, 1 / sqrt D
+//   * once per step: A = J M^-1 J^T out of a Gram matrix.  The smooth solve's articulated-body factors (U / sqrt D, 1 / sqrt D
 //     per hinge and per root axis) are kept in LDS; lane (contact, direction) pushes its unit force leaf-to-root through them
 //     — u_j / sqrt(D_j) at every hinge of its leg and at the six root axes, 17 numbers — and
-//     A[row][row'] = <root parts> + [same leg] <leg parts>:  M^-1 = L^-T D^-1 L^-1, and legs meet at the root only.
-//     The vectors stay in registers (a row's vector reaches the other lanes through ds_bpermute); A's lower triangle goes
-//     to LDS, over buffers that are dead until the next step's inertia stage.
+//     G[dir][dir'] = <root parts> + [same leg] <leg parts>:  M^-1 = L^-T D^-1 L^-1, and legs meet at the root only.
+//     The vectors stay in registers (a contact's three vectors reach another contact's lanes through ds_bpermute, the
+//     three pairings inside the quad through DPP); G goes to LDS as one 3x3 block per unordered pair of contacts, over buffers
+//     that are dead until the next step's inertia stage.  A row of the pyramid is n +- mu t, so
+//       A[(c,k)][(c',k')] = G[n,n'] + s'mu' G[n,t'] + s mu (G[t,n'] + s'mu' G[t,t'])
+//     — four reads of one block and three multiply-adds when an elimination needs a column (DualCol).  Storing G instead of
+//     A's row triangle is what lets 16 contacts (64 rows: the wave) fit the LDS of eight flies per CU: 9 * 16 * 17 / 2 = 1224
+//     floats, where the rows' triangle took 1176 for 12 contacts and 2080 for 16 (rounds 3-4: a second kernel flavour).
 //   * per iteration: ONE Gauss-Jordan elimination of [R + A | j0] (R = 1 / D, j0 = J qacc_smooth - aref) with the active
 //     rows as pivots and every row taking part — see dual_eliminate.  It yields the Newton target directly: active rows
 //     lambda* = -x and residual -R lambda*, inactive rows the eliminated j0.  If the target's own sign pattern is the pivot
@@ -25,8 +30,9 @@
 //     rounding floor of the cost are guards from the sixth elimination on (see the loop).
 //   * once at the end: qacc from the summed row responses (one root-to-leaf pass over the kept factors; hybrid kernels: the
 //     rest of the body follows the root through the smooth solve's cached factors).
-// Steps with more than kDualMaxCon<TP> contacts (A's triangle no longer fits), with a contact on the rest of the body (hybrid
-// kernels) and tethered worlds take the primal loop; so do ALL_POSSIBLE and the general-tree kernels altogether.
+// Steps with more than kDualMaxCon<TP> contacts (16: the rows are the wave's lanes; hybrid kernels 13: G in T..W), with a
+// contact on the rest of the body (hybrid kernels) and tethered worlds take the primal loop; so do ALL_POSSIBLE and the
+// general-tree kernels altogether.
 // Code size matters here as much as instruction count: the step kernel's hot path fills the 64 KB instruction cache a pair
 // of CUs shares, so what runs once per row is a loop, and the elimination — unrolled by pivot ordinal, its multipliers live in
 // registers — is ordered so that only the blocks a step needs are ever fetched.
@@ -37,19 +43,54 @@
 namespace nmf {
 
 // (the factors' homes: dual_leg / dual_root / dual_aref / dual_acc in nmf_step.hip)
-// A's lower triangle, row i at i (i + 1) / 2: over Ib..W (+ dual_pad); hybrid kernels: over T..W (Ib is their one copy of
-// the inertias)
+// G, block (c, c') with c >= c' at 9 (c (c + 1) / 2 + c'), entry [direction of c][direction of c'] (0 normal, 1 / 2 tangents):
+// over Ib..W (+ dual_pad); hybrid kernels: over T..W (Ib is their one copy of the inertias)
 template <class TP>
-__device__ __forceinline__ float* dual_a(FlyLds<TP>& s) {
-  constexpr size_t need = sizeof(float) * (4 * kDualMaxCon<TP>) * (4 * kDualMaxCon<TP> + 1) / 2;
+__device__ __forceinline__ float* dual_g(FlyLds<TP>& s) {
+  constexpr size_t need = sizeof(float) * dual_g_floats(kDualMaxCon<TP>);
   if constexpr (kDualH<TP>) {
-    static_assert(!kDualH<TP> || need <= sizeof(s.T) + sizeof(s.W), "A does not fit T..W");
+    static_assert(!kDualH<TP> || need <= sizeof(s.T) + sizeof(s.W), "G does not fit T..W");
     return &s.T[0][0];
   } else {
-    static_assert(kDualH<TP> || need <= sizeof(s.Ib) + sizeof(s.T) + sizeof(s.W) + sizeof(s.dual_pad), "A does not fit Ib..W");
+    static_assert(kDualH<TP> || need <= sizeof(s.Ib) + sizeof(s.T) + sizeof(s.W) + sizeof(s.dual_pad), "G does not fit Ib..W");
     return &s.Ib[0][0];
   }
 }
+// Column kk (wave-uniform) of A as row `lane` sees it: the four entries of block (contact of lane, contact of kk) that a pair of
+// pyramid rows combines.  fetch() issues the reads (an elimination asks a pivot ahead), value() combines them.
+struct DualCol {
+  lds_cptr G;
+  int cc;                 // the lane's contact
+  int cc9b, blk9b;        // byte offsets: 36 cc, 36 cc (cc + 1) / 2
+  int tdb, td3b;          // the lane's tangent (1: rows 0 / 1, 2: rows 2 / 3) as byte offsets 4 td, 12 td
+  float smu;              // +- mu of the lane's row
+  struct Raw { float nn, nt, tn, tt, smu2; };
+  __device__ __forceinline__ void init(const float* g, int lane, float smu_) {
+    G = lds_pinned(g); cc = lane >> 2; cc9b = 36 * cc; blk9b = 36 * (cc * (cc + 1) / 2);
+    const int td = 1 + ((lane >> 1) & 1);
+    tdb = 4 * td; td3b = 12 * td; smu = smu_;
+    asm("" : "+v"(cc9b), "+v"(blk9b), "+v"(tdb), "+v"(td3b));      // lane constants, not expressions to re-derive per pivot
+  }
+  __device__ __forceinline__ Raw fetch(int kk) const {
+    const unsigned int c2 = (unsigned int)kk >> 2, td2b = 4u + (((unsigned int)kk << 1) & 4u);      // scalar
+    int c29b = (int)(36u * c2), blk29b = (int)(18u * (c2 * (c2 + 1u)));
+    asm("" : "+s"(c29b), "+s"(blk29b));      // (scalar multiplies, not v_mad_u64_u32 per lane)
+    // the lane's contact names the block's row side (cc >= c2) or its column side: both forms of the block's address, then
+    // selected — no branch, no exec masking; the other offsets by arithmetic on the lane's two-valued multiplier
+    int lo = blk9b + c29b, up = cc9b + blk29b;
+    asm("" : "+v"(lo), "+v"(up));
+    const bool ge = cc >= (int)c2;
+    const int base = ge ? lo : up;
+    const int o_nt = (ge ? 1 : 3) * (int)td2b, o_tn = ge ? td3b : tdb;
+    const int a_nt = base + o_nt, a_tn = base + o_tn, a_tt = a_tn + o_nt;
+    auto at = [&](int byte_off) { return *(lds_cptr)((const __attribute__((address_space(3))) char*)G + byte_off); };
+    Raw r;
+    r.nn = at(base); r.nt = at(a_nt); r.tn = at(a_tn); r.tt = at(a_tt);
+    r.smu2 = readlane_f(smu, kk);
+    return r;
+  }
+  __device__ __forceinline__ float value(const Raw& r) const { return fmaf(smu, fmaf(r.smu2, r.tt, r.tn), fmaf(r.smu2, r.nt, r.nn)); }
+};
 __device__ __forceinline__ float quad_sum(float v) {
   v += NMF_DPP(v, 0xB1);
   v += NMF_DPP(v, 0x4E);
@@ -62,27 +103,23 @@ constexpr int dual_root_axis(int i) { return i < 3 ? 2 - i : 8 - i; }     // eli
 // zero on the pivot's own row; the pivot row's entry at a later pivot column kk is that column's entry of row kk by symmetry
 // of the not-yet-eliminated block — v_readlane(cq[q], kk) — so column kk of the current matrix is
 //   A[.][kk] - sum_{q < p} cq[q] * cq[q](lane kk)      (two chains: the sum is a dependent sequence of multiply-adds).
-// A's column kk is one read of the stored triangle, requested a pivot ahead.  On return b holds the eliminated right-hand
+// A's column kk is four reads of G (DualCol), requested a pivot ahead.  On return b holds the eliminated right-hand
 // side, diag the pivot of the lane's own row (active rows).
 template <int PMAX>
-__device__ __forceinline__ void dual_eliminate(unsigned long long rem, const float* At, float R, int lane, float& b, float& diag) {
+__device__ __forceinline__ void dual_eliminate(unsigned long long rem, const DualCol& dc, float R, int lane, float& b, float& diag) {
   float cq[PMAX];
-  const int tri_own = lane * (lane + 1) / 2;
-  auto a_of = [&](int kk) {       // A[lane][kk] out of the lower triangle (both addresses formed, then selected: no branch)
-    int lo = tri_own + kk, up = kk * (kk + 1) / 2 + lane;
-    asm("" : "+v"(lo), "+v"(up));
-    return At[lane >= kk ? lo : up];
-  };
-  int kk_next = rem ? __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1) : 0;
-  float an = a_of(kk_next);
+  auto first_of = [](unsigned long long r) { return __builtin_amdgcn_readfirstlane(max(__ffsll((long long)r) - 1, 0)); };      // (0 for an empty set: a harmless fetch)
+  int kk_next = first_of(rem);
+  DualCol::Raw an = dc.fetch(kk_next);
 #define NMF_DUAL_PIVOT(P)                                                                                   \
   if constexpr (P < PMAX) {                                                                                 \
     if (rem == 0ull) return;                                                                                \
     const int kk = kk_next;                                                                                 \
     rem &= rem - 1ull;                                                                                      \
-    float col = an + (lane == kk ? R : 0.f);                                                                \
-    kk_next = rem ? __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1) : 0;                       \
-    an = a_of(kk_next);                                                                                     \
+    float col = dc.value(an) + (lane == kk ? R : 0.f);                                                      \
+    kk_next = first_of(rem);                                                                                \
+    an = dc.fetch(kk_next);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);      /* the next column's reads are in flight while this pivot's chain runs */ \
     { float c1 = 0.f;                                                                                       \
       _Pragma("unroll") for (int q = 0; q + 1 < P; q += 2) {                                                \
         col = fmaf(-cq[q], readlane_f(cq[q], kk), col); c1 = fmaf(-cq[q + 1], readlane_f(cq[q + 1], kk), c1); } \
@@ -101,11 +138,31 @@ __device__ __forceinline__ void dual_eliminate(unsigned long long rem, const flo
 #undef NMF_DUAL_PIVOT
 }
 
+// What the primal loop needs and a contact-space solve overwrote — the inertias (star kernels: G lies on Ib; Isym holds the same
+// numbers) and the twists of the unconstrained acceleration in T.  Its own function: a rejected solve is one in ten thousand, and
+// inlined its registers and instructions sat in every step's way.
+template <class TP>
+__device__ __noinline__ void dual_restore(FlyLds<TP>& s, const GModel& m, int lane) {
+  WSYNC();
+  if constexpr (kDualS<TP>) {
+    for (int b = lane; b < TP::NB; b += kWave) {
+      const float* Q = s.Isym[b];
+      float* I = s.Ib[b];
+      I[0] = Q[15]; I[1] = Q[13]; I[2] = Q[5]; I[3] = Q[8]; I[4] = Q[0]; I[5] = Q[6]; I[6] = Q[11]; I[7] = Q[1]; I[8] = Q[2]; I[9] = Q[7];
+    }
+    WSYNC();
+  }
+  sweep_twists(s, s.qacc_smooth, s.T, m, lane);
+}
+
+// How a solve ended (SolveReport bits, nmf_step.hip) and what the elimination it ended on violates: for every end but the
+// exact one the rows in (target's sign pattern) xor (pivot set) are the target's KKT violations — the largest |residual| among
+// them relative to the largest |residual| of all rows goes out as `resid` (0 = exact).
 // aref of row (contact c, pyramid row k) is expected in s.vB[4 c + k] (physics_forward puts it there).  Leaves qacc and the
 // contact wrenches (c_w: the Euler step's solve takes them as forces on the bodies, J^T f is never formed); returns the
-// number of Newton iterations (= eliminations).
+// number of Newton iterations (= eliminations), the report through `report` / `resid`.
 template <class TP, int NC>
-__device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls STAGE_ARG) {
+__device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls, unsigned int& report, float& resid STAGE_ARG) {
   constexpr int NDL = TP::NDL, NLEG = TP::NLEG, SW = row_width_s<TP>();
   // (per-lane addresses of this stage are rebuilt every step: hoisted out of the persistent item loop they sat in registers
   // across all other stages and pushed 16 of the loop's other invariants into scratch — ten reloads per step)
@@ -120,7 +177,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   const Frame fr0 = ld_frame(s, m);
   float (*const DFleg)[8] = dual_leg(s);
   float (*const DFroot)[8] = dual_root(s);
-  float* const At = dual_a(s);
+  float* const Gm = dual_g(s);
   const int n4 = 4 * ncon;
   const bool on = lane < n4;
   const int cc = on ? lane >> 2 : 0, k = lane & 3;
@@ -225,37 +282,43 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       for (int q = 0; q < 6; ++q) w[q] = fmaf(-f[q], u, w[q]);
     });
   }
-  // this lane's row: n +- mu t, from the direction lanes of its quad (lane 0: n, 1: t1, 2: t2)
+  // ---- G = Gram matrix of the direction responses, every unordered pair of contacts once: in round t the quad of contact c
+  // takes contact c - t (cyclically over the ncon contacts), whose three vectors come through ds_bpermute — lane (c, k) fetches
+  // direction k — and pairs every one of them with its own: the partner's other two directions reach the lane through a
+  // quad permutation (k -> k + p mod 3; lane 3 of a quad carries a copy of t2 and stores nothing).  ncon / 2 + 1 rounds.
   {
-    auto row_of = [&](float v) {
-      const float vn = NMF_DPP(v, 0x00), v1 = NMF_DPP(v, 0x55), v2 = NMF_DPP(v, 0xAA);
-      return fmaf(smu, k < 2 ? v1 : v2, vn);
-    };
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ur[i] = row_of(ur[i]);
-#pragma unroll
-    for (int d = 0; d < NDL; ++d) ul[d] = row_of(ul[d]);
-  }
-  // ---- A = J M^-1 J^T, every unordered pair of rows once: in round t lane i takes the row t lanes below it (cyclically over
-  // the n4 rows), whose vector comes through ds_bpermute — n4 / 2 + 1 rounds instead of one per row
-  {
-    const int tri_own = lane * (lane + 1) / 2;
-    const int half = n4 >> 1;
+    const int kd = k < 3 ? k : 2;
+    const int half = ncon >> 1;
     for (int t = 0; t <= half; ++t) {
-      int kk = lane - t;
-      kk = kk < 0 ? kk + n4 : kk;
-      const int src = (on ? kk : lane) << 2;
+      int c2 = cc - t;
+      c2 = c2 < 0 ? c2 + ncon : c2;
+      const int src = (on ? 4 * c2 + k : lane) << 2;
       auto from = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v))); };
-      float a = from(ur[0]) * ur[0];
+      float pr[6], pl[NDL];
 #pragma unroll
-      for (int i = 1; i < 6; ++i) a = fmaf(from(ur[i]), ur[i], a);
-      float bl = from(ul[0]) * ul[0];
+      for (int i = 0; i < 6; ++i) pr[i] = from(ur[i]);
 #pragma unroll
-      for (int d = 1; d < NDL; ++d) bl = fmaf(from(ul[d]), ul[d], bl);
-      a += __builtin_amdgcn_ds_bpermute(src, leg) == leg ? bl : 0.f;
-      int lo = tri_own + kk, up = kk * (kk + 1) / 2 + lane;
-      asm("" : "+v"(lo), "+v"(up));
-      if (on) At[lane >= kk ? lo : up] = a;
+      for (int d = 0; d < NDL; ++d) pl[d] = from(ul[d]);
+      const bool same = __builtin_amdgcn_ds_bpermute(src, leg) == leg;
+      const bool ge = cc >= c2;
+      int base = ge ? 9 * (cc * (cc + 1) / 2 + c2) + 3 * kd : 9 * (c2 * (c2 + 1) / 2 + cc) + kd;
+      const int stride = ge ? 1 : 3;
+      asm("" : "+v"(base));
+      static_for<3>([&](auto PP) {
+        constexpr int p = decltype(PP)::value;
+        auto rot = [&](float v) {      // the fetched vector of direction (k + p) mod 3
+          if constexpr (p == 0) return v; else if constexpr (p == 1) return NMF_DPP(v, 0xC9); else return NMF_DPP(v, 0xD2);
+        };
+        float a = rot(pr[0]) * ur[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) a = fmaf(rot(pr[i]), ur[i], a);
+        float bl = rot(pl[0]) * ul[0];
+#pragma unroll
+        for (int d = 1; d < NDL; ++d) bl = fmaf(rot(pl[d]), ul[d], bl);
+        a += same ? bl : 0.f;
+        const int d2 = kd + p >= 3 ? kd + p - 3 : kd + p;
+        if (on && k < 3) Gm[base + stride * d2] = a;
+      });
     }
   }
   WSYNC();
@@ -263,6 +326,8 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
 
   // ---- Newton iterations on the rows
   float jar = fmaf(c_ws, je, j0), lam = 0.f;
+  DualCol dcol;
+  dcol.init(Gm, lane, smu);
   const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
   int iters = 0;
   // The first active set: the rows that were active at the end of the previous step, for the contacts that existed then (same
@@ -271,27 +336,34 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // one elimination proves it.  A guess that does not even give a descent direction falls back to the start point's pattern.
   bool guessed = hist_any && !(m.solver_flags & 2);
   int stalls = 0;
+  unsigned int exit_bit = kExitMaxIter;
+  int npiv = 0;
+  float jar_last = 0.f;                                    // the last elimination's target residuals and its violated rows
+  unsigned long long viol_last = 0ull;
   unsigned long long mask_p = ~0ull, mask_pp = ~0ull;      // the pivot sets of the last two eliminations (none yet)
   unsigned long long mask = guessed ? __ballot(on && (hist_nib ? ((hist_nib >> k) & 1) != 0 : jar < 0.f)) : __ballot(on && jar < 0.f);
   for (int iter = 0; iter < m.max_iter; ++iter) {
     iters = iter + 1;
     // Gauss-Jordan on [R + A | j0]: pivots = active rows in index order, every row takes part
     float b = j0, diag = 1.f;
-    dual_eliminate<4 * NC>(mask, At, R, lane, b, diag);
+    dual_eliminate<4 * NC>(mask, dcol, R, lane, b, diag);
     const bool act = (mask >> lane) & 1ull;
     const float lam_t = act ? -b * __builtin_amdgcn_rcpf(diag) : 0.f;
     const float jar_t = act ? -R * lam_t : b;
     const unsigned long long tmask = __ballot(on && jar_t < 0.f);
+    npiv = max(npiv, (int)__popcll(mask));
+    jar_last = jar_t; viol_last = tmask ^ mask;
 #ifdef NMF_DUAL_DEBUG
     {
       const float dmin = wave_min(act ? diag : 1e30f), lmax = wave_max(on ? fabsf(lam_t) : 0.f), jmax = wave_max(on ? fabsf(jar_t) : 0.f);
-      const float amax = wave_max(on ? fabsf(At[lane * (lane + 1) / 2 + lane]) : 0.f);
+      const float amax = wave_max(on ? fabsf(dcol.value(dcol.fetch(0))) : 0.f);      // (column 0)
       if (blockIdx.x == 0 && lane == 0) printf("iter %d npiv %d mask %016llx tmask %016llx min pivot %g max|lam_t| %g max|jar_t| %g max diag A %g c %g\n", iter, __popcll(mask), mask, tmask, dmin, lmax, jmax, amax, c_ws);
     }
 #endif
     STAGE(10);
     if (tmask == mask) {       // the target satisfies its own active set: the optimum
       lam = lam_t; jar = jar_t; c_ws = 0.f;
+      exit_bit = kExitKkt;
       break;
     }
     // A tie: the pivot set of two eliminations ago again.  In exact arithmetic the cost falls with every step and no set
@@ -302,7 +374,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     if (iter >= 2 && mask == mask_pp) {
       const bool off = on && (((tmask ^ mask) >> lane) & 1ull);
       const float viol = wave_max(off ? fabsf(jar_t) : 0.f), all = wave_max(on ? fabsf(jar_t) : 0.f);
-      if (viol <= 1e-3f * all) { lam = lam_t; jar = jar_t; c_ws = 0.f; break; }
+      if (viol <= 1e-3f * all) { lam = lam_t; jar = jar_t; c_ws = 0.f; exit_bit = kExitTie; break; }
     }
     mask_pp = mask_p; mask_p = mask;
     // line search towards the target
@@ -350,7 +422,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       // this solve's missing one).  The Newton target itself does not depend on the cost: go towards it as far as the first
       // row that changes sign (the active-set step; a hair beyond it, so that the row's new state is what the next
       // elimination sees).  At most three such steps per solve.
-      if (++stalls > 3) break;
+      if (++stalls > 3) { exit_bit = kExitStall; break; }
       const bool flips = on && ((jar < 0.f) != (jar_t < 0.f)) && jv != 0.f;
       const float ai = flips ? -jar / jv : 1.f;
       alpha = fminf(1.f, wave_min(ai) * 1.001f + 1e-6f);
@@ -374,27 +446,42 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
 #define NMF_DUAL_EXIT_FROM 5
 #endif
     if (!was_guess && iter >= NMF_DUAL_EXIT_FROM &&
-        (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) break;
+        (scale * improvement < m.tolerance || improvement <= kNoiseFactor * 1.1920929e-07f * fabsf(gauss + ccost))) { exit_bit = kExitCost; break; }
     mask = __ballot(on && jar < 0.f);
   }
+  // the report: how it ended, the most pivots an elimination had, what the last target violates
+  resid = 0.f;
+  if (exit_bit != kExitKkt) {
+    const bool off = on && ((viol_last >> lane) & 1ull);
+    const float viol = wave_max(off ? fabsf(jar_last) : 0.f), all = wave_max(on ? fabsf(jar_last) : 0.f);
+    resid = all > 0.f ? viol * __builtin_amdgcn_rcpf(all) : 0.f;
+  }
+  report = kExitDual | exit_bit | (npiv > kDualRegPivots ? kExitBigPivots : 0u) | ((unsigned int)npiv << 20);
+  // An end that is not the exact one and whose last target violates more than kDualResidMax of the residuals is not taken: the
+  // step goes to the primal loop (physics_forward).
+#ifndef NMF_NO_FALLBACK
+  if (resid > kDualResidMax && !(m.solver_flags & 4)) {
+    dual_restore(s, m, lane);
+    report = kExitFallback | (report & kExitBigPivots) | ((unsigned int)npiv << 20);
+    return -1;
+  }
+#endif
   // the rows' forces
   float frow = on && jar < 0.f ? -D * jar : 0.f;
   // ---- noslip post-pass (the CPU flavour's option/noslip_iterations, reference mujoco_globals.yaml:15 under mujoco.mj_step,
   // src/flygym/simulation.py:74-76; restated from MuJoCo's documentation in oracle/nmf_oracle.c::noslip): Gauss-Seidel over
   // the pairs of opposing pyramid edges with the regulariser removed — a pair (mid + y, mid - y) keeps its sum, y in
   // [-mid, mid] minimises 1/2 f^T A f + f^T j0; an update that raises the cost is undone; up to noslip_iter sweeps.
-  // A is the triangle in LDS, a pair's residual two wave sums.  Not a throughput path: the batched class strips the option.
+  // A's columns come out of G (DualCol), a pair's residual is two wave sums.  Not a throughput path: the batched class strips the option.
   if (m.noslip_iter > 0) {
-    const int tri_own = lane * (lane + 1) / 2;
-    auto a_at = [&](int i, int j) { return i >= j ? At[i * (i + 1) / 2 + j] : At[j * (j + 1) / 2 + i]; };
     for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
       float improvement = sweep == 0 ? wave_sum(0.5f * frow * frow * R) : 0.f;       // the regulariser's share of the cost drops out
       for (int c2 = 0; c2 < ncon; ++c2) {
         for (int pp = 0; pp < 2; ++pp) {
           const int r0 = 4 * c2 + 2 * pp, r1 = r0 + 1;
-          const float col0 = At[lane >= r0 ? tri_own + r0 : r0 * (r0 + 1) / 2 + lane], col1 = At[lane >= r1 ? tri_own + r1 : r1 * (r1 + 1) / 2 + lane];
+          const float col0 = dcol.value(dcol.fetch(r0)), col1 = dcol.value(dcol.fetch(r1));
           const float res0 = wave_sum(on ? col0 * frow : 0.f) + readlane_f(j0, r0), res1 = wave_sum(on ? col1 * frow : 0.f) + readlane_f(j0, r1);
-          const float a00 = a_at(r0, r0), a01 = a_at(r1, r0), a11 = a_at(r1, r1);
+          const float a00 = readlane_f(col0, r0), a01 = readlane_f(col0, r1), a11 = readlane_f(col1, r1);
           const float old0 = readlane_f(frow, r0), old1 = readlane_f(frow, r1);
           const float bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
           const float mid = 0.5f * (old0 + old1);
@@ -421,7 +508,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     } else {     // entry of contact cc in half (cc & 1) of word cc / 2: lane 8 i packs contacts 2 i and 2 i + 1
       const unsigned int entry = on && k == 0 && hist_slot < 4 ? 0x4000u | (unsigned int)hist_g | ((unsigned int)hist_slot << 8) | (nib << 10) : 0u;
       const unsigned int other = (unsigned int)__builtin_amdgcn_ds_bpermute(((lane + 4) & 63) << 2, (int)entry);
-      if (on && (lane & 7) == 0) s.act_hist[lane >> 3] = entry | (other << 16);
+      if (on && (lane & 7) == 0 && (lane >> 3) < kHistLds<TP>) s.act_hist[lane >> 3] = entry | (other << 16);
     }
   }
   STAGE(9);
@@ -432,14 +519,18 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
   WSYNC();
   {
+    // the rows' multipliers as forces along the contact's directions (lane k < 3 of a quad: n, t1, t2): the response vectors
+    // in registers are the directions'
     const float l0 = on ? lam : 0.f;
-    if (l0 != 0.f && leg >= 0) {
+    const float q0 = NMF_DPP(l0, 0x00), q1 = NMF_DPP(l0, 0x55), q2 = NMF_DPP(l0, 0xAA), q3 = NMF_DPP(l0, 0xFF);
+    const float fdir = k == 0 ? (q0 + q1) + (q2 + q3) : k == 1 ? mu * (q0 - q1) : k == 2 ? mu * (q2 - q3) : 0.f;
+    if (fdir != 0.f && leg >= 0) {
 #pragma unroll
-      for (int d = 0; d < NDL; ++d) if (d <= dlast) (void)__hip_atomic_fetch_add(&acc[leg * NDL + d], l0 * ul[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int d = 0; d < NDL; ++d) if (d <= dlast) (void)__hip_atomic_fetch_add(&acc[leg * NDL + d], fdir * ul[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     float rsum[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rsum[i] = wave_sum(l0 * ur[i]);
+    for (int i = 0; i < 6; ++i) rsum[i] = wave_sum(fdir * ur[i]);
     if (lane < 6) {
       float v = rsum[0];
 #pragma unroll

@@ -39,6 +39,27 @@ namespace nmf {
 #endif
 #define NMF_HAS_TOPO(k) ((NMF_TOPO_MASK >> (k)) & 1)
 constexpr float kNoiseFactor = 8.f;
+// SolveReport: how the constraint solve of a step ended — one bit per kind, counted per world in stats_sum columns 4..15 (bit k ->
+// column 4 + k; include/nmf.h) and, for the launch's last step, in stats column 4 (the bits) / 5 (pivots) / 6 (KKT residual).
+// FlyLds::iters carries it: iterations | bits << 8 | most pivots of an elimination << 20.
+enum : unsigned int {
+  kExitDual = 1u << 8,         // solved in contact space (nmf_dual.h) — ended one of the five ways below:
+  kExitKkt = 1u << 9,          //   the elimination's target satisfies its own active set: exact
+  kExitTie = 1u << 10,         //   the pivot set of two eliminations ago again and what its target violates is small (1e-3 of the residuals)
+  kExitStall = 1u << 11,       //   a fourth line search without measurable descent
+  kExitCost = 1u << 12,        //   MuJoCo's improvement test / the cost's float32 rounding floor (from the sixth elimination on)
+  kExitMaxIter = 1u << 13,     //   iteration limit
+  kExitPrimal = 1u << 14,      // solved by the primal Newton loop (more contacts than the contact-space solve takes, a contact on the rest of the body, tether, general tree, fallback)
+  kExitFallback = 1u << 15,    // the contact-space solve's end failed the residual test and the step was solved again on the primal loop
+  kExitBigPivots = 1u << 16,   // an elimination had more pivots than live in registers without spilling (kDualRegPivots)
+  kExitNoNoslip = 1u << 17,    // CPU flavour: a step with contacts that could not take the noslip pass
+  kExitFree = 1u << 18,        // no contact: nothing to solve
+};
+constexpr int kExitKinds = 12;      // bits 8..19
+constexpr int kDualRegPivots = 47;
+// contact-space solves that do not end exactly: what the last target may violate, relative to the largest residual, before the step is
+// solved again on the primal loop (the tie rule's own bound)
+constexpr float kDualResidMax = 1e-3f;
 
 // Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
 // -DNMF_STAGE_PROFILE into a separate diagnostic library; the product build has no trace of it.
@@ -158,14 +179,20 @@ constexpr int conflict_free_width(int rows_per_leg, int nleg) {
 }
 template <class TP> constexpr int row_width_s() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NDL, TP::NLEG) : 6; else return 6; }
 template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) return TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6; else return 6; }
-// Leg-chain kernels solve the constraints in contact space (nmf_dual.h) while a step has at most kDualMaxCon<TP> contacts
-// (A's triangle in LDS).  Two flavours:
-//  * kDualS — stars without a rest-of-body tree (LEGS_ONLY, LEGS_ACTIVE_ONLY): factors on c_w + c_m3, A on Ib..W (the
+// Leg-chain kernels solve the constraints in contact space (nmf_dual.h) while a step has at most kDualMaxCon<TP> contacts.
+// What LDS has to hold for it is G, the Gram matrix of the contacts' DIRECTION responses (normal and two tangents: three per
+// contact, stored as one 3x3 block per unordered pair of contacts, dual_g_floats) — a pyramid row is n +- mu t, so an entry of
+// A = J M^-1 J^T is four entries of G and three multiply-adds.  Two flavours:
+//  * kDualS — stars without a rest-of-body tree (LEGS_ONLY, LEGS_ACTIVE_ONLY): factors on c_w + c_m3, G on Ib..W (the
 //    inertias live a second time in Isym), warm start blended in, previous step's active set as first guess (act_hist);
+//    16 contacts = 64 rows = the wave (G: 1224 floats; Ib..W of the 49-body skeleton: 1225);
 //  * kDualH — hybrid kernels whose leg factors fit the four solver vectors (ALL_BIOLOGICAL): no LDS to spare, so the
-//    leg factors go to vA..vD, the root's, the rows' reference accelerations and the hinge sums to c_w, A to T..W only
-//    (Ib is the one copy of the inertias), no warm-start term and no history.  Steps with a contact on the rest of the
+//    leg factors go to vA..vD, the root's, the rows' reference accelerations and the hinge sums to c_w, G to T..W only
+//    (Ib is the one copy of the inertias: 13 contacts), no warm-start term.  Steps with a contact on the rest of the
 //    body take the primal loop.
+// One kernel per skeleton and world kind whatever the batch size: a world's result does not depend on how many worlds step
+// beside it (rounds 3-4 had a second LEGS_ONLY flavour for small batches, nmf::Wide, because A's row triangle for 16 contacts
+// cost two flies per CU).
 // NMF_NO_DUAL: development switch, every step on the primal loop.
 template <class TP> constexpr bool dual_hybrid() {
   if constexpr (TP::kStar) return TP::REST_B > 0 && 4 * TP::NV >= TP::NLEG * TP::NDL * 8; else return false;
@@ -182,24 +209,26 @@ template <class TP> inline constexpr bool kDualH = dual_hybrid<TP>();
 #endif
 #endif
 template <class TP> inline constexpr bool kDual = kDualS<TP> || kDualH<TP>;
+constexpr int dual_g_floats(int ncon) { return 9 * ncon * (ncon + 1) / 2; }      // one 3x3 block per unordered pair of contacts
 template <class TP> constexpr int dual_max_con() {
-  if constexpr (kDualH<TP>) {      // the rows whose triangle fits T..W
+  if constexpr (kDualH<TP>) {      // the contacts whose blocks fit T..W
     int n = 0;
-    while (n < 12 && (4 * (n + 1)) * (4 * (n + 1) + 1) / 2 <= 2 * TP::NB * 6) ++n;
+    while (n < 16 && dual_g_floats(n + 1) <= 2 * TP::NB * 6) ++n;
     return n;
-  } else return (TP::kWide && TP::NV >= 64) ? 16 : 12;      // (16 contacts = 64 rows = the wave; their reference accelerations take 64 floats of vB)
+  } else return 16;      // 64 rows = the wave; their reference accelerations take 64 floats of vB(..vC)
 }
 template <class TP> inline constexpr int kDualMaxCon = dual_max_con<TP>();
 // LDS words of the active-set history (the contact-space solve's first guess, DevState::act_hist).  kDualS: a table by geom,
-// 16 bits per geom (4 contacts x 4 rows); kDualH (32 bytes of LDS to spare): a list, one 16-bit entry per contact of the
-// last solved step — geom (8) | ordinal within the geom (2) | active rows (4) | valid (1) — which the rows search.
-template <class TP> inline constexpr int kHistLds = kDualS<TP> ? kActHistWords : kDualH<TP> ? (kDualMaxCon<TP> + 1) / 2 : 0;
+// 16 bits per geom (4 contacts x 4 rows); kDualH (no LDS to spare: the ALL_BIOLOGICAL kernel sits exactly on 160 KB / 8): a list
+// of five words, one 16-bit entry per contact for the first ten contacts of the last solved step — geom (8) | ordinal within
+// the geom (2) | active rows (4) | valid (1) — which the rows search; later contacts start from their own sign pattern.
+template <class TP> inline constexpr int kHistLds = kDualS<TP> ? kActHistWords : kDualH<TP> ? 5 : 0;
 template <class TP, class M> __device__ __forceinline__ int hist_words(const M& m) {      // ... of them in use
   if constexpr (kDualS<TP>) return (m.ng + 1) / 2; else return kHistLds<TP>;
 }
 template <class TP> constexpr int dual_pad_floats() {
   if constexpr (kDualS<TP>) {
-    constexpr int need = (4 * kDualMaxCon<TP>) * (4 * kDualMaxCon<TP> + 1) / 2;      // A's lower triangle (nmf_dual.h)
+    constexpr int need = dual_g_floats(kDualMaxCon<TP>);      // G (nmf_dual.h)
     constexpr int have = TP::NB * 11 + 2 * TP::NB * (TP::REST_B == 0 ? conflict_free_width(TP::NBL, TP::NLEG) : 6);
     return need > have ? need - have : 0;
   } else return 0;
@@ -245,7 +274,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   // spatial inertia about the root origin: m, h, I (inertia * twist products; ABA rows via InertiaRowMap).  Rows are 11
   // floats apart where LDS allows: lane = body loops then hit 32 different banks (stride 10: bodies b and b + 16 collide)
   float Isym[kHasIsym<TP> ? TP::NB : 1][kHasIsym<TP> ? 21 : 1];   // the same as a symmetric 6x6 (upper triangle): row fetches of the star ABA
-  // (Ib, T, W are contiguous and 16-byte aligned: the contact-space solve (nmf_dual.h) keeps its per-contact response vectors there)
+  // (Ib, T, W are contiguous and 16-byte aligned: the contact-space solve (nmf_dual.h) keeps the Gram matrix of the contact directions there)
   alignas(kDualS<TP> ? 16 : 4) float Ib[TP::NB][kHasCm3<TP> ? 11 : 10];
   static_assert(6 * TP::NV >= 9 * (TP::NB - 1), "rotation matrices do not fit the solver vectors");
   static_assert(7 * kMaxCon >= 3 * (TP::NB - 1), "body positions do not fit the contact wrenches");
@@ -298,7 +327,9 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   }
   // the constraint solver's second warm start (DevState::act_hist), carried from step to step: 16 bits per geom
   unsigned int act_hist[kHistLds<TP>];
-  int ncon, overflow, iters;
+  int ncon, overflow;
+  int iters;                            // SolveReport: Newton iterations | how the solve ended << 8 | pivots << 20
+  float solve_resid;                    // ... and what its last elimination's target violates (nmf_dual.h)
   int nwall;                            // contacts of this step that touch a terrain side face (frame id != 0)
   // LDS vectors addressed by id: non-inlined functions take ids, not pointers, so that every access stays a
   // ds_* instruction (a float* argument would be a generic pointer -> flat_load / flat_store)
@@ -1806,7 +1837,7 @@ struct CtrlPrefetch {
 
 // ------------------------------------------------------------------ the step
 template <class TP, bool WELD>
-__device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, CtrlPrefetch& pf STAGE_ARG) {
+__device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, float* rec, CtrlPrefetch& pf STAGE_ARG) {
   // hybrid kernels: per-lane addresses are rebuilt every step instead of living across the item loop — hoisted, they left
   // the 132-dof kernel 19 spilled registers and a dozen scratch reloads per step (the 72-dof kernels have the registers to
   // keep them: recomputing costs those 2 %)
@@ -1980,6 +2011,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       s.vA[j] += f;
     }
     if (last) st.actuator_force[(size_t)w * m.nu + opaque(u)] = f;     // pure output: only the launch's last step stores it
+    if (rec && u < st.ring_nact) rec[2 * st.ring_nj + opaque(u)] = f;  // ... and the steps an observation ring records
   }
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) {
@@ -1998,6 +2030,8 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // ---- constraint solve (Newton, exact line search) — mirrors oracle solve_constraints()
   int iters = 0;
   bool solved = false;
+  unsigned int report = 0u;      // SolveReport bits
+  float resid = 0.f;
   if constexpr (kDual<TP> && !WELD) {
     if (dual) {
       if (c.on) {      // reference accelerations of the rows: lane = row from here on
@@ -2005,13 +2039,21 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         for (int k = 0; k < 4; k++) dual_aref(s)[4 * lane + k] = c.aref[k];
       }
       WSYNC();
-      iters = dual_solve<TP, kDualMaxCon<TP>>(s, m, lane, ncon, walls STAGE_PASS);
-      solved = true;
+      iters = dual_solve<TP, kDualMaxCon<TP>>(s, m, lane, ncon, walls, report, resid STAGE_PASS);
+      solved = iters >= 0;       // (-1: rejected, the primal loop below solves the step)
+      if (!solved) {             // the rows' reference accelerations come back from where the solve read them
+        iters = 0; contact_reload(c, s, lane);
+        if (c.on) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) c.aref[k] = dual_aref(s)[4 * lane + k];
+        }
+      }
     }
   }
   if constexpr (kDual<TP>) { if (!solved && lane < kHistLds<TP>) s.act_hist[lane] = 0u; }      // nothing known for the next step
-  // a step the contact-space solve cannot take has no noslip pass: flagged with the overflow counter, never silent
-  if (m.noslip_iter > 0 && !solved && ncon > 0 && lane == 0) s.overflow = 1;
+  // a step the contact-space solve cannot take has no noslip pass: counted (stats_sum column 13), never silent
+  if (m.noslip_iter > 0 && !solved && ncon > 0) report |= kExitNoNoslip;
+  if (!solved) report |= (ncon == 0 && !WELD) ? kExitFree : kExitPrimal;
   if (solved) {
   } else if (ncon == 0 && !WELD) {
     for (int j = lane; j < s.nv(); j += kWave) { s.qacc[j] = s.qacc_smooth[j]; s.vD[j] = 0.f; }
@@ -2224,15 +2266,20 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       }
     } }
   }
-  if (lane == 0) s.iters = iters;
+  if (lane == 0) { s.iters = (int)((unsigned int)iters | report); s.solve_resid = resid; }
   STAGE(14);
 
-  // ---- contact sensors (oracle contact_sensors): a pure output, evaluated on the launch's last step only and
-  // written straight to HBM.  c_w holds the world-frame contact wrenches about the root origin.
+  // ---- contact sensors (oracle contact_sensors): a pure output, evaluated on the launch's last step (into the batch's arrays)
+  // and on the steps an observation ring records (into the ring's row), written straight to HBM.  c_w holds the world-frame
+  // contact wrenches about the root origin.
   if (last) {
     const int ol = opaque(lane);
     if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + ol] = c.on ? (float)info_geom(c.info) : -1.f;
-    float* out = &st.sensordata[(size_t)w * 96];
+  }
+  for (int dest = 0; dest < 2; ++dest) {
+    float* out = dest == 0 ? (last ? &st.sensordata[(size_t)w * 96] : nullptr) : (rec ? rec + 2 * st.ring_nj + st.ring_nact : nullptr);
+    if (!out) continue;
+    const int ol = opaque(lane);
     for (int i = ol; i < 96; i += kWave) out[i] = 0.f;
     WSYNC();
     if (m.nsensor && lane < 6 && ncon > 0) {
@@ -2379,8 +2426,9 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
   }
   if (lane == 0) st_state(&st.time[opaque(w)], time);      // (opaque: the address is not kept in a register pair from the item's start)
   if (lane == 0 && final) {
-    st.stats[4 * w] = (float)s.ncon; st.stats[4 * w + 1] = (float)s.iters; st.stats[4 * w + 2] = (float)s.overflow;
-    st.stats[4 * w + 3] = (float)(4 * s.ncon);
+    float* q = &st.stats[8 * (size_t)w];
+    q[0] = (float)s.ncon; q[1] = (float)(s.iters & 0xff); q[2] = (float)s.overflow; q[3] = (float)(4 * s.ncon);
+    q[4] = (float)((s.iters >> 8) & 0xfff); q[5] = (float)((s.iters >> 20) & 0x7f); q[6] = s.solve_resid; q[7] = 0.f;
   }
 }
 
@@ -2492,12 +2540,12 @@ __global__ void __launch_bounds__(kWave) nmf_reset_kernel(const DevModel* __rest
   for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
   for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
   for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
-  if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; }
+  if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; s.solve_resid = 0.f; }
   WSYNC();
   stage_kinematics(s, m, lane);
   write_poses(s, m, st, w, lane);
   write_outputs(s, m, st, w, lane, 0.f, true);
-  if (lane < 4) st.stats_sum[4 * (size_t)w + lane] = 0u;
+  if (lane < 16) st.stats_sum[16 * (size_t)w + lane] = 0u;
   if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = 0u;
   if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + lane] = -1.f;
 }
@@ -2554,6 +2602,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
     float time;
     unsigned int carry = 0u; // lanes 1..4: what the world's earlier items of this launch accumulated (steps, contacts, iterations, overflow steps); lane 5: their cycles (float bits)
     unsigned int sum_con = 0u, sum_it = 0u, sum_of = 0u;     // running sums over the steps of this item (wave-uniform)
+    unsigned int sum_dual = 0u, sum_kkt = 0u;                // ... steps solved in contact space / ended on the KKT test (scalar registers)
     {
       // control table: lane a < 64 carries column a; the row of step s + 1 is requested while step s runs, so its
       // HBM latency (~1.5 k cycles per step when loaded on demand) is off the step's critical path; the item's first
@@ -2601,11 +2650,30 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
           WSYNC();
         }
         STAGE(0);
-        const bool wrenches = physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, pf STAGE_PASS);     // pure outputs: the launch's last step only
+        // an observation ring records this step: its row (wave-uniform address)
+        float* rec = nullptr;
+        if (st.obs_every > 0 && (step + 1) % st.obs_every == 0)
+          rec = st.ring + ((size_t)((step + 1) / st.obs_every - 1) * (size_t)st.n_worlds + (size_t)w) * (size_t)st.ring_stride;
+        const bool wrenches = physics_forward<TP, WELD>(s, m, lane, st, w, step == n_steps - 1, rec, pf STAGE_PASS);     // pure outputs: the launch's last step and the recorded ones
         physics_integrate<TP, WELD>(s, m, lane, wrenches STAGE_PASS);
+        if (rec) {       // the state after the step, as nmf_pack_observations reads it after a launch
+          const int nj = st.ring_nj;
+          for (int i = opaque(lane); i < nj; i += kWave) { rec[i] = s.qpos[7 + i]; rec[nj + i] = s.qvel[6 + i]; }
+        }
         STAGE(15);
         time += m.timestep;
-        sum_con += (unsigned int)s.ncon; sum_it += (unsigned int)s.iters; sum_of += (unsigned int)s.overflow;
+        // how the step's solve ended.  The two common kinds (solved in contact space, ended on the KKT test) are counted in scalar
+        // registers and added once per item; any other bit of the report — one step in ten thousand — goes straight to the world's
+        // counter from lane 6 + k, an atomic the wave does not wait for
+        const unsigned int rep = (unsigned int)__builtin_amdgcn_readfirstlane(s.iters);
+        sum_con += (unsigned int)s.ncon; sum_it += rep & 0xffu; sum_of += (unsigned int)s.overflow;
+        sum_dual += (rep >> 8) & 1u; sum_kkt += (rep >> 9) & 1u;
+#ifndef NMF_NO_EXIT_COUNT
+        if (rep & (0xffcu << 8)) {
+          const int xl = opaque(lane) - 6;
+          if (xl >= 2 && xl < kExitKinds && ((rep >> (8 + xl)) & 1u)) add_count(&st.stats_sum[16 * (size_t)w + 4 + xl], 1u);
+        }
+#endif
       }
     }
     TRACE_BUSY_END();
@@ -2627,9 +2695,10 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
       if (lane >= 1 && lane <= 4) carry += own;
       if (lane == 5) carry = __float_as_uint(__uint_as_float(carry) + cyc);
       const bool final = step1 == n_steps;
+      if (lane == 6 || lane == 7) add_count(&st.stats_sum[16 * (size_t)w + opaque(lane) - 2], lane == 6 ? sum_dual : sum_kkt);      // (every item adds its own)
       write_outputs(s, m, st, w, lane, time, final, epoch * 32u + (unsigned int)(chunk + 1), carry);
       if (final) {
-        if (lane >= 1 && lane <= 4) add_count(&st.stats_sum[4 * (size_t)w + opaque(lane) - 1], carry);
+        if (lane >= 1 && lane <= 4) add_count(&st.stats_sum[16 * (size_t)w + opaque(lane) - 1], carry);
         if (lane == 5) st_state(&st.cost[w], __uint_as_float(carry));     // the world's cycles over the whole launch
       }
       if (st.sched && lane == 0) atomicMax(&st.sched->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());

@@ -38,15 +38,20 @@ class HIPSimulation:
         max_constraints: accepted for signature compatibility (four pyramid rows per kept contact + the tether's six).
         strict_contacts: raise at construction if the model can make more contacts than the engine keeps.
         device: CUDA/HIP device index (one process per GPU for multi-GPU runs).
+        _options: development switches of ``nmf_batch_create_ex`` (``include/nmf.h``; keywords of
+            :meth:`flygym_amd._native.BatchOptions.make`: ``solver`` "primal" / "nohist" / "nofallback", ``sched`` "plain",
+            ``order``, ``max_chunks``, ...).  What a batch runs is reported by :meth:`batch_info`.
     """
 
     def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
                  max_contacts: int = 500, device: int | None = None, strict_contacts: bool = False,
-                 _cpu_flavour: bool = False) -> None:
+                 _cpu_flavour: bool = False, _options: dict | None = None) -> None:
         import torch
 
         if len(world.fly_lookup) == 0:
             raise ValueError("The world must contain at least one fly.")
+        if int(max_contacts) < 1:
+            raise ValueError(f"max_contacts must be at least 1, got {max_contacts}")
         if not (_cpu_flavour and self._noslip_supported(world)):      # (flygym_amd.Simulation keeps the CPU class's noslip pass)
             self._strip_unsupported_options(world)
         self.world = world
@@ -68,12 +73,11 @@ class HIPSimulation:
         self._model_h = self._lib.nmf_model_create(blob, len(blob))
         if not self._model_h:
             raise _native.NativeError(self._lib.nmf_last_error().decode())
+        opts = _native.BatchOptions.make(**(_options or {}))
         with torch.cuda.device(self.device):
-            self._batch_h = self._lib.nmf_batch_create(self._model_h, self.n_worlds, self.device_index)
+            self._batch_h = self._lib.nmf_batch_create_ex(self._model_h, self.n_worlds, self.device_index, ctypes.byref(opts))
         if not self._batch_h:
             raise _native.NativeError(self._lib.nmf_last_error().decode())
-        if int(max_contacts) < 1:
-            raise ValueError(f"max_contacts must be at least 1, got {max_contacts}")
         self.contact_bound = _native.check_count(self._lib.nmf_model_contact_bound(self._model_h))
         self.contact_capacity = _native.check_count(self._lib.nmf_batch_set_contact_capacity(self._batch_h, int(max_contacts)))
         if strict_contacts and self.contact_bound > self.contact_capacity:
@@ -211,12 +215,35 @@ class HIPSimulation:
         m = (m != 0).to(t.uint8).contiguous()
         _native.check(self._lib.nmf_reset_worlds(self._batch_h, m.data_ptr(), self._stream()))
 
-    def step(self, n_steps: int = 1) -> None:
-        """Advance all worlds by one timestep (``n_steps`` > 1 fuses several into one launch)."""
-        _native.check(self._lib.nmf_step(self._batch_h, int(n_steps), self._stream()))
+    def step(self, n_steps: int = 1, record_every: int | None = None, n_act: int = 42):
+        """Advance all worlds by one timestep (``n_steps`` > 1 fuses several into one launch).
 
-    def step_replay(self, table, act_ids, start: int, n_steps: int) -> None:
+        ``record_every=k``: the launch also records the observation block of every k-th step — what the reference's loops read
+        after every ``step()`` (``get_joint_angles`` / ``get_joint_velocities`` / ``get_actuator_forces`` /
+        ``get_ground_contact_info``, reference ``simulation.py:142-243``) — and returns it as a float32 tensor
+        ``(n_steps // k, n_worlds, 2 nj + n_act + 96)`` in the layout of :meth:`pack_observations`; row ``i`` is bit for bit what
+        ``pack_observations`` gives after step ``(i + 1) k`` (``nmf_step_record``)."""
+        if record_every is None:
+            _native.check(self._lib.nmf_step(self._batch_h, int(n_steps), self._stream()))
+            return None
+        return self._record(None, None, 0, n_steps, record_every, n_act)
+
+    def _record(self, table, act_ids, start, n_steps, record_every, n_act):
+        t = self._torch
+        k = int(record_every)
+        if k < 1 or int(n_steps) < k:
+            raise ValueError(f"record_every must be in 1..n_steps, got {record_every} for {n_steps} steps")
+        nj = self.model.nv - 6
+        width = 2 * nj + int(n_act) + 96
+        ring = t.empty((int(n_steps) // k, self.n_worlds, width), dtype=t.float32, device=self.device)
+        tab = (table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr()) if table is not None else (None, 0, 0, None)
+        _native.check(self._lib.nmf_step_record(self._batch_h, tab[0], tab[1], tab[2], tab[3], int(start), int(n_steps), k, nj, int(n_act),
+                                                ring.data_ptr(), width, self._stream()))
+        return ring
+
+    def step_replay(self, table, act_ids, start: int, n_steps: int, record_every: int | None = None, n_act: int = 42):
         """Device-resident replay loop: before step ``s`` load ``ctrl[:, act_ids] = table[:, start+s]``.
+        ``record_every``: as in :meth:`step` (returns the observation ring).
 
         ``table``: float32 ``(n_worlds, table_steps, n_act)`` and ``act_ids``: int32 ``(n_act,)`` engine control ids
         (:meth:`replay_ids`), both contiguous on this simulation's device — the kernel reads them through raw pointers,
@@ -233,9 +260,12 @@ class HIPSimulation:
                              f"but got {tuple(table.shape)} and {tuple(act_ids.shape)}")
         if not (table.is_contiguous() and act_ids.is_contiguous()):
             raise ValueError("step_replay needs contiguous tensors")
+        if record_every is not None:
+            return self._record(table, act_ids, start, n_steps, record_every, n_act)
         _native.check(self._lib.nmf_step_replay(
             self._batch_h, table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr(),
             int(start), int(n_steps), self._stream()))
+        return None
 
     def replay_ids(self, fly_name: str, with_adhesion: bool = False):
         """Engine control ids (device int32) of the columns of a replay / CPG target table: the fly's position actuators
@@ -330,8 +360,27 @@ class HIPSimulation:
         return sd[:, :, 0], sd[:, :, 1:4], sd[:, :, 4:7], sd[:, :, 7:10], sd[:, :, 10:13], sd[:, :, 13:16]
 
     def get_solver_stats(self):
-        """``(n_worlds, 4)``: contacts, Newton iterations, contact-overflow flag, constraint rows."""
+        """``(n_worlds, 8)`` of the last step: contacts, Newton iterations, contact-overflow flag, constraint rows, solve-report
+        bits, most pivots of an elimination, KKT residual of the last elimination's target, 0 (``NMF_STATS``)."""
         return self.field("stats").clone()
+
+    SOLVER_EXIT_NAMES = ("contact_space", "kkt_exact", "tie_rule", "stalled_line_search", "cost_tests", "iteration_limit",
+                         "primal_loop", "fallback_resolves", "big_eliminations", "noslip_skipped", "no_contact")
+
+    def get_solver_exits(self) -> dict:
+        """How the constraint solves of all steps since the last reset ended, summed over the worlds (``NMF_STATS_SUM`` columns
+        4..14; synchronises): ``steps`` and one count per kind."""
+        tot = self.field("stats_sum").to(self._torch.int64).sum(dim=0).cpu().tolist()
+        out = {"steps": int(tot[0])}
+        out.update({k: int(tot[4 + i]) for i, k in enumerate(self.SOLVER_EXIT_NAMES)})
+        return out
+
+    def batch_info(self) -> dict:
+        """What this batch runs (``nmf_batch_info``): kernel family, contact-space flavour and the contacts it takes, flies per
+        CU, chunk plan, world-order policy, solver option bits, kernel LDS / VGPRs."""
+        out = (ctypes.c_int32 * 16)()
+        _native.check(self._lib.nmf_batch_info(self._batch_h, out))
+        return dict(zip(_native.INFO_KEYS, [int(v) for v in out]))
 
     def overflow_steps(self) -> int:
         """Steps since the last reset, summed over the worlds, in which a world made more contacts than

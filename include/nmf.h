@@ -37,14 +37,21 @@ enum nmf_field {
   NMF_ACTUATOR_FORCE = 7, /* [nu]                                                              */
   NMF_SENSORDATA = 8,   /* [96]      6 legs x (found, force3, torque3, pos3, normal3, tangent3)*/
   NMF_TIME = 9,         /* [1]                                                                 */
-  NMF_STATS = 10,       /* [4]       ncon, solver iterations, overflow flag, nefc (as floats)  */
+  NMF_STATS = 10,       /* [8]       of the launch's last step, as floats: ncon, solver iterations, overflow flag, nefc, solve-report
+                                    bits (bit k = column 4 + k of NMF_STATS_SUM), most pivots of an elimination, KKT residual of
+                                    the last elimination's target (0 = exact end; contact-space solve only), 0                */
   NMF_QACC = 11,        /* [nv]                                                                */
   NMF_COST = 12,        /* [1]       shader cycles the world took in the last stepping launch (load metric) */
-  NMF_STATS_SUM = 13,   /* [4]       since the last reset: physics steps, sum of ncon, sum of solver iterations, steps with
-                                    contact overflow (means over any window = differences of two reads).  The four
-                                    words are uint32_t COUNTERS (read them through a uint32_t / int32_t view of the
-                                    pointer nmf_field_ptr returns): exact up to 4.29e9, i.e. ~7e8 steps of one world at
-                                    6 contacts per step between two resets                                           */
+  NMF_STATS_SUM = 13,   /* [16]      since the last reset, uint32_t COUNTERS (read them through a uint32_t / int32_t view of the
+                                    pointer nmf_field_ptr returns; means over any window = differences of two reads; exact up to
+                                    4.29e9, i.e. ~7e8 steps of one world at 6 contacts per step between two resets):
+                                    0 physics steps, 1 sum of ncon, 2 sum of solver iterations, 3 steps with contact overflow;
+                                    how the steps' constraint solves ended — 4 solved in contact space, of which 5 exactly (the
+                                    elimination's target satisfies its own active set: KKT), 6 by the tie rule, 7 after a fourth
+                                    line search without measurable descent, 8 by the cost tests, 9 at the iteration limit;
+                                    10 solved by the primal Newton loop, of which 11 after a contact-space solve whose end failed
+                                    the residual test; 12 steps with an elimination of more than 47 pivots; 13 steps with contacts
+                                    that could not take the CPU flavour's noslip pass; 14 steps without contact; 15 unused    */
   NMF_CONTACT_GEOM = 14, /* [48]     contact list of the launch's last step: index (into the world's contact-geom list,
                                     reference compose/world.py:300-309 pair order sorted by body) of the geom of contact
                                     c, as a float; -1 beyond ncon                                                    */
@@ -73,6 +80,38 @@ nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device);
 void nmf_batch_destroy(nmf_batch* batch);
 int nmf_batch_n_worlds(const nmf_batch* batch);
 
+/* The same with explicit options (NULL = defaults = nmf_batch_create).  Every field: 0 = the library's default.  These are the
+ * switches the tests and A/B measurements use; none changes WHAT is computed beyond solver tolerance (`solver`) — `sched`,
+ * `order`, `max_chunks`, `chunk_div`, `min_chunk_steps`, `order_every` never change a result (worlds are independent).
+ * The library reads NO environment variable unless NMF_ALLOW_ENV=1 is set in the process environment (development: the
+ * NMF_SOLVER / NMF_SCHED / NMF_ORDER / NMF_MAX_CHUNKS / NMF_CHUNK_DIV / NMF_MIN_CHUNK_STEPS / NMF_ORDER_EVERY /
+ * NMF_DISABLE_REST_FAST variables then override these options); what a batch actually runs is reported by nmf_batch_info. */
+typedef struct nmf_batch_options {
+  int32_t struct_size;      /* sizeof(nmf_batch_options) as the caller was compiled                                            */
+  int32_t solver;           /* bit 0: every step on the primal Newton loop; bit 1: the contact-space solve starts from the start
+                               point's own sign pattern, not from the previous step's active set; bit 2: its ends are never
+                               re-solved on the primal loop (no residual test)                                                 */
+  int32_t sched;            /* 1: whole-launch work items (no chunks)                                                          */
+  int32_t order;            /* world order of over-subscribed launches: 1 in index order (order kernel), 2 costliest first,
+                               3 none (no order kernel), 4 the measured policy of rounds 1-2                                    */
+  int32_t max_chunks;       /* 1..16                                                                                           */
+  int32_t min_chunk_steps;  /* >= 1                                                                                            */
+  int32_t order_every;      /* costliest-first order recomputed every n-th launch                                              */
+  int32_t rest_slow;        /* 1: hybrid kernels use the table-driven level passes of the rest of the body                     */
+  float chunk_div;          /* each chunk takes 1 / chunk_div of the steps that are left (> 1)                                 */
+} nmf_batch_options;
+nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, int device, const nmf_batch_options* options);
+
+/* What the batch runs — so that a result can always be traced to the code that made it:
+ * out[0] kernel family (0 LEGS_ONLY star, 1 LEGS_ACTIVE_ONLY star, 2 / 3 general tree 144 / 216 dofs, 4 ALL_BIOLOGICAL hybrid,
+ * 5 ALL_POSSIBLE hybrid), out[1] terrain kernel, out[2] tether (weld) kernel, out[3] contact-space solve (0 none: primal loop
+ * only, 1 star flavour, 2 hybrid flavour), out[4] contacts it takes (steps with more go to the primal loop), out[5] flies
+ * (workgroups) per CU, out[6] resident workgroups of the device, out[7] chunked launches (0 / 1), out[8] max chunks,
+ * out[9] 1000 * chunk_div, out[10] world-order policy (0 in order, 1 costliest first, 2 none, 3 auto, -1 measured), out[11]
+ * solver option bits in effect, out[12] noslip iterations, out[13] contact capacity, out[14] LDS bytes / out[15] vector
+ * registers of the stepping kernel (from the loaded code object). */
+int nmf_batch_info(const nmf_batch* batch, int32_t out[16]);
+
 /* Contacts kept per world and step: min(max_contacts, 48); returns the capacity in effect (negative on error).  Contacts
  * beyond it, in geom order, are dropped and the step counts as overflowed (stats column 2, nmf_stats overflow steps).
  * Call between launches (synchronous).  Replaces: the nconmax of mjw.put_data  (warp/simulation.py:50-56, 418-424). */
@@ -96,6 +135,18 @@ int nmf_step(nmf_batch* batch, int n_steps, void* stream);
  * update_target_angles_kernel + set_actuator_inputs + step + increment_counter, graph-captured). */
 int nmf_step_replay(nmf_batch* batch, const float* table_dev, int table_steps, int n_act,
                     const int32_t* act_ids_dev, int start, int n_steps, void* stream);
+
+/* The same launch (table_dev NULL: nmf_step, controls held; else nmf_step_replay with n_act_table columns) that also RECORDS the
+ * observation block after every obs_every-th step — what the reference's loops read after every step (get_joint_angles /
+ * get_joint_velocities / get_actuator_forces / get_ground_contact_info, src/flygym/simulation.py:142-243; MJWarp computes its
+ * sensors every step, warp/simulation.py:260-263), without leaving the kernel:
+ *   ring[(s + 1) / obs_every - 1][w][0 .. 2 n_joint + n_act + 96) for every step s (0-based) with (s + 1) % obs_every == 0,
+ * in the layout of nmf_pack_observations — [joint angles | joint velocities | forces of the first n_act actuators | the 96
+ * contact-sensor floats] — and with its values: each row is bit for bit what nmf_pack_observations gives when the launch ends at
+ * that step.  ring_dev: float32 [n_steps / obs_every][n_worlds][row_stride].  The contact sensors and actuator forces are
+ * evaluated on the recorded steps (and, as always, on the launch's last step for the batch's own arrays). */
+int nmf_step_record(nmf_batch* batch, const float* table_dev, int table_steps, int n_act_table, const int32_t* act_ids_dev, int start,
+                    int n_steps, int obs_every, int n_joint, int n_act, float* ring_dev, int row_stride, void* stream);
 
 /* Device pointer + row width of a per-world field (zero-copy views for PyTorch). */
 float* nmf_field_ptr(nmf_batch* batch, int field, int32_t* width);

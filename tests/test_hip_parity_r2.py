@@ -380,8 +380,9 @@ def test_adhesion_through_the_adhesion_segments_geom(torch_mod, oracle_lib, mode
 
 
 def test_stats_sum_and_step_replay_validation(torch_mod, bench_model):
-    """NMF_STATS_SUM accumulates (steps, contacts, solver iterations, overflow steps) over every step of every launch;
-    step_replay refuses tables it could only read as garbage."""
+    """NMF_STATS_SUM accumulates (steps, contacts, solver iterations, overflow steps, and one counter per bit of the solve
+    report: how each step's constraint solve ended) over every step of every launch; step_replay refuses tables it could only
+    read as garbage."""
     torch = torch_mod
     from flygym_amd import HIPSimulation
 
@@ -392,16 +393,21 @@ def test_stats_sum_and_step_replay_validation(torch_mod, bench_model):
     for s in (a, b):
         s.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
     a.step(400)
-    acc = torch.zeros((n, 4), device=a.device)
+    acc = torch.zeros((n, 16), device=a.device)
     for _ in range(400):
         b.step(1)
         st = b.field("stats")
         acc[:, 0] += 1; acc[:, 1] += st[:, 0]; acc[:, 2] += st[:, 1]; acc[:, 3] += st[:, 2]
+        bits = st[:, 4].int()
+        for k in range(12):
+            acc[:, 4 + k] += ((bits >> k) & 1).float()
     torch.cuda.synchronize()
     assert torch.equal(a.field("qpos"), b.field("qpos"))
     assert a.field("stats_sum").dtype == torch.int32                 # uint32 counters behind the field pointer
     assert torch.equal(a.field("stats_sum").float(), acc) and torch.equal(b.field("stats_sum").float(), acc)
     assert float(acc[:, 1].min()) > 100          # landed within the 400 steps
+    # every step ended exactly one way: in contact space, on the primal loop, or without a contact; a contact-space solve one of five
+    assert torch.equal(acc[:, 4] + acc[:, 10] + acc[:, 14], acc[:, 0]) and torch.equal(acc[:, 5:10].sum(dim=1), acc[:, 4])
     a.reset()
     assert float(a.field("stats_sum").abs().max()) == 0.0 and bool((a.field("contact_geom") == -1).all())
     ids = a.replay_ids(fly.name)

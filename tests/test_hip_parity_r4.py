@@ -1,6 +1,5 @@
 """Round 4: the contact-space constraint solve (csrc/nmf_dual.h) against the primal Newton loop and the oracle, and the
 collision fix it exposed.  GPU tests, through the C ABI."""
-import os
 from pathlib import Path
 
 import numpy as np
@@ -24,14 +23,7 @@ def _walkers(n, solver, torch, preset="legs_only"):
     from flygym_amd.controllers import TripodCPG
 
     fly, world, _ = make_model(joints_preset=preset)
-    old = os.environ.get("NMF_SOLVER")
-    if solver: os.environ["NMF_SOLVER"] = solver
-    else: os.environ.pop("NMF_SOLVER", None)
-    try:
-        sim = HIPSimulation(world, n_worlds=n, device=0)          # the switch is read when the batch is created
-    finally:
-        if old is None: os.environ.pop("NMF_SOLVER", None)
-        else: os.environ["NMF_SOLVER"] = old
+    sim = HIPSimulation(world, n_worlds=n, device=0, _options=dict(solver=solver))          # an explicit create option (nmf_batch_create_ex)
     table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(n, 2500, device=sim.device)
     ids = sim.replay_ids(fly.name)
     sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
@@ -285,14 +277,7 @@ def test_a_tie_row_does_not_send_the_solve_into_the_noise(torch_mod, oracle_lib,
         fly = make_model()[0]
         world = C.MixedTerrainWorld()
         world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
-        old = os.environ.get("NMF_SOLVER")
-        if solver: os.environ["NMF_SOLVER"] = solver
-        else: os.environ.pop("NMF_SOLVER", None)
-        try:
-            sim = HIPSimulation(world, n_worlds=2, device=0)
-        finally:
-            if old is None: os.environ.pop("NMF_SOLVER", None)
-            else: os.environ["NMF_SOLVER"] = old
+        sim = HIPSimulation(world, n_worlds=2, device=0, _options=dict(solver=solver))
         ids = sim.replay_ids(fly.name, with_adhesion=True)
         rows = torch.as_tensor(d["rows"], device=sim.device)[None].repeat(2, 1, 1).contiguous()
         for k in keys: sim.field(k)[:] = torch.as_tensor(d[k], device=sim.device)[None, :]

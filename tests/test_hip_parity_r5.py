@@ -1,0 +1,182 @@
+"""Round 5: one contact-space solve for every walking step and every batch size (the Gram matrix of the contact DIRECTIONS,
+csrc/nmf_dual.h), the solver's exit accounting, the per-step observation ring.  GPU tests, through the C ABI."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+def _world(kind):
+    import flygym_amd.compose as C
+    from flygym_amd import make_model
+    from flygym_amd.utils.math import Rotation3D
+
+    if kind in ("legs_only", "legs_active_only", "all_biological"):
+        fly, world, _ = make_model(joints_preset=kind)
+        return fly, world
+    fly = make_model(joints_preset="legs_only")[0]
+    world = getattr(C, {"blocks": "BlocksTerrainWorld", "mixed": "MixedTerrainWorld"}[kind])()
+    world.add_fly(fly, (0.3, 0.2, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    return fly, world
+
+
+STATE = ("qpos", "qvel", "qacc_warmstart", "ctrl", "time", "stats_sum", "stats", "sensordata", "seg_xpos", "contact_geom",
+         "actuator_force", "qacc")
+
+
+@pytest.mark.parametrize("kind", ["legs_only", "legs_active_only", "all_biological", "blocks"])
+def test_a_world_does_not_depend_on_the_size_of_its_batch(torch_mod, kind):
+    """Worlds 0..511 of a 4096-world batch against the same 512 worlds stepped as a batch of their own — and as a batch of 64:
+    every state array, the clock, the statistics and the outputs bit for bit after a settle and 600 steps of CPG walking in
+    launches of three lengths.  (Rounds 3-4 chose between two LEGS_ONLY kernel flavours by batch size — 12 or 16 contacts in the
+    contact-space solve — and a sharded run agreed with the single-GPU run only to solver tolerance.  One kernel per skeleton
+    now: the schedule, the residency and the shard plan never change a result.)"""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world = _world(kind)
+    big_n = 4096
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(big_n, 1250, device="cuda:0")
+
+    def run(n):
+        sim = HIPSimulation(world, n_worlds=n, device=0)
+        ids = sim.replay_ids(fly.name)
+        sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+        tab = table[:n].contiguous()
+        sim.step(500)
+        cur = 0
+        for length, count in ((50, 8), (20, 9), (1, 20)):
+            for _ in range(count):
+                sim.step_replay(tab, ids, cur, length); cur += length
+        torch.cuda.synchronize()
+        return {k: sim.field(k).clone() for k in STATE}
+
+    big = run(big_n)
+    assert bool(torch.isfinite(big["qpos"]).all())
+    assert float(big["stats_sum"][:, 1].float().mean()) / 1100 > 3.0          # the flies stand and walk (contacts per step)
+    for n in (512, 64):
+        small = run(n)
+        for k in STATE:
+            assert torch.equal(small[k], big[k][:n]), f"{kind}: worlds 0..{n - 1} of a {big_n}-batch differ from a {n}-batch in {k}"
+
+
+def test_observation_ring_rows_are_the_per_step_reads(torch_mod):
+    """``nmf_step_record``: one fused launch of 40 steps that records the observation block of every step (and of every 5th)
+    against 40 one-step launches each followed by ``pack_observations`` and the getters — what the reference's loops do after
+    every ``step()`` (reference simulation.py:142-243).  Bit for bit, including the contact sensors and the actuator forces,
+    which the kernel otherwise evaluates on a launch's last step only; the final state is the same too."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.compose.fly import ActuatorType
+    from flygym_amd.controllers import TripodCPG
+
+    fly, world, _ = make_model()
+    n = 4096
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(n, 1250, device="cuda:0")
+    sims = [HIPSimulation(world, n_worlds=n, device=0) for _ in range(3)]
+    ids = sims[0].replay_ids(fly.name)
+    for sim in sims:
+        sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+        sim.step(500); sim.step_replay(table, ids, 0, 300)
+    a, b, c = sims
+    ring = a.step_replay(table, ids, 300, 40, record_every=1)
+    ring5 = c.step_replay(table, ids, 300, 40, record_every=5)
+    assert tuple(ring.shape) == (40, n, 270) and tuple(ring5.shape) == (8, n, 270)
+    row = torch.empty((n, 270), device=b.device)
+    touched = 0
+    for s in range(40):
+        b.step_replay(table, ids, 300 + s, 1)
+        b.pack_observations(row)
+        assert torch.equal(ring[s], row), f"ring row {s} differs from the per-step read"
+        if s % 5 == 4:
+            assert torch.equal(ring5[s // 5], row)
+        if s == 17:       # the getters of the reference surface read the same numbers
+            assert torch.equal(ring[s][:, :66], b.get_joint_angles(fly.name)) and torch.equal(ring[s][:, 66:132], b.get_joint_velocities(fly.name))
+            assert torch.equal(ring[s][:, 132:174], b.get_actuator_forces(fly.name, ActuatorType.POSITION))
+            act = b.get_ground_contact_info(fly.name)[0]
+            assert torch.equal(ring[s][:, 174:].reshape(n, 6, 16)[:, :, 0], act)
+        touched += int((row[:, 174::16] > 0).sum().item())
+    assert touched > 40 * n          # legs on the ground in every step: the sensor block is not a block of zeros
+    torch.cuda.synchronize()
+    for k in STATE:
+        assert torch.equal(a.field(k), b.field(k)) and torch.equal(c.field(k), b.field(k)), k
+    with pytest.raises(ValueError):
+        a.step(3, record_every=5)
+
+
+WORKLOADS = {"config2": ("legs_only", "flat", 1.0), "config4_blocks": ("legs_only", "blocks", 1.0), "config5_mixed_adhesion": ("legs_only", "mixed", 20.0)}
+
+
+@pytest.mark.parametrize("name", list(WORKLOADS))
+def test_how_the_solves_end(torch_mod, name):
+    """2 000 steps x 4096 worlds of BASELINE configs 2 / 4 / 5 with the solver's exit accounting on (``NMF_STATS_SUM`` columns
+    4..14): every step ends exactly one way; at least 99.9 % of the contact-space solves end on the exact KKT test; whatever
+    ends otherwise passed the residual test (what the last elimination's target violates is at most 1e-3 of the rows' residuals)
+    or was solved again on the primal loop and counted; no step is left unsolved (finite state, no iteration limit)."""
+    torch = torch_mod
+    import flygym_amd.compose as C
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+
+    preset, terrain, adhesion = WORKLOADS[name]
+    fly = make_model(joints_preset=preset)[0]
+    world = {"flat": C.FlatGroundWorld, "blocks": C.BlocksTerrainWorld, "mixed": C.MixedTerrainWorld}[terrain]()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    n = 4096
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
+    sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+    if adhesion > 1.0:       # adhesion driven by the gait: `adhesion` while a leg's phase is a stance phase, else 1 (bench.py --cpg-adhesion)
+        table = cpg.targets(n, 1250, device="cuda:0", adhesion=(cpg.stance_bins(sim.model, fly), adhesion, 1.0))
+        ids = sim.replay_ids(fly.name, with_adhesion=True)
+    else:
+        table = cpg.targets(n, 1250, device="cuda:0")
+        ids = sim.replay_ids(fly.name)
+    sim.step(500)
+    s0 = sim.field("stats_sum").clone()
+    cur = 0
+    for _ in range(40):
+        sim.step_replay(table, ids, cur, 50); cur += 50
+    torch.cuda.synchronize()
+    d = (sim.field("stats_sum") - s0).to(torch.int64).sum(dim=0).cpu().numpy()
+    steps, dual, kkt, tie, stall, cost, maxit, primal, fallback, big, noslip, free = (int(d[k]) for k in (0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14))
+    print(name, dict(steps=steps, contact_space=dual, kkt=kkt, tie=tie, stall=stall, cost=cost, maxit=maxit, primal=primal, fallback=fallback, big=big, free=free))
+    assert steps == 2000 * n and bool(torch.isfinite(sim.field("qpos")).all())
+    assert dual + primal + free == steps and kkt + tie + stall + cost + maxit == dual
+    assert kkt >= 0.999 * dual and maxit == 0 and noslip == 0
+    assert fallback <= primal and fallback <= 1e-3 * steps
+    if name == "config2":
+        assert primal <= 1e-4 * steps          # sixteen contacts: a walking fly on flat ground never leaves the contact-space solve
+
+
+def test_batch_info_names_what_runs(torch_mod, monkeypatch):
+    """``nmf_batch_info``: kernel family, contact-space flavour, residency, chunk plan and solver options as the batch runs
+    them; explicit create options show up in it, stray ``NMF_*`` environment variables do not change it (the library reads
+    the environment only under ``NMF_ALLOW_ENV=1``)."""
+    from flygym_amd import HIPSimulation, make_model
+
+    fly, world, _ = make_model()
+    monkeypatch.setenv("NMF_SOLVER", "primal"); monkeypatch.setenv("NMF_SCHED", "plain")
+    info = HIPSimulation(world, n_worlds=8, device=0).batch_info()
+    assert info["kernel_family"] == 0 and info["contact_space_flavour"] == 1 and info["contact_space_max_contacts"] == 16
+    assert info["flies_per_cu"] == 8 and info["resident_workgroups"] == 8 * 256 and info["chunked"] == 1 and info["solver_option_bits"] == 0
+    assert info["kernel_vgprs"] <= 256 and 0 < info["kernel_lds_bytes"] <= 20480
+    info = HIPSimulation(world, n_worlds=8, device=0, _options=dict(solver="primal", sched="plain", max_chunks=5)).batch_info()
+    assert info["solver_option_bits"] == 1 and info["contact_space_flavour"] == 0 and info["chunked"] == 0 and info["max_chunks"] == 5
+    bio = make_model(joints_preset="all_biological")[1]
+    info = HIPSimulation(bio, n_worlds=8, device=0).batch_info()
+    assert info["kernel_family"] == 4 and info["contact_space_flavour"] == 2 and info["contact_space_max_contacts"] == 13 and info["flies_per_cu"] == 8
