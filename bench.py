@@ -95,6 +95,10 @@ def parse_args(argv=None):
                     help="--vision render: rays per ommatidium; 0 = every pixel of the raw frame inside the lattice (readings = "
                          "resampling the rendered frame, bit for bit), 16 = the sampled mode (an approximation, 15 x fewer rays)")
     ap.add_argument("--simplify-geom", action="store_true", help="all-capsule collision geometry variant")
+    ap.add_argument("--obs-every", type=int, default=0, metavar="K",
+                    help="record the 270-float observation block (joint angles, velocities, actuator forces, contact sensors) of every "
+                         "K-th physics step inside the fused launch (nmf_step_record): the reference's loops read them after every step. "
+                         "The roofline then prices 3008 B per recorded env-step (SURVEY 8(d)); 0 = off (outputs on a launch's last step only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-counters", action="store_true",
                     help="do not re-run the workload under rocprofv3 --pmc after the timed region (N = 1): roofline.traffic / "
@@ -465,10 +469,19 @@ def run(args, primary=True):
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)]
     ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(n_events + 1)] if see is not None else None
 
+    obs_every = int(getattr(args, "obs_every", 0) or 0)
+    if obs_every and (spl % obs_every or obs_every > spl):
+        raise SystemExit("--obs-every must divide --steps-per-launch")
+    # the observation ring of a launch: one buffer, reused (a consumer would read it before the next tick)
+    ring = torch.empty((spl // obs_every, n_local, OBS_DIM if args.joint_preset == "legs_only" else 2 * nj + 42 + 96), dtype=torch.float32, device=sim.device) if obs_every else None
+
     def control_tick(start, k=n_events):
         # the kernel is launched on torch's current stream, so these events bracket exactly it
         ev0[k].record()
-        sim.step_replay(table, act_ids, start, spl)
+        if ring is None:
+            sim.step_replay(table, act_ids, start, spl)
+        else:
+            sim.record_into(ring, table, act_ids, start, spl, obs_every)
         ev1[k].record()
         if see is not None:                # the vision tick: ev1 .. ev2 bracket exactly the retina / eye kernel
             nonlocal vision_out
@@ -543,6 +556,9 @@ def run(args, primary=True):
         # SURVEY §8(d) formula on this model's sizes: read qpos + qvel + ctrl + warm start, write qpos + qvel + warm start
         bytes_per_env_step = 4 * (2 * sim.model.nq + 4 * sim.model.nv + sim.model.nu)
         assert args.joint_preset != "legs_only" or bytes_per_env_step == BYTES_PER_ENV_STEP
+        if obs_every:      # + the observation block on the recorded steps (1928 + 1080 = 3008 B with obs on every step)
+            bytes_per_env_step += 4.0 * ring.shape[2] / obs_every
+            assert args.joint_preset != "legs_only" or obs_every != 1 or bytes_per_env_step == 3008
         achieved = bytes_per_env_step * n_local * spl / (ms * 1e-3) / 1e9
         traffic, issue = traffic_model(n_local, spl, args)
         traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder, fitted per world and per step)" if traffic is not None else None
@@ -601,6 +617,10 @@ def run(args, primary=True):
                 # pure outputs (segment poses, contact sensors, actuator forces) are computed on a launch's last step only: a
                 # caller of nmf_step(n) cannot observe the intermediate ones (the reference's captured loop computes them every step)
                 "outputs_every_steps": spl,
+                # the observation block (joint angles, velocities, actuator forces, contact sensors: what the reference's loops read
+                # after every step) is recorded inside the launch on every obs_every-th step (nmf_step_record); 0 = not recorded
+                "obs_every_steps": obs_every,
+                "batch_info": sim.batch_info(),
                 "shard_sizes": shard_sizes, "active_gpus": active_gpus, "resident_worlds_per_gpu": resident, "shard_note": shard_note,
                 "settle_steps": {"neutral": settle_neutral, "gait": settle_gait, "warmup": args.warmup},
                 "repeats": repeats, "timed_steps_total": args.steps * repeats,
@@ -700,6 +720,8 @@ OTHER_CONFIGS = (
     ("config 3: 4096 flies, vision every 20 steps, raw frames resampled", dict(vision="resample", steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast", dict(vision="render", steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast, 16 rays per ommatidium (sampled mode: an approximation)", dict(vision="render", eye_rays=16, steps=200)),
+    ("config 2 with the observation block recorded on EVERY step inside the fused launches (3008 B/env-step, SURVEY 8(d))", dict(obs_every=1, steps=200)),
+    ("config 2 stepped one launch per step (what a caller reading outputs between steps pays without the ring)", dict(steps_per_launch=1, steps=100)),
     ("config 4: 4096 flies per GPU, gapped terrain", dict(terrain="gapped", steps=200)),
     ("config 4: 4096 flies per GPU, blocks terrain", dict(terrain="blocks", steps=200)),
     ("config 5: 1024 flies, mixed terrain + odor sensors + gait-driven adhesion", dict(worlds_per_gpu=1024, terrain="mixed", odor=True, cpg_adhesion=20.0, steps=200)),
@@ -715,7 +737,7 @@ def other_configs(args):
         a = argparse.Namespace(**vars(args))
         a.gpus, a.scaling, a.warmup, a.repeats, a.no_cpu_baseline, a.no_live_counters = 1, "weak", 0, 0, True, True
         a.workload, a.terrain, a.odor, a.cpg_adhesion, a.vision, a.worlds_per_gpu, a.steps_per_launch = "cpg", "flat", False, 0.0, "off", 4096, 50
-        a.joint_preset, a.simplify_geom, a.eye_rays = "legs_only", False, 0
+        a.joint_preset, a.simplify_geom, a.eye_rays, a.obs_every = "legs_only", False, 0, 0
         for k, v in over.items():
             setattr(a, k, v)
         try:
@@ -724,6 +746,10 @@ def other_configs(args):
             rec = {"config": name, "value": o["value"], "unit": o["unit"], "valid": ok, "worlds": c["total_worlds"], "steps": a.steps,
                    "steps_per_launch": c["steps_per_launch"], "kernel_ms_per_launch": c["kernel_ms_per_launch"]["mean"],
                    "mean_contacts": c["mean_contacts"], "mean_newton_iters": c["mean_newton_iters"]}
+            if c.get("obs_every_steps"):
+                rec["obs_every_steps"] = c["obs_every_steps"]
+                rec["algorithmic_bytes_per_env_step"] = o["roofline"]["algorithmic_bytes_per_env_step"]
+                rec["roofline_frac"] = o["roofline"]["frac"]
             if "vision" in c:
                 rec["vision_kernel_ms_per_tick"] = c["vision"]["kernel_ms_per_tick"]
                 rec["vision_kernel"] = o["roofline"]["kernel"]

@@ -20,6 +20,12 @@
 // (frames_out, for inspection and for the parity tests): compute-bound instead of HBM-bound.
 #include "nmf_device.h"
 
+// The two instantiations of the kernel below (pixel-exact, sampled) must colour a pixel identically — the sampled mode's readings
+// equal its specification applied to the pixel-exact mode's frames bit for bit (tests/test_sensors.py) — so the ray and scene
+// arithmetic may not be re-associated differently in the two contexts (the library is built with -fassociative-math).  Fused
+// multiply-adds stay (contraction does not depend on the surrounding code).
+#pragma clang fp reassociate(off)
+
 namespace nmf {
 
 #ifdef NMF_EYE_STATS
@@ -125,14 +131,20 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   const int sg = A.eye_seg[eye];
   float Rs[9];
   qmat(Rs, ldq(seg_xquat + ((size_t)w * nseg + sg) * 4));
-  const V3 cam = ld3(seg_xpos + ((size_t)w * nseg + sg) * 3) + mat_vec(Rs, ld3(A.rel_pos[eye]));
+  const V3 cam_v = ld3(seg_xpos + ((size_t)w * nseg + sg) * 3) + mat_vec(Rs, ld3(A.rel_pos[eye]));
   float R[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       R[3 * i + j] = Rs[3 * i] * A.rel_mat[eye][j] + Rs[3 * i + 1] * A.rel_mat[eye][3 + j] + Rs[3 * i + 2] * A.rel_mat[eye][6 + j];
-  const int n_pix = A.height * A.width, n_chunk = n_pix / 16;
+  // the view's constants are the same in every lane: scalar registers (they took 16 of the pixel loop's 72 vector registers,
+  // and 24 more values went to scratch)
+  auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = uni(R[i]);
+  const V3 cam = v3(uni(cam_v.x), uni(cam_v.y), uni(cam_v.z));
+  const int n_pix = A.height * A.width;
   const float inv_half_h = 2.0f / (float)A.height, cx = 0.5f * (float)A.width, cy = 0.5f * (float)A.height;
   const float inv_cs = 1.0f / A.checker_size;
   const float hz = cam.z - A.ground_z;
@@ -218,9 +230,17 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     const unsigned long long grp_caps = __ballot(sees_cap);
     const unsigned int grp_sph = (unsigned int)__ballot(lane < A.n_spheres && cone_sees(sphc[lane < A.n_spheres ? lane : 0][0], sphc[lane < A.n_spheres ? lane : 0][1],
                                                                                       sphc[lane < A.n_spheres ? lane : 0][2], sphc[lane < A.n_spheres ? lane : 0][3], sphc[lane < A.n_spheres ? lane : 0][4]));
-    const bool grp_ground = gw[0].z < g_sin[0] + 1e-3f || (two && gw[1].z < g_sin[1] + 1e-3f);          // some ray of the group points below the horizon
+    // some ray of the group points below the horizon (a cone wider than a hemisphere always does: sin falls again beyond 90 degrees)
+    const bool grp_ground = g_cos[0] <= 0.f || gw[0].z < g_sin[0] + 1e-3f || (two && (g_cos[1] <= 0.f || gw[1].z < g_sin[1] + 1e-3f));
     constexpr bool sampled = SAMPLED;         // the visit list holds PIXELS, kEyeRays per ommatidium, one ray per lane
     if (!sampled && ch < 0) continue;
+    // A group whose cone meets nothing — no ray below the horizon, no sphere, no capsule — sees the sky in every pixel: no ray
+    // is built at all (the upper half of an eye's image, less what the fly's own body covers).  Same bytes as the pixel loop
+    // would produce (the chunks it applies to are those of the polynomial path: never behind the lens' full sphere).
+    const bool sky_only = !grp_ground && grp_sph == 0u && grp_caps == 0ull && cn[9] != 0.f;
+#ifdef NMF_EYE_STATS
+    if (lane == 0) atomicAdd(&g_eye_stats[7], (sky_only ? 1ull : 0ull) | ((!grp_ground && grp_sph == 0u) ? 1ull << 32 : 0ull));
+#endif
     const int chunk = sampled ? (ch < 0 ? 0 : ch >> 4) : ch;
     const u32x4 pl = plan[chunk];
     const bool planned = !(pl.y & 0x10000u);
@@ -339,7 +359,10 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
         const int px = turn == 0 ? ch : visit[(grp * (kEyeSlots / 4) + turn) * 64 + lane];
         const int omm = slot < n_omm ? slot_omm[slot] : 0;
         unsigned int val = 0u;
-        if (px >= 0) {
+        if (px >= 0 && sky_only && (px >> 4) * 16 / A.width == ((px >> 4) * 16 + 15) / A.width && !(reinterpret_cast<const unsigned int*>(plan)[4 * (px >> 4) + 1] & 0x10000u)) {
+          const unsigned int rgbw = mats[1];          // (a pixel of the polynomial path in a group that sees the sky only)
+          val = pale[omm] ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
+        } else if (px >= 0) {
           const int pchunk = px >> 4;
           const int prow = px / A.width, pcol = px - prow * A.width;
           const bool wraps = (pchunk * 16) / A.width != (pchunk * 16 + 15) / A.width;
@@ -381,7 +404,31 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       }
       continue;
     }
-    if (!two && planned && cn[9] != 0.f) {
+    if (!SAMPLED && sky_only && !two) {
+      // (wave-uniform: a chunk with more than three runs — one in fifty, i.e. most waves hold one — adds its sixteen equal pixels
+      // through the id map instead of sending the whole wave through the pixel loop)
+      const unsigned int sky = mats[1];
+      const unsigned int skyG = (sky >> 8) & 0xffu, skyB = (sky >> 16) & 0xffu;
+      const unsigned int pm = pl.z & 0xffffu, mA = pl.w & 0xffffu, mAB = pl.w >> 16;
+      if (planned) {
+        tot = (unsigned int)__popc(pm) * skyB + (unsigned int)__popc(~pm & 0xffffu) * skyG;
+        sA = (unsigned int)__popc(pm & mA) * skyB + (unsigned int)__popc(~pm & mA) * skyG;
+        sAB = (unsigned int)__popc(pm & mAB) * skyB + (unsigned int)__popc(~pm & mAB) * skyG;
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+          const int id = (int)((unsigned short)id_map[(size_t)ch * 16 + k] & 0x7fffu);
+          if (id > 0) atomicAdd(&acc[id - 1], ((pm >> k) & 1u) ? skyB : skyG);
+        }
+      }
+      if (fout) {
+        const unsigned int r0 = sky & 0xffu, r1 = skyG, r2 = skyB;
+        const unsigned int w0 = r0 | (r1 << 8) | (r2 << 16) | (r0 << 24), w1 = r1 | (r2 << 8) | (r0 << 16) | (r1 << 24), w2 = r2 | (r0 << 8) | (r1 << 16) | (r2 << 24);
+        unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { o[3 * g] = w0; o[3 * g + 1] = w1; o[3 * g + 2] = w2; }
+      }
+    } else if (!two && planned && cn[9] != 0.f) {
       // The common case — a chunk inside one image row, three or fewer runs, the whole image within the lens polynomials' range
       // (cn[9]; both are properties of the chunk / the lens, so a pixel takes the same path whatever the call renders) — on a diet: the row's part of the ray is hoisted, sin(theta) / rho and cos(theta) are polynomials in
       // theta^2 (theta <= 2.1 for a lens up to 240 degrees: truncation < 1e-7, no rsq / sin / cos), the chosen colour byte
@@ -391,43 +438,49 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       const V3 rowv = v3(-vv * R[1], -vv * R[4], -vv * R[7]);
       // (four pixels per turn of a rolled loop: the scene code exists four times, not sixteen — the kernel has to fit the
       // instruction cache too)
+      auto chunk_pixels = [&](auto&& colour_of) {      // colour_of(ray) -> the material's rgb word
 #pragma unroll 1
-      for (int g = 0; g < 4; ++g) {
-        unsigned int G4 = 0u, B4 = 0u, raw[3] = {0u, 0u, 0u};
+        for (int g = 0; g < 4; ++g) {
+          unsigned int G4 = 0u, B4 = 0u, raw[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const float u = ((float)(col + 4 * g + k4) + 0.5f - cx) * inv_half_h;
-          const float x = fmaf(u, u, v2) * hf2;               // theta^2
-          float sc = -1.0f / 1307674368000.f;                 // sin(theta) / theta
-          sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
-          sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
-          float cs = 1.0f / 20922789888000.f;                 // cos(theta)
-          cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
-          cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
-          const float s1 = sc * A.half_fov;                   // sin(theta) / rho
-          const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
-          const unsigned int rgbw = mats[scene(d) + 1];
-          constexpr unsigned int keep = 0x03020100u;
-          G4 = __builtin_amdgcn_perm(rgbw, G4, (keep & ~(0xffu << (8 * k4))) | (5u << (8 * k4)));
-          B4 = __builtin_amdgcn_perm(rgbw, B4, (keep & ~(0xffu << (8 * k4))) | (6u << (8 * k4)));
-          if (fout) {
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const float u = ((float)(col + 4 * g + k4) + 0.5f - cx) * inv_half_h;
+            const float x = fmaf(u, u, v2) * hf2;               // theta^2
+            float sc = -1.0f / 1307674368000.f;                 // sin(theta) / theta
+            sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
+            sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
+            float cs = 1.0f / 20922789888000.f;                 // cos(theta)
+            cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
+            cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
+            const float s1 = sc * A.half_fov;                   // sin(theta) / rho
+            const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
+            const unsigned int rgbw = colour_of(d);
+            constexpr unsigned int keep = 0x03020100u;
+            G4 = __builtin_amdgcn_perm(rgbw, G4, (keep & ~(0xffu << (8 * k4))) | (5u << (8 * k4)));
+            B4 = __builtin_amdgcn_perm(rgbw, B4, (keep & ~(0xffu << (8 * k4))) | (6u << (8 * k4)));
+            if (fout) {
 #pragma unroll
-            for (int cidx = 0; cidx < 3; ++cidx) {
-              const int bpos = 3 * k4 + cidx;
-              raw[bpos >> 2] |= ((rgbw >> (8 * cidx)) & 0xffu) << ((bpos & 3) * 8);
+              for (int cidx = 0; cidx < 3; ++cidx) {
+                const int bpos = 3 * k4 + cidx;
+                raw[bpos >> 2] |= ((rgbw >> (8 * cidx)) & 0xffu) << ((bpos & 3) * 8);
+              }
             }
           }
+          const unsigned int P4 = ((((pl.z >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+          const unsigned int V4 = (B4 & P4) | (G4 & ~P4);
+          tot = __builtin_amdgcn_udot4(V4, 0x01010101u, tot, false);
+          sA = __builtin_amdgcn_udot4(V4, (((pl.w >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sA, false);
+          sAB = __builtin_amdgcn_udot4(V4, (((pl.w >> (16 + 4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sAB, false);
+          if (fout) {
+            unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48) + 3 * g;
+            o[0] = raw[0]; o[1] = raw[1]; o[2] = raw[2];
+          }
         }
-        const unsigned int P4 = ((((pl.z >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
-        const unsigned int V4 = (B4 & P4) | (G4 & ~P4);
-        tot = __builtin_amdgcn_udot4(V4, 0x01010101u, tot, false);
-        sA = __builtin_amdgcn_udot4(V4, (((pl.w >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sA, false);
-        sAB = __builtin_amdgcn_udot4(V4, (((pl.w >> (16 + 4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sAB, false);
-        if (fout) {
-          unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48) + 3 * g;
-          o[0] = raw[0]; o[1] = raw[1]; o[2] = raw[2];
-        }
-      }
+      };
+      // (Tried, round 5: a straight-line loop for the groups that can only see the checker or the sky — more than half of them —
+      // with the three colours in registers: 49 spilled registers at this occupancy, 2.96 ms against 2.43, and bytes that differ
+      // from scene()'s at checker edges, which the sampled mode's bit-equality with these frames does not allow.)
+      chunk_pixels([&](const V3 d) { return mats[scene(d) + 1]; });
     } else {
       // everything else (a chunk that wraps to the next row, more than three runs, a lens beyond the polynomials' range): per
       // pixel, rolled

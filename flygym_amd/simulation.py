@@ -233,12 +233,25 @@ class HIPSimulation:
         k = int(record_every)
         if k < 1 or int(n_steps) < k:
             raise ValueError(f"record_every must be in 1..n_steps, got {record_every} for {n_steps} steps")
+        width = 2 * (self.model.nv - 6) + int(n_act) + 96
+        ring = t.empty((int(n_steps) // k, self.n_worlds, width), dtype=t.float32, device=self.device)
+        return self.record_into(ring, table, act_ids, start, n_steps, k, n_act)
+
+    def record_into(self, ring, table, act_ids, start: int, n_steps: int, record_every: int, n_act: int = 42):
+        """:meth:`step` / :meth:`step_replay` with ``record_every``, writing into a caller-owned ring (float32, contiguous,
+        ``(n_steps // record_every, n_worlds, >= 2 nj + n_act + 96)`` on this device) — no allocation per tick."""
+        t = self._torch
         nj = self.model.nv - 6
         width = 2 * nj + int(n_act) + 96
-        ring = t.empty((int(n_steps) // k, self.n_worlds, width), dtype=t.float32, device=self.device)
+        k = int(record_every)
+        if k < 1 or int(n_steps) < k:
+            raise ValueError(f"record_every must be in 1..n_steps, got {record_every} for {n_steps} steps")
+        if ring.dtype != t.float32 or ring.device != self.device or ring.ndim != 3 or not ring.is_contiguous() \
+                or ring.shape[0] < int(n_steps) // k or ring.shape[1] != self.n_worlds or ring.shape[2] < width:
+            raise ValueError(f"the observation ring must be a contiguous float32 ({int(n_steps) // k}+, {self.n_worlds}, {width}+) tensor on {self.device}")
         tab = (table.data_ptr(), int(table.shape[1]), int(table.shape[2]), act_ids.data_ptr()) if table is not None else (None, 0, 0, None)
         _native.check(self._lib.nmf_step_record(self._batch_h, tab[0], tab[1], tab[2], tab[3], int(start), int(n_steps), k, nj, int(n_act),
-                                                ring.data_ptr(), width, self._stream()))
+                                                ring.data_ptr(), int(ring.shape[2]), self._stream()))
         return ring
 
     def step_replay(self, table, act_ids, start: int, n_steps: int, record_every: int | None = None, n_act: int = 42):

@@ -18,5 +18,5 @@ eyes.render(); torch.cuda.synchronize()
 L.nmf_debug_eye_stats(buf)
 g = list(buf)
 print(f"groups per view {g[0] / (2 * n):.1f}; group capsule candidates {g[1] / g[0]:.2f}; union of chunk candidates per group {g[2] / g[0]:.2f}; per-chunk candidates {g[3] / (g[0] * 64):.2f}; "
-      f"inside-bound tests per chunk {(g[7] & 0xffffffff) / (g[0] * 64):.3f}, wide-sum tests per chunk {(g[7] >> 32) / (g[0] * 64):.3f}; "
+      f"groups that see the sky only {(g[7] & 0xffffffff) / g[0]:.3f}, groups above the horizon without a sphere {(g[7] >> 32) / g[0]:.3f}; "
       f"groups seeing ground {g[4] / g[0]:.2f}, spheres per group {g[5] / g[0]:.2f}, groups with any candidate {g[6] / g[0]:.2f}")
