@@ -551,6 +551,14 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
       (void)hipMemset(p, 0, sizeof(unsigned int) * (size_t)n_worlds * nmf::kActHistWords);
       b->allocs.push_back(p); st.act_hist = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
+    st.noslip_buf = nullptr;
+    if (d.noslip_iter > 0) {       // CPU flavour: scratch of the primal path's noslip pass (157 KB per world)
+      p = nullptr;
+      if (hipMalloc(&p, sizeof(float) * (size_t)n_worlds * nmf::kNoslipFloats) == hipSuccess) {
+        (void)hipMemset(p, 0, sizeof(float) * (size_t)n_worlds * nmf::kNoslipFloats);
+        b->allocs.push_back(p); st.noslip_buf = (float*)p;
+      } else rc |= fail("nmf_batch_create: out of device memory");
+    }
     p = nullptr;
     if (hipMalloc(&p, 2 * sizeof(unsigned long long)) == hipSuccess) {
       (void)hipMemset(p, 0, 2 * sizeof(unsigned long long));

@@ -180,6 +180,9 @@ struct DevState {
   // goes to ring[(step + 1) / obs_every - 1][world][.], rows ring_stride floats apart
   float* ring;
   int ring_stride, obs_every, ring_nj, ring_nact;
+  // CPU flavour (noslip iterations on): per world the scratch of the primal path's noslip pass (nmf_step.hip::noslip_primal);
+  // nullptr on the batched path
+  float* noslip_buf;
   int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 

@@ -1824,6 +1824,107 @@ __device__ __forceinline__ void contact_row_forces(const ContactRegs& c, float s
 #include "nmf_dual.h"
 namespace nmf {
 
+// ------------------------------------------------------------------ noslip post-pass on the primal path
+// option/noslip_iterations of the CPU flavour (reference mujoco_globals.yaml:15 under mujoco.mj_step, src/flygym/simulation.py:74-76;
+// restated from MuJoCo's documentation in oracle/nmf_oracle.c::noslip) for every step the contact-space solve — where the pass
+// is a few wave sums over G — does not take: the full-body and general-tree skeletons, tethered worlds, steps with more than
+// sixteen contacts.  One world, so cost is no object: A = J M^-1 J^T is built column by column with one articulated-body solve
+// per constraint row (a unit force on the row, pushed to the dofs, solved, read back through every row) into the world's
+// scratch in HBM (DevState::noslip_buf: [198][198] columns by fixed row ids — contact c row k = 4 c + k, tether row i = 192 + i —
+// then the rows' reference accelerations, stored when they were computed, then this function's result); then the same pair
+// Gauss-Seidel as the oracle's — (f0, f1) = (mid + y, mid - y), y in [-mid, mid] minimises 1/2 f^T A f + f^T b, an update that
+// raises the cost is undone, up to noslip_iter sweeps — lane = contact, its four forces in registers.  The caller turns the
+// forces into J^T f and qacc.  Its own function: nothing of it may sit in the stepping kernels' registers.
+constexpr int kNoslipRows = 4 * kMaxCon + 6;
+constexpr int kNoslipFloats = kNoslipRows * (kNoslipRows + 2);
+template <class TP, bool WELD>
+__device__ __noinline__ void noslip_primal(FlyLds<TP>& s, const GModel& m, int lane, float* __restrict__ buf, int ncon, bool walls,
+                                           bool con, int cinfo, float q0, float q1, float q2, float q3, float wforce, float wD) {
+  constexpr int NR = kNoslipRows;
+  const Frame fr = make_frame(v3(m.plane[0], m.plane[1], m.plane[2]));
+  ContactRegs c{};
+  c.on = con; c.info = cinfo; c.body = info_body(cinfo); c.geom = info_geom(cinfo);
+  contact_reload(c, s, lane);
+  WeldRow wr{};
+  wr.comp = lane - 48;
+  wr.on = WELD && wr.comp >= 0 && wr.comp < 6;
+  auto rows = [&](SV t, float* out) {
+    if (walls) rows_of_twist(c, contact_frame(info_fid(c.info), fr), t, out); else rows_of_twist(c, fr, t, out);
+  };
+  float f[4] = {q0, q1, q2, q3};
+  // b = J qacc_smooth - aref
+  sweep_twists(s, s.qacc_smooth, s.T, m, lane);
+  float b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c.on) {
+    rows(ldsv(s.T[c.body]), b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] -= buf[NR * NR + 4 * lane + k];
+  }
+  WSYNC();
+  const int nrow_c = 4 * ncon;
+  for (int i = 0; i < nrow_c + (WELD ? 6 : 0); ++i) {
+    const bool isw = i >= nrow_c;
+    const int ci = i >> 2, ki = i & 3, wc = i - nrow_c;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = (!isw && lane == ci && k == ki) ? 1.f : 0.f;
+    const float ew = isw && wr.comp == wc ? 1.f : 0.f;
+    contact_project<TP, false>(s, c, wr, fr, e, ew, 0.f, m, lane, walls, [&](int j, float v) { s.vA[j] = v; });
+    aba_solve<TP, WELD>(s, V_A, V_B, false, 0.f, m, lane);       // T = twists(M^-1 J_i^T)
+    contact_reload(c, s, lane);
+    const int col = isw ? 4 * kMaxCon + wc : i;
+    if (c.on) {
+      float a[4];
+      rows(ldsv(s.T[c.body]), a);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) buf[col * NR + 4 * lane + k] = a[k];
+    }
+    if (wr.on) buf[col * NR + 4 * kMaxCon + wr.comp] = s.T[0][wr.comp];
+    WSYNC();
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the columns are read across lanes through memory
+  const float scale = 1.0f / (m.meaninertia * (float)s.nv());
+  for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
+    float improvement = 0.f;
+    if (sweep == 0) {      // the regulariser's share of the cost drops out
+      float v = 0.f;
+      if (c.on) { const float rD = 1.0f / c.D; v = 0.5f * rD * (f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3]); }
+      if (wr.on && wD > 0.f) v += 0.5f * wforce * wforce / wD;
+      improvement = wave_sum(v);
+    }
+    for (int c2 = 0; c2 < ncon; ++c2) {
+      for (int pp = 0; pp < 2; ++pp) {
+        const int r0 = 4 * c2 + 2 * pp, r1 = r0 + 1;
+        float p0 = 0.f, p1 = 0.f;
+        if (c.on) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { p0 = fmaf(buf[r0 * NR + 4 * lane + k], f[k], p0); p1 = fmaf(buf[r1 * NR + 4 * lane + k], f[k], p1); }
+        }
+        if (wr.on) { p0 = fmaf(buf[r0 * NR + 4 * kMaxCon + wr.comp], wforce, p0); p1 = fmaf(buf[r1 * NR + 4 * kMaxCon + wr.comp], wforce, p1); }
+        const float res0 = wave_sum(p0) + readlane_f(pp == 0 ? b[0] : b[2], c2), res1 = wave_sum(p1) + readlane_f(pp == 0 ? b[1] : b[3], c2);
+        const float a00 = buf[r0 * NR + r0], a01 = buf[r0 * NR + r1], a11 = buf[r1 * NR + r1];
+        const float old0 = readlane_f(pp == 0 ? f[0] : f[2], c2), old1 = readlane_f(pp == 0 ? f[1] : f[3], c2);
+        const float bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
+        const float mid = 0.5f * (old0 + old1);
+        const float K1 = a00 + a11 - 2.f * a01, K0 = mid * (a00 - a11) + bc0 - bc1;
+        float n0 = mid, n1 = mid;
+        if (!(K1 < kMinVal)) { const float y = fminf(fmaxf(-K0 / K1, -mid), mid); n0 = mid + y; n1 = mid - y; }
+        const float d0 = n0 - old0, d1 = n1 - old1;
+        float change = 0.5f * (d0 * (a00 * d0 + a01 * d1) + d1 * (a01 * d0 + a11 * d1)) + d0 * res0 + d1 * res1;
+        if (change > 1e-10f) { n0 = old0; n1 = old1; change = 0.f; }
+        if (lane == c2) { if (pp == 0) { f[0] = n0; f[1] = n1; } else { f[2] = n0; f[3] = n1; } }
+        improvement -= change;
+      }
+    }
+    if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
+  }
+  if (c.on) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) buf[NR * NR + NR + 4 * lane + k] = f[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+}
+
 // The control-table row of the NEXT step, requested from inside the current one.  Every non-inlined stage function begins
 // with `s_waitcnt vmcnt(0)` (the calling convention: a callee cannot know what is in flight), so a load issued right before
 // a call — round 2 requested the row at the top of the step, just ahead of the kinematics call — is waited for at once, HBM
@@ -1916,6 +2017,15 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   }
   STAGE(4);
   // ---- velocities and bias accelerations: three passes over the chains
+  // (CPU flavour: the rows' reference accelerations also go to the world's noslip scratch — noslip_primal reads them back)
+  float* const nsbuf = m.noslip_iter > 0 && st.noslip_buf ? st.noslip_buf + (size_t)w * kNoslipFloats : nullptr;
+  auto stash_aref = [&]() {
+    if (!nsbuf) return;
+    if (c.on) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) nsbuf[kNoslipRows * kNoslipRows + 4 * opaque(lane) + k] = c.aref[k];
+    }
+  };
   if constexpr (!TP::kStar) {
     tree_velocity_bias(s, m, lane);
     if (c.on) {
@@ -1925,6 +2035,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 #pragma unroll
       for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
     }
+    stash_aref();
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
   } else {
     // hybrid: root + the rest of the body by tree levels first (the chain passes below redo the root identically)
@@ -1955,6 +2066,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 #pragma unroll
       for (int k = 0; k < 4; k++) c.aref[k] = -c.B * velrow[k] - c.K * c.imp * rr0;
     }
+    stash_aref();
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
     for (int j = 3 + lane; j < s.nv(); j += kWave)
@@ -2265,6 +2377,23 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         else rest_levels<TP, false, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 0, true>(s, nd, s.qacc, L); });
       }
     } }
+    // ---- CPU flavour: the noslip post-pass (noslip_primal), then J^T f and qacc = M^-1 (qfrc_smooth + J^T f) from its forces
+    if (nsbuf && ncon > 0) {
+      float f0[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c.on) contact_row_forces(c, 1.f, f0);
+      WSYNC();
+      noslip_primal<TP, WELD>(s, m, lane, nsbuf, ncon, walls, c.on, c.info, f0[0], f0[1], f0[2], f0[3], -wr.D * wr.jar, wr.D);
+      contact_reload(c, s, lane);
+      float ff[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c.on) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) ff[k] = nsbuf[kNoslipRows * kNoslipRows + kNoslipRows + 4 * opaque(lane) + k];
+      }
+      contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, walls, [&](int j, float v) { s.vD[j] = v; s.vA[j] = s.qfrc_smooth[j] + v; });
+      aba_solve<TP, WELD>(s, V_A, V_QACC, false, 0.f, m, lane);
+      contact_reload(c, s, lane);
+      report &= ~kExitNoNoslip;
+    }
   }
   if (lane == 0) { s.iters = (int)((unsigned int)iters | report); s.solve_resid = resid; }
   STAGE(14);

@@ -52,7 +52,7 @@ class HIPSimulation:
             raise ValueError("The world must contain at least one fly.")
         if int(max_contacts) < 1:
             raise ValueError(f"max_contacts must be at least 1, got {max_contacts}")
-        if not (_cpu_flavour and self._noslip_supported(world)):      # (flygym_amd.Simulation keeps the CPU class's noslip pass)
+        if not _cpu_flavour:      # (flygym_amd.Simulation keeps the CPU class's noslip pass, on every skeleton and world)
             self._strip_unsupported_options(world)
         self.world = world
         self.n_worlds = int(n_worlds)
@@ -110,14 +110,6 @@ class HIPSimulation:
                 self._model_h = None
         except Exception:
             pass
-
-    @staticmethod
-    def _noslip_supported(world: BaseWorld) -> bool:
-        """The noslip post-pass lives in the contact-space solve (csrc/nmf_dual.h): leg-chain skeletons (LEGS_ONLY,
-        LEGS_ACTIVE_ONLY) on untethered worlds.  Elsewhere the option is stripped, with the reference's warning."""
-        m = world.compile_model()
-        star = tuple(int(v) for v in np.asarray(m["star"]).ravel())
-        return star in ((1, 6, 11, 8), (1, 6, 7, 4)) and int(np.asarray(m["weld_active"]).ravel()[0]) == 0
 
     @staticmethod
     def _strip_unsupported_options(world: BaseWorld) -> bool:
@@ -492,10 +484,11 @@ class Simulation:
     For user loops written against ``flygym.Simulation``; throughput work belongs on :class:`HIPSimulation`
     (a single world is launch-latency bound: ≈ 0.1 ms per ``step()``; use ``step(n)`` to fuse steps).  Differences:
     no ``mj_model`` / ``mj_data`` (the engine arrays are reachable through ``batch.field(name)``), rendering handed off.
-    The CPU class's noslip post-pass (``option/noslip_iterations = 5``, ``mujoco_globals.yaml:15``) runs here too — on the
-    LEGS_ONLY skeleton on every step (the class steps on kernels with room for 16 contacts in the contact-space solve, where
-    the pass lives; a walking fly makes up to 15); on LEGS_ACTIVE_ONLY a step with more than 12 contacts cannot take it and
-    is counted in the overflow statistic.
+    The CPU class's noslip post-pass (``option/noslip_iterations = 5``, ``mujoco_globals.yaml:15``) runs here too, on every
+    skeleton and world: inside the contact-space solve where a step takes it (leg-chain skeletons and ALL_BIOLOGICAL with up
+    to 16 / 13 contacts on the legs), else after the primal Newton loop with ``A = J M^-1 J^T`` built by one articulated-body
+    solve per constraint row (``csrc/nmf_step.hip::noslip_primal`` — one world: cost is no object).  A step with contacts
+    that went without the pass would be counted (``get_solver_exits()["noslip_skipped"]``); none does.
     """
 
     def __init__(self, world: BaseWorld, device: int | None = None) -> None:

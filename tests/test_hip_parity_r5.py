@@ -180,3 +180,112 @@ def test_batch_info_names_what_runs(torch_mod, monkeypatch):
     bio = make_model(joints_preset="all_biological")[1]
     info = HIPSimulation(bio, n_worlds=8, device=0).batch_info()
     assert info["kernel_family"] == 4 and info["contact_space_flavour"] == 2 and info["contact_space_max_contacts"] == 13 and info["flies_per_cu"] == 8
+
+
+@pytest.mark.parametrize("kind", ["all_biological", "all_possible", "custom_tree", "tethered", "legs_only_on_blocks"])
+def test_cpu_flavour_runs_noslip_on_every_kernel_family(torch_mod, oracle_lib, kind):
+    """``flygym_amd.Simulation`` keeps ``option/noslip_iterations = 5`` (reference mujoco_globals.yaml:15) for EVERY model the
+    reference's CPU class can step — rounds 3-4 had the pass in the contact-space solve only and stripped it elsewhere with the
+    GPU class's warning.  Hybrid (ALL_BIOLOGICAL: contact-space pass while the contacts are on the legs, primal pass when head /
+    abdomen touch), ALL_POSSIBLE and a custom skeleton (primal loop + ``noslip_primal``), a tethered fly (six weld rows in A)
+    and a terrain world: no warning, every step with contacts takes the pass, and sampled steps match the oracle running the
+    same pass from the same state — which differs from the oracle without it by far more."""
+    torch = torch_mod
+    import warnings
+    import flygym_amd.compose as C
+    from flygym_amd import Simulation, make_model, anatomy as A
+    from flygym_amd.controllers import TripodCPG
+    from flygym_amd.utils.math import Rotation3D
+
+    def build(noslip):
+        upright = Rotation3D("quat", (1, 0, 0, 0))
+        if kind in ("all_biological", "all_possible"):
+            fly, world, _ = make_model(joints_preset=kind)
+        elif kind == "tethered":
+            fly = make_model()[0]; world = C.TetheredWorld(); world.add_fly(fly, (0, 0, 1.5), upright)
+        elif kind == "legs_only_on_blocks":
+            fly = make_model()[0]; world = C.BlocksTerrainWorld(); world.add_fly(fly, (0.3, 0.2, 0.8), upright)
+        else:
+            fly = C.Fly(name="t")
+            bio = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.ALL_BIOLOGICAL)
+            keep = [j for j in bio.anatomical_joints if not any(k in j.child.name for k in ("wing", "haltere", "abdomen"))]
+            fly.add_joints(A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, anatomical_joints=keep), neutral_pose=C.KinematicPosePreset.NEUTRAL)
+            legs = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+            fly.add_actuators(legs.get_actuated_dofs_from_preset("legs_active_only"), C.ActuatorType.POSITION, kp=50.0, neutral_input=C.KinematicPosePreset.NEUTRAL)
+            fly.add_leg_adhesion()
+            world = C.FlatGroundWorld(); world.add_fly(fly, (0, 0, 0.8), upright)
+        if not noslip:
+            world.noslip_iterations = 0; world._compiled = None
+        return fly, world
+
+    fly, world = build(True)
+    assert world.noslip_iterations == 5
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # no "does not run noslip iterations" warning on any model
+        sim = Simulation(world)
+    batch = sim.batch
+    assert int(batch.model["opt_solver"][1]) == 5 and batch.batch_info()["noslip_iterations"] == 5
+    batch.set_leg_adhesion_states(fly.name, np.ones((1, 6), dtype=np.float32))
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4).targets(1, 2500, device=batch.device)
+    ids = batch.replay_ids(fly.name)
+    batch.warmup(); batch.step_replay(table, ids, 0, 400)
+    keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
+    blob5, blob0 = batch.model.to_blob(), build(False)[1].compile_model().to_blob()
+    worst, changed, cur, compared, primal_steps = 0.0, 0.0, 400, 0, 0
+    for k in range(8):
+        batch.step_replay(table, ids, cur, 19); cur += 19
+        state = {kk: batch.field(kk)[0].cpu().numpy().astype(np.float64) for kk in keys}
+        batch.step_replay(table, ids, cur, 1); cur += 1
+        torch.cuda.synchronize()
+        qacc = batch.field("qacc")[0].cpu().numpy().astype(np.float64)
+        stats = batch.field("stats")[0].cpu().numpy()
+        refs = {}
+        for name, blob in (("noslip", blob5), ("plain", blob0)):
+            r = oracle_lib.Oracle(blob, "f64", cpu_flavour=True)
+            for kk in keys: r.arr(kk)[:] = state[kk]
+            r.step_replay(table[0].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
+            refs[name] = r
+        if refs["noslip"].ints()["ncon"] != int(stats[0]) or int(stats[0]) == 0: continue
+        compared += 1
+        primal_steps += (int(stats[4]) >> 6) & 1
+        scale = np.abs(refs["noslip"].arr("qacc")).max()
+        worst = max(worst, np.abs(qacc - refs["noslip"].arr("qacc")).max() / scale)
+        changed = max(changed, np.abs(refs["noslip"].arr("qacc") - refs["plain"].arr("qacc")).max() / scale)
+    ex = batch.get_solver_exits()
+    print(kind, "compared", compared, "primal-loop steps among them", primal_steps, "worst", f"{worst:.2e}", "the pass moves qacc by", f"{changed:.2e}", ex)
+    if kind == "tethered":                                  # no ground: the pass has nothing to do (and must not disturb the weld)
+        assert ex["noslip_skipped"] == 0 and bool(torch.isfinite(batch.field("qpos")).all())
+        return
+    assert compared >= 5 and worst < 2e-3 and changed > 5 * worst, (compared, worst, changed)
+    assert ex["noslip_skipped"] == 0
+    if kind in ("all_possible", "custom_tree"):
+        assert primal_steps == compared and ex["contact_space"] == 0      # these skeletons have the primal loop only
+
+
+def test_noslip_removes_the_creep_on_the_kernel(torch_mod, oracle_lib):
+    """The closed-form anchor of the pass (tests/test_oracle_closed_form.py::test_noslip_removes_the_creep: a body on an incline
+    below half the friction slope comes to REST instead of creeping at the soft rows' steady velocity) on the kernel's
+    general-tree path, where the pass is ``noslip_primal``: velocity below 2 % of the creep prediction, held by a friction force
+    of m g sin(theta), the same numbers as the float32 oracle."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from tiny_models import TinyWorld, sphere_on_plane
+
+    MASS, RADIUS, MU, SOLREF, SOLIMP, MARGIN, G = 1e-3, 0.1, 1.0, (2e-4, 1.0), (0.98, 0.99, 0.5, 0.9999, 2.0), 1e-3, 9810.0
+    theta = np.arctan(0.3 * MU)
+    n = np.array([np.sin(theta), 0.0, np.cos(theta)])
+    m = sphere_on_plane(MASS, RADIUS, normal=n, mu=MU, solref=SOLREF, solimp=SOLIMP, margin=MARGIN, start_height=RADIUS + MARGIN, noslip_iterations=5)
+    world = TinyWorld(m); world.noslip_iterations = 5
+    sim = HIPSimulation(world, n_worlds=1, device=0, _cpu_flavour=True)
+    plain = HIPSimulation(TinyWorld(sphere_on_plane(MASS, RADIUS, normal=n, mu=MU, solref=SOLREF, solimp=SOLIMP, margin=MARGIN, start_height=RADIUS + MARGIN)), n_worlds=1, device=0)
+    sim.step(600); plain.step(600)
+    torch.cuda.synchronize()
+    o = oracle_lib.Oracle(m.to_blob(), "f32", cpu_flavour=True)
+    o.step(600)
+    v, v_plain = sim.field("qvel")[0, :3].cpu().numpy(), plain.field("qvel")[0, :3].cpu().numpy()
+    creep = np.abs(v_plain).max()
+    assert creep > 1e-3                                              # without the pass the body creeps down the slope
+    assert np.abs(v).max() < 0.02 * creep                            # with it: at rest
+    assert np.abs(sim.field("qacc")[0, :3].cpu().numpy()).max() < 1e-3 * G
+    np.testing.assert_allclose(sim.field("qpos")[0, :3].cpu().numpy(), np.asarray(o.qpos[:3], dtype=np.float64), atol=2e-5)
+    assert sim.get_solver_exits()["noslip_skipped"] == 0 and sim.get_solver_exits()["primal_loop"] >= 590
