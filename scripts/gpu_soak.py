@@ -1,6 +1,6 @@
 """Soak of the stepping kernel (run through gpurun): N worlds x many steps of CPG walking on several worlds / skeletons;
 checks that the state stays finite, no world overflows its contact list, every world keeps walking (forward speed) and
-the solver's iteration counts stay bounded.  usage: python scripts/gpu_soak.py [steps]"""
+the solver's iteration counts stay bounded.  usage: python scripts/gpu_soak.py [steps] [all]   (round 5 log of record: profiles/r5_soak.txt = `gpu_soak.py 50000 all`: 205 M env-steps per workload)"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -24,6 +24,7 @@ for name, world_cls, preset, adhesion in (WORKLOADS if len(sys.argv) > 2 and sys
         world = getattr(C, world_cls)()
         world.add_fly(fly, (0, 0, 1.5 if world_cls == "TetheredWorld" else 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     sim = HIPSimulation(world, n_worlds=n, device=0)
+    if name == WORKLOADS[0][0]: print("batch_info", sim.batch_info())
     cpg = TripodCPG(fly.get_actuated_jointdofs_order("position"), 1e-4)
     table = cpg.targets(n, 2500, device=sim.device, adhesion=(cpg.stance_bins(sim.model, fly), adhesion, 1.0) if adhesion else None)
     ids = sim.replay_ids(fly.name, with_adhesion=bool(adhesion))
@@ -44,4 +45,4 @@ for name, world_cls, preset, adhesion in (WORKLOADS if len(sys.argv) > 2 and sys
     speed = sim.field("qvel")[:, :2].norm(dim=1).cpu().numpy()
     print(f"{name:28s} {steps} steps x {n} worlds in {time.time() - t0:5.1f} s: finite {bool(torch.isfinite(q).all())} (non-finite samples {bad}), "
           f"overflow steps {int(ss[:, 3].sum())}, contacts/step {ss[:, 1].sum().item() / ss[:, 0].sum().item():.2f}, iterations/step {ss[:, 2].sum().item() / ss[:, 0].sum().item():.2f} "
-          f"(max seen at a sample {worst_it}), x displacement median {np.median(dx):.2f} mm (min {dx.min():.2f}, max {dx.max():.2f}), ground speed median {np.median(speed):.1f} mm/s (max {speed.max():.1f}), body height median {float(q[:, 2].median()):.3f}")
+          f"(max seen at a sample {worst_it}), solve reports per million steps { {k: round(v * 1e6 / max(sim.get_solver_exits()['steps'], 1), 2) for k, v in sim.get_solver_exits().items() if k != 'steps' and v} }, x displacement median {np.median(dx):.2f} mm (min {dx.min():.2f}, max {dx.max():.2f}), ground speed median {np.median(speed):.1f} mm/s (max {speed.max():.1f}), body height median {float(q[:, 2].median()):.3f}")

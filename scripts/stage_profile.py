@@ -5,7 +5,8 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 from flygym_amd import _native
-lib_prof = ROOT / "flygym_amd" / "libnmf_hip_prof.so"
+lib_prof = ROOT / "build" / "libnmf_prof.so"      # (a diagnostic build: never beside the product library)
+lib_prof.parent.mkdir(exist_ok=True)
 if "--build" in sys.argv or not lib_prof.exists():
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *_native.MATH_FLAGS,
                     "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC", "-shared", "-DNMF_STAGE_PROFILE", *[a for a in sys.argv if a.startswith("-D")],
