@@ -379,7 +379,7 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
     for (int cand = 4; cand <= 5 && topo < 0 && bp && dn; ++cand) {
       const int* pat = cand == 4 ? patB : patA;
       const int nb = model->nb, lb0 = 21, want_nv = cand == 4 ? 132 : 210;
-      bool ok = nb == 69 && model->nv == want_nv && (int)dn->i.size() == nb && dn->i[0] == 6 && model->nu <= nmf::FlyTopoBio::kCtrl;
+      bool ok = nb == 69 && model->nv == want_nv && (int)dn->i.size() == nb && dn->i[0] == 6 && model->nu <= (cand == 4 ? nmf::FlyTopoBio::kCtrl : nmf::FlyTopoAll::kCtrl);
       int rest_v = 0;
       for (int bb = 1; ok && bb < lb0; ++bb) { rest_v += dn->i[(size_t)bb]; ok = bp->i[(size_t)bb] >= 0 && bp->i[(size_t)bb] < lb0 && bp->i[(size_t)bb] < bb; }
       ok = ok && rest_v == 60;
@@ -551,6 +551,12 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
       (void)hipMemset(p, 0, sizeof(unsigned int) * (size_t)n_worlds * nmf::kActHistWords);
       b->allocs.push_back(p); st.act_hist = (unsigned int*)p;
     } else rc |= fail("nmf_batch_create: out of device memory");
+    st.dual_scratch = nullptr;
+    if (topo == 5) {       // ALL_POSSIBLE: the contact-space solve's leg factors live in HBM, one block per workgroup of a launch (<= n_worlds)
+      p = nullptr;
+      if (hipMalloc(&p, sizeof(float) * (size_t)n_worlds * nmf::kDualScratchFloats) == hipSuccess) { b->allocs.push_back(p); st.dual_scratch = (float*)p; }
+      else rc |= fail("nmf_batch_create: out of device memory");
+    }
     st.noslip_buf = nullptr;
     if (d.noslip_iter > 0) {       // CPU flavour: scratch of the primal path's noslip pass (157 KB per world)
       p = nullptr;

@@ -34,9 +34,10 @@ template <int REST_B_, int REST_V_, int NLEG_, int... DOFS>
 struct HybridTopo {
   static constexpr bool kStar = true;
   static constexpr bool kTerrain = false;   // see Terrain<> below
-  // controls a kernel keeps in LDS: 48 for the leg skeletons, 64 for the full-body ones (nmf_batch_create sends models
-  // with more actuators to the general-tree kernel, which holds one per dof)
-  static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : 64;
+  // controls a kernel keeps in LDS: 48 for the leg skeletons, 64 for ALL_BIOLOGICAL (which sits exactly on its LDS budget), 96 for
+  // ALL_POSSIBLE (the default actuated set on it is 72 leg dofs + 6 adhesion); nmf_batch_create sends models with more
+  // actuators to the general-tree kernel, which holds one per dof
+  static constexpr int kCtrl = REST_V_ == 0 ? kMaxCtrl : ((DOFS + ...) > 16 ? 96 : 64);
   static constexpr int REST_B = REST_B_, REST_V = REST_V_;
   static constexpr int NLEG = NLEG_;
   static constexpr int NBL = sizeof...(DOFS);
@@ -183,6 +184,9 @@ struct DevState {
   // CPU flavour (noslip iterations on): per world the scratch of the primal path's noslip pass (nmf_step.hip::noslip_primal);
   // nullptr on the batched path
   float* noslip_buf;
+  // kernels whose leg factors do not fit LDS (ALL_POSSIBLE): per workgroup of a stepping launch the contact-space solve's leg
+  // factors (nmf_step.hip kDualGlob); nullptr elsewhere
+  float* dual_scratch;
   int chunk_start[17];        // chunk c covers steps chunk_start[c] .. chunk_start[c + 1] - 1 (lengths shrink towards the end)
 };
 

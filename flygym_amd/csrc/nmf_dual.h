@@ -255,14 +255,15 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const V3 tq = cross(r, dm);
     float w[6] = {tq.x, tq.y, tq.z, dm.x, dm.y, dm.z};
     const lds_cptr Sl = lds_pinned(&s.S[TP::LD0 + legA * NDL][0]);
-    const lds_cptr Fl = lds_pinned(&DFleg[legA * NDL][0]);
+    const lds_cptr Fl = lds_pinned(kDualGlob<TP> ? &DFroot[0][0] : &DFleg[legA * NDL][0]);      // (kDualGlob: unused)
+    [[maybe_unused]] const gptr<float> Fg = G((const float*)DFleg) + legA * NDL * 8;               // kDualGlob: the factors in HBM
     static_for<NDL>([&](auto DD) {
       constexpr int d = NDL - 1 - decltype(DD)::value;
       float sj[6], f[7];
 #pragma unroll
       for (int i = 0; i < 6; ++i) sj[i] = Sl[d * SW + i];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) f[i] = Fl[d * 8 + i];
+      for (int i = 0; i < 7; ++i) { if constexpr (kDualGlob<TP>) f[i] = Fg[d * 8 + i]; else f[i] = Fl[d * 8 + i]; }
       float pr = sj[0] * w[0];
 #pragma unroll
       for (int i = 1; i < 6; ++i) pr = fmaf(sj[i], w[i], pr);
@@ -555,7 +556,10 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     const int jb = TP::LD0 + L.lg * NDL;
     static_for<NDL>([&](auto DD) {
       constexpr int d = decltype(DD)::value;
-      const float xj = DFleg[L.lg * NDL + d][6] * (acc[L.lg * NDL + d] - grp8_sum(L.mask * DFleg[L.lg * NDL + d][L.rr] * a));
+      float f6, fr;
+      if constexpr (kDualGlob<TP>) { const gptr<float> q = G((const float*)DFleg) + (L.lg * NDL + d) * 8; f6 = q[6]; fr = q[L.rr]; }
+      else { f6 = DFleg[L.lg * NDL + d][6]; fr = DFleg[L.lg * NDL + d][L.rr]; }
+      const float xj = f6 * (acc[L.lg * NDL + d] - grp8_sum(L.mask * fr * a));
       s.qacc[jb + d] = s.qacc_smooth[jb + d] + (kWarm ? c_ws * s.vA[jb + d] : 0.f) + xj;
       a = fmaf(xj, s.S[jb + d][L.rr], a);
     });

@@ -186,16 +186,22 @@ template <class TP> constexpr int row_width_tw() { if constexpr (TP::kStar) retu
 //  * kDualS — stars without a rest-of-body tree (LEGS_ONLY, LEGS_ACTIVE_ONLY): factors on c_w + c_m3, G on Ib..W (the
 //    inertias live a second time in Isym), warm start blended in, previous step's active set as first guess (act_hist);
 //    16 contacts = 64 rows = the wave (G: 1224 floats; Ib..W of the 49-body skeleton: 1225);
-//  * kDualH — hybrid kernels whose leg factors fit the four solver vectors (ALL_BIOLOGICAL): no LDS to spare, so the
-//    leg factors go to vA..vD, the root's, the rows' reference accelerations and the hinge sums to c_w, G to T..W only
-//    (Ib is the one copy of the inertias: 13 contacts), no warm-start term.  Steps with a contact on the rest of the
-//    body take the primal loop.
+//  * kDualH — hybrid kernels (ALL_BIOLOGICAL, ALL_POSSIBLE): no LDS to spare, so the leg factors go to vA..vD — or, where
+//    they do not fit those either (ALL_POSSIBLE, kDualGlob), to the workgroup's scratch in HBM —, the root's, the rows'
+//    reference accelerations and the hinge sums to c_w, G to T..W only (Ib is the one copy of the inertias: 13 contacts),
+//    no warm-start term.  Steps with a contact on the rest of the body take the primal loop.
 // One kernel per skeleton and world kind whatever the batch size: a world's result does not depend on how many worlds step
 // beside it (rounds 3-4 had a second LEGS_ONLY flavour for small batches, nmf::Wide, because A's row triangle for 16 contacts
 // cost two flies per CU).
 // NMF_NO_DUAL: development switch, every step on the primal loop.
 template <class TP> constexpr bool dual_hybrid() {
-  if constexpr (TP::kStar) return TP::REST_B > 0 && 4 * TP::NV >= TP::NLEG * TP::NDL * 8; else return false;
+  if constexpr (TP::kStar) return TP::REST_B > 0; else return false;
+}
+// ... whose leg factors (8 floats per leg hinge) do not fit the four solver vectors either (ALL_POSSIBLE: 144 leg hinges, 4.6 KB):
+// they go to a scratch of the workgroup in HBM (DevState::dual_scratch) — written once per step by the smooth solve, read
+// twice by the contact-space solve (response sweep, final expansion); a persistent workgroup's 4.6 KB stay in L2
+template <class TP> constexpr bool dual_global() {
+  if constexpr (TP::kStar) return TP::REST_B > 0 && 4 * TP::NV < TP::NLEG * TP::NDL * 8; else return false;
 }
 #ifdef NMF_NO_DUAL
 template <class TP> inline constexpr bool kDualS = false;
@@ -209,6 +215,8 @@ template <class TP> inline constexpr bool kDualH = dual_hybrid<TP>();
 #endif
 #endif
 template <class TP> inline constexpr bool kDual = kDualS<TP> || kDualH<TP>;
+template <class TP> inline constexpr bool kDualGlob = kDualH<TP> && dual_global<TP>();
+constexpr int kDualScratchFloats = 8 * 6 * 24;      // per workgroup: the leg factors of the largest skeleton (six legs of 24 hinges)
 constexpr int dual_g_floats(int ncon) { return 9 * ncon * (ncon + 1) / 2; }      // one 3x3 block per unordered pair of contacts
 template <class TP> constexpr int dual_max_con() {
   if constexpr (kDualH<TP>) {      // the contacts whose blocks fit T..W
@@ -327,6 +335,7 @@ struct __align__(16) FlyLds : TreeLds<TP> {
   }
   // the constraint solver's second warm start (DevState::act_hist), carried from step to step: 16 bits per geom
   unsigned int act_hist[kHistLds<TP>];
+  float* dual_glob[kDualGlob<TP> ? 1 : 0];      // kDualGlob: this workgroup's leg-factor scratch in HBM (set once per launch)
   int ncon, overflow;
   int iters;                            // SolveReport: Newton iterations | how the solve ended << 8 | pivots << 20
   float solve_resid;                    // ... and what its last elimination's target violates (nmf_dual.h)
@@ -1404,8 +1413,9 @@ __device__ __forceinline__ lds_cptr lds_pinned(const T* p) {
 //   kDualH: leg factors on vA..vD, the root's + reference accelerations + hinge sums on c_w (its rest hand-off slots are
 //           consumed before the root is eliminated).
 template <class TP> __device__ __forceinline__ float (*dual_leg(FlyLds<TP>& s))[8] {
-  if constexpr (kDualH<TP>) {
-    static_assert(!kDualH<TP> || 4 * TP::NV >= TP::NLEG * TP::NDL * 8, "leg factors do not fit vA..vD");
+  if constexpr (kDualGlob<TP>) return reinterpret_cast<float(*)[8]>(s.dual_glob[0]);      // HBM (generic pointer: callers go through gptr)
+  else if constexpr (kDualH<TP>) {
+    static_assert(!kDualH<TP> || kDualGlob<TP> || 4 * TP::NV >= TP::NLEG * TP::NDL * 8, "leg factors do not fit vA..vD");
     return reinterpret_cast<float(*)[8]>(&s.vA[0]);
   } else {
     static_assert(sizeof(float) * 8 * (TP::NLEG * TP::NDL + 6) <= sizeof(float) * 12 * kMaxCon, "articulated-body factors do not fit c_w + c_m3");
@@ -1540,7 +1550,8 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (kDual<TP>) {
       if (store) {      // rows 0..5: U / sqrt D; lanes 6, 7 of the group: 1 / sqrt D
         const float rs = __builtin_sqrtf(invDraw);
-        dual_leg(s)[L.lg * TP::NDL + d][L.r < 6 ? L.r : 6] = L.r < 6 ? Uraw * rs : rs;
+        if constexpr (kDualGlob<TP>) ((__attribute__((address_space(1))) float*)s.dual_glob[0])[(L.lg * TP::NDL + d) * 8 + (L.r < 6 ? L.r : 6)] = L.r < 6 ? Uraw * rs : rs;
+        else dual_leg(s)[L.lg * TP::NDL + d][L.r < 6 ? L.r : 6] = L.r < 6 ? Uraw * rs : rs;
       }
     }
   });
@@ -2705,6 +2716,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(wave
   unsigned int t_first = 0;
   if (chunked && lane == 0) t_first = atomicAdd(&st.csched->ticket, 1u);
   stage_launch_constants(s, m);
+  if constexpr (kDualGlob<TP>) { if (lane == 0) s.dual_glob[0] = st.dual_scratch + (size_t)blockIdx.x * kDualScratchFloats; }
   unsigned int t_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)t_first);
   STAGE_INIT();
   const int n_chunks = chunked ? st.n_chunks : 1;

@@ -45,4 +45,4 @@ for k, nm in enumerate(names):
     print(f"  {nm:14s} {int(sel.sum()):9d} ({sel.mean() * 100:8.4f} %)  contacts mean {st[sel, 0].mean():5.2f} max {int(st[sel, 0].max()):2d}  pivots mean {st[sel, 5].mean():5.1f} max {int(st[sel, 5].max()):2d}  iters mean {st[sel, 1].mean():.2f} max {int(st[sel, 1].max())}"
           + (f"  resid q50 {np.quantile(r, .5):.1e} q90 {np.quantile(r, .9):.1e} q99 {np.quantile(r, .99):.1e} max {r.max():.1e}  >1e-3: {int((r > 1e-3).sum())}" if k in (2, 3, 4, 5) else ""))
 piv = st[(bits & 1) == 1, 5].astype(int)
-print("pivots of contact-space solves: q50", int(np.quantile(piv, .5)), "q99", int(np.quantile(piv, .99)), "max", piv.max(), " >40:", int((piv > 40).sum()), ">44:", int((piv > 44).sum()), ">48:", int((piv > 48).sum()), ">52:", int((piv > 52).sum()))
+if piv.size: print("pivots of contact-space solves: q50", int(np.quantile(piv, .5)), "q99", int(np.quantile(piv, .99)), "max", piv.max(), " >40:", int((piv > 40).sum()), ">44:", int((piv > 44).sum()), ">48:", int((piv > 48).sum()), ">52:", int((piv > 52).sum()))

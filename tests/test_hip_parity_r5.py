@@ -187,7 +187,7 @@ def test_cpu_flavour_runs_noslip_on_every_kernel_family(torch_mod, oracle_lib, k
     """``flygym_amd.Simulation`` keeps ``option/noslip_iterations = 5`` (reference mujoco_globals.yaml:15) for EVERY model the
     reference's CPU class can step — rounds 3-4 had the pass in the contact-space solve only and stripped it elsewhere with the
     GPU class's warning.  Hybrid (ALL_BIOLOGICAL: contact-space pass while the contacts are on the legs, primal pass when head /
-    abdomen touch), ALL_POSSIBLE and a custom skeleton (primal loop + ``noslip_primal``), a tethered fly (six weld rows in A)
+    abdomen touch; ALL_POSSIBLE likewise, its leg factors in HBM), a custom skeleton (primal loop + ``noslip_primal``), a tethered fly (six weld rows in A)
     and a terrain world: no warning, every step with contacts takes the pass, and sampled steps match the oracle running the
     same pass from the same state — which differs from the oracle without it by far more."""
     torch = torch_mod
@@ -258,8 +258,8 @@ def test_cpu_flavour_runs_noslip_on_every_kernel_family(torch_mod, oracle_lib, k
         return
     assert compared >= 5 and worst < 2e-3 and changed > 5 * worst, (compared, worst, changed)
     assert ex["noslip_skipped"] == 0
-    if kind in ("all_possible", "custom_tree"):
-        assert primal_steps == compared and ex["contact_space"] == 0      # these skeletons have the primal loop only
+    if kind == "custom_tree":
+        assert primal_steps == compared and ex["contact_space"] == 0      # the general-tree kernels have the primal loop only
 
 
 def test_noslip_removes_the_creep_on_the_kernel(torch_mod, oracle_lib):
