@@ -866,6 +866,19 @@ extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w, float fov_deg, int n_omm) {
   auto& P = b->eye_plan;
   if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg && P.n_omm == n_omm) return 0;
+  // another id map (or lens): the previous plan's buffers go back (hipFree waits for the kernels that read them) — two
+  // renderers alternating on one batch rebuild every call, but no longer grow the batch's memory (round-4 advisor finding).
+  // The key is the id map's ADDRESS and shape: a caller must keep the tensor alive while it renders with it (EyeRenderer does).
+  {
+    auto drop = [&](void* q) {
+      if (!q) return;
+      auto it = std::find(b->allocs.begin(), b->allocs.end(), q);
+      if (it != b->allocs.end()) b->allocs.erase(it);
+      (void)hipFree(q);
+    };
+    for (int mode = 0; mode < 3; ++mode) { drop(P.visit[mode]); drop(P.cones[mode]); if (mode < 2) drop(P.chunk_cones[mode]); P.visit[mode] = nullptr; P.cones[mode] = nullptr; P.chunk_cones[mode] = nullptr; P.n_groups[mode] = 0; }
+    drop(P.slot_omm); P.slot_omm = nullptr; P.id_map = nullptr;
+  }
   const int n_pix = h * w, n_chunk = n_pix / 16;
   std::vector<int16_t> ids((size_t)n_pix);
   HIP_OK(hipMemcpy(ids.data(), id_map_dev, sizeof(int16_t) * (size_t)n_pix, hipMemcpyDeviceToHost));

@@ -24,5 +24,12 @@ timeout 300 $B --steps 20 --warmup 5 2>/dev/null | line "cpg 20-step launches (d
 timeout 300 $B --workload replay --steps 20 --warmup 5 2>/dev/null | line "replay 20-step launches"
 timeout 300 $B --vision resample --steps 200 2>/dev/null | line "config 3, vision resample"
 timeout 300 $B --vision render --steps 200 2>/dev/null | line "config 3, vision render"
+timeout 300 $B --vision render --eye-rays 16 --steps 200 2>/dev/null | line "config 3, vision render, 16 rays per ommatidium"
+timeout 300 $B --obs-every 1 2>/dev/null | line "cpg, observation block recorded every step (50-step launches)"
+timeout 300 $B --obs-every 1 --steps 20 --warmup 5 2>/dev/null | line "cpg, observation block recorded every step (20-step launches)"
+timeout 300 $B --obs-every 10 2>/dev/null | line "cpg, observation block recorded every 10th step"
+timeout 300 $B --steps-per-launch 1 --steps 100 2>/dev/null | line "cpg, one launch per step"
+for n in 512 1024 1536 2048; do timeout 300 $B --worlds-per-gpu $n 2>/dev/null | line "cpg worlds $n"; done
+timeout 300 $B --joint-preset all_possible --terrain mixed 2>/dev/null | line "all_possible, mixed terrain"
 } > gpurun_out/workloads.log 2>&1
 cat gpurun_out/workloads.log
