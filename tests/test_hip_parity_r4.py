@@ -46,6 +46,8 @@ def test_contact_space_solve_reaches_the_primal_loops_optimum(torch_mod, oracle_
     blob = lead.model.to_blob()
     it_sum = {k: 0.0 for k in sims}
     worst = {k: 0.0 for k in sims}
+    worst_between = {"": 0.0, "nohist": 0.0}
+    compared = skipped = 0          # oracle comparisons made / not made because the oracle's contact count differs (a near-tie at the margin)
     cur = 850
     for checkpoint in range(6):
         lead.step_replay(table, ids, cur, 37); cur += 37
@@ -65,17 +67,22 @@ def test_contact_space_solve_reaches_the_primal_loops_optimum(torch_mod, oracle_
         scale = np.abs(qacc["primal"]).max(axis=1)
         for name in ("", "nohist"):
             dev = np.abs(qacc[name] - qacc["primal"]).max(axis=1) / scale
-            assert np.median(dev) < 2e-4 and np.quantile(dev, 0.99) < 2e-3 and dev.max() < 2e-2, (name, np.sort(dev)[-4:])      # the stated tolerance (the primal loop is the less accurate of the two)
+            worst_between[name] = max(worst_between[name], float(dev.max()))
+            # the stated tolerance (the primal loop is the less accurate of the two); worst seen over 6 x 2048 states: 4e-3
+            assert np.median(dev) < 2e-4 and np.quantile(dev, 0.99) < 2e-3 and dev.max() < 1e-2, (name, np.sort(dev)[-4:])
         for w in np.random.default_rng(checkpoint).choice(n, size=12, replace=False):
             r = oracle_lib.Oracle(blob, "f64")
             for k in keys: r.arr(k)[:] = state[k][w].cpu().numpy().astype(np.float64)
             r.step_replay(table[w].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
-            if r.ints()["ncon"] != int(nc[""][w]): continue
+            if r.ints()["ncon"] != int(nc[""][w]): skipped += 1; continue
+            compared += 1
             a = r.arr("qacc")
             for name in sims:
                 worst[name] = max(worst[name], float(np.abs(qacc[name][w] - a).max() / np.abs(a).max()))
     its = {k: v / 6 for k, v in it_sum.items()}
-    print("iterations per step", {k or "default": round(v, 2) for k, v in its.items()}, "worst |qacc - oracle| / max", {k or "default": f"{v:.1e}" for k, v in worst.items()})
+    print("iterations per step", {k or "default": round(v, 2) for k, v in its.items()}, "worst |qacc - oracle| / max", {k or "default": f"{v:.1e}" for k, v in worst.items()},
+          "worst between solvers", {k or "default": f"{v:.1e}" for k, v in worst_between.items()}, "oracle comparisons", compared, "skipped", skipped)
+    assert skipped <= 2 and compared >= 70                         # 72 sampled states: nearly all of them are compared
     assert max(worst.values()) < 2e-3
     assert worst[""] < 2.0 * worst["primal"] + 1e-4                 # the contact-space solve is at least as accurate
     if preset == "legs_only":
@@ -148,7 +155,7 @@ def test_noslip_pass_of_the_cpu_flavour(torch_mod, oracle_lib):
     blob5 = batch.model.to_blob()
     world0 = make_model()[1]; world0.noslip_iterations = 0
     blob0 = world0.compile_model().to_blob()
-    worst, changed, cur = 0.0, 0.0, 700
+    worst, changed, cur, skipped = 0.0, 0.0, 700, 0
     for k in range(12):
         batch.step_replay(table, ids, cur, 23); cur += 23
         state = {kk: batch.field(kk)[0].cpu().numpy().astype(np.float64) for kk in keys}
@@ -161,12 +168,13 @@ def test_noslip_pass_of_the_cpu_flavour(torch_mod, oracle_lib):
             for kk in keys: r.arr(kk)[:] = state[kk]
             r.step_replay(table[0].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
             refs[name] = r
-        if refs["noslip"].ints()["ncon"] != int(batch.field("stats")[0, 0].item()): continue
+        if refs["noslip"].ints()["ncon"] != int(batch.field("stats")[0, 0].item()): skipped += 1; continue
         scale = np.abs(refs["noslip"].arr("qacc")).max()
         worst = max(worst, np.abs(qacc - refs["noslip"].arr("qacc")).max() / scale)
         changed = max(changed, np.abs(refs["noslip"].arr("qacc") - refs["plain"].arr("qacc")).max() / scale)
+    assert skipped <= 1, skipped                                   # (a contact at the margin may differ: at most one of the 12 samples)
     assert worst < 2e-3 and changed > 10 * worst, (worst, changed)
-    assert int(batch.field("stats_sum")[0, 3].item()) == 0         # no step fell outside the contact-space solve
+    assert int(batch.field("stats_sum")[0, 3].item()) == 0 and batch.get_solver_exits()["noslip_skipped"] == 0         # every step with contacts took the pass
 
 
 def test_cells_narrower_than_a_hulls_footprint(torch_mod, oracle_lib):
@@ -294,9 +302,9 @@ def test_a_tie_row_does_not_send_the_solve_into_the_noise(torch_mod, oracle_lib,
 
 
 def test_cpu_flavour_runs_the_noslip_pass_on_every_step(torch_mod, oracle_lib):
-    """7 % of a walking fly's steps have 13-15 contacts — more than the batched kernels' contact-space solve takes (12: the
-    triangle of A in LDS at eight flies per CU).  The CPU flavour steps on kernels with room for 16 (``nmf::Wide``, six flies
-    per CU — irrelevant for one world), so its noslip pass, which lives in that solve, runs on EVERY step.  256 walkers:
+    """7 % of a walking fly's steps have 13-15 contacts — more than rounds 3-4's contact-space solve took at eight flies per CU (12:
+    the triangle of A by rows).  Since round 5 the solve keeps the Gram matrix of the contact directions and takes 16 on every
+    kernel, so the CPU flavour's noslip pass, which lives in that solve, runs on EVERY step.  256 walkers:
     no step without the pass over 3000 steps although the contact count passes 12 on the way; steps with 13 contacts and more
     against the oracle running the same pass."""
     torch = torch_mod
@@ -313,7 +321,7 @@ def test_cpu_flavour_runs_the_noslip_pass_on_every_step(torch_mod, oracle_lib):
     sim.warmup(); sim.step_replay(table, ids, 0, 850)
     keys = ("qpos", "qvel", "ctrl", "qacc_warmstart")
     blob = sim.model.to_blob()
-    cur, many, worst = 850, 0, 0.0
+    cur, many, worst, compared, skipped = 850, 0, 0.0, 0, 0
     for k in range(40):
         sim.step_replay(table, ids, cur, 49); cur += 49
         state = {kk: sim.field(kk).clone() for kk in keys}
@@ -326,10 +334,12 @@ def test_cpu_flavour_runs_the_noslip_pass_on_every_step(torch_mod, oracle_lib):
             r = oracle_lib.Oracle(blob, "f64", cpu_flavour=True)
             for kk in keys: r.arr(kk)[:] = state[kk][w].cpu().numpy().astype(np.float64)
             r.step_replay(table[w].cpu().numpy(), ids.cpu().numpy(), cur - 1, 1)
-            if r.ints()["ncon"] != int(stats[w, 0]): continue
+            if r.ints()["ncon"] != int(stats[w, 0]): skipped += 1; continue
+            compared += 1
             a = r.arr("qacc")
             worst = max(worst, float(np.abs(sim.field("qacc")[w].cpu().numpy() - a).max() / np.abs(a).max()))
     ss = sim.field("stats_sum").cpu().numpy()
     assert many >= 20, many                                           # the walk does pass 12 contacts
-    assert int(ss[:, 3].sum()) == 0 and int(ss[:, 0].min()) == cur + 500      # ... and no step went without the pass
+    assert compared >= 20 and skipped <= max(2, compared // 10), (compared, skipped)
+    assert int(ss[:, 3].sum()) == 0 and int(ss[:, 13].sum()) == 0 and int(ss[:, 0].min()) == cur + 500      # ... and no step went without the pass
     assert 0.0 < worst < 2e-3, worst
