@@ -172,7 +172,10 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
 #ifdef NMF_DUAL_NOWARM
   constexpr bool kWarm = false;
 #else
-  constexpr bool kWarm = kDualS<TP>;      // warm-start term c e (see kDualS / kDualH)
+  // warm-start term c e (see kDualS / kDualH).  (Round 5 measured it on the hybrid kernels too, with the leg factors in HBM and
+  // vA free for e: ALL_BIOLOGICAL 2.27 -> 1.92 eliminations per step but 8 bytes over its LDS budget, seven flies per CU, 30.7 ->
+  // 26.2 M; ALL_POSSIBLE 2.14 -> 1.85 eliminations, 19.1 -> 18.5 M: e's twists and e.M.e over 210 dofs cost more than they save.)
+  constexpr bool kWarm = kDualS<TP>;
 #endif
   const Frame fr0 = ld_frame(s, m);
   float (*const DFleg)[8] = dual_leg(s);

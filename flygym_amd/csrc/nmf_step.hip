@@ -2416,17 +2416,25 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     const int ol = opaque(lane);
     if (lane < kMaxCon) st.contact_geom[(size_t)w * kMaxCon + ol] = c.on ? (float)info_geom(c.info) : -1.f;
   }
+  // the contacts of every leg sensor as a bit mask: lane = contact tells its sensor, lane s < 6 keeps sensor s's mask and walks
+  // its own one or two contacts (in contact order: the sums are those of a walk over the whole list) instead of all of them
+  unsigned long long smask = 0ull;
+  if (last || rec) {
+    const int my_s = lane < ncon ? info_sensor(s.c_info[lane]) : -1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { const unsigned long long bq = __ballot(my_s == q); smask = lane == q ? bq : smask; }
+  }
   for (int dest = 0; dest < 2; ++dest) {
     float* out = dest == 0 ? (last ? &st.sensordata[(size_t)w * 96] : nullptr) : (rec ? rec + 2 * st.ring_nj + st.ring_nact : nullptr);
     if (!out) continue;
     const int ol = opaque(lane);
     for (int i = ol; i < 96; i += kWave) out[i] = 0.f;
     WSYNC();
-    if (m.nsensor && lane < 6 && ncon > 0) {
+    if (m.nsensor && lane < 6 && smask) {
       float wsum = 0.f; V3 pc = v3(0, 0, 0), pm = v3(0, 0, 0), F = v3(0, 0, 0), Tq = v3(0, 0, 0); int cnt = 0;
       Frame f1 = fr;                       // frame of the leg's first contact (what the sensor reports as normal / tangent)
-      for (int cc = 0; cc < ncon; ++cc) {
-        if (info_sensor(s.c_info[cc]) != lane) continue;
+      for (unsigned long long mk = smask; mk; mk &= mk - 1ull) {
+        const int cc = __ffsll((long long)mk) - 1;
         V3 f = ld3(&s.c_w[cc][3]);
         const Frame cf = walls ? contact_frame(info_fid(s.c_info[cc]), fr) : fr;
         if (cnt == 0) f1 = cf;
@@ -2434,22 +2442,20 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         V3 p = ld3(s.c_r[cc]);
         wsum += fn; pc = pc + fn * p; pm = pm + p; cnt++;
       }
-      if (cnt) {
-        pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
-        for (int cc = 0; cc < ncon; ++cc) {
-          if (info_sensor(s.c_info[cc]) != lane) continue;
-          V3 f = ld3(&s.c_w[cc][3]);
-          F = F + f;
-          Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
-        }
-        float* o16 = out + 16 * ol;
-        V3 o = ld3(s.xpos()[0]);
-        if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
-          F = v3(dot(f1.n, F), dot(f1.t1, F), dot(f1.t2, F));
-          Tq = v3(dot(f1.n, Tq), dot(f1.t1, Tq), dot(f1.t2, Tq));
-        }
-        o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, f1.n); st3(o16 + 13, f1.t1);
+      pc = wsum > 0.f ? (1.0f / wsum) * pc : (1.0f / (float)cnt) * pm;
+      for (unsigned long long mk = smask; mk; mk &= mk - 1ull) {
+        const int cc = __ffsll((long long)mk) - 1;
+        V3 f = ld3(&s.c_w[cc][3]);
+        F = F + f;
+        Tq = Tq + cross(ld3(s.c_r[cc]) - pc, f);
       }
+      float* o16 = out + 16 * ol;
+      V3 o = ld3(s.xpos()[0]);
+      if (m.sem_sensor_contact_frame) {    // net force / torque expressed in the contact frame (normal, t1, t2)
+        F = v3(dot(f1.n, F), dot(f1.t1, F), dot(f1.t2, F));
+        Tq = v3(dot(f1.n, Tq), dot(f1.t1, Tq), dot(f1.t2, Tq));
+      }
+      o16[0] = (float)cnt; st3(o16 + 1, F); st3(o16 + 4, Tq); st3(o16 + 7, pc + o); st3(o16 + 10, f1.n); st3(o16 + 13, f1.t1);
     }
   }
   WSYNC();
