@@ -253,6 +253,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
 
   // ---- responses of the unit forces, lane = (contact, direction n / t1 / t2)
   float ur[6], ul[NDL];
+  SUB_T0();
   {
     const V3 dm = k == 0 ? cf.n : (k == 1 ? cf.t1 : cf.t2);
     const V3 tq = cross(r, dm);
@@ -286,6 +287,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       for (int q = 0; q < 6; ++q) w[q] = fmaf(-f[q], u, w[q]);
     });
   }
+  SUB(43);
   // ---- G = Gram matrix of the direction responses, every unordered pair of contacts once: in round t the quad of contact c
   // takes contact c - t (cyclically over the ncon contacts), whose three vectors come through ds_bpermute — lane (c, k) fetches
   // direction k — and pairs every one of them with its own: the partner's other two directions reach the lane through a
@@ -308,6 +310,9 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       int base = ge ? 9 * (cc * (cc + 1) / 2 + c2) + 3 * kd : 9 * (c2 * (c2 + 1) / 2 + cc) + kd;
       const int stride = ge ? 1 : 3;
       asm("" : "+v"(base));
+      // (Round 5 tried to skip the leg parts — NDL of the 6 + NDL numbers, which couple contacts of one leg only — in the rounds
+      // that cannot pair two contacts of a leg: any root-only variant of this round, as a second instantiation or under a
+      // wave-uniform branch, raised the kernel's spilled registers from 12 to 50 and cost 6 %.)
       static_for<3>([&](auto PP) {
         constexpr int p = decltype(PP)::value;
         auto rot = [&](float v) {      // the fetched vector of direction (k + p) mod 3
@@ -326,6 +331,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     }
   }
   WSYNC();
+  SUB(44);
   STAGE(9);
 
   // ---- Newton iterations on the rows
@@ -520,18 +526,42 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // ---- qacc = qacc_smooth + c e + M^-1 J^T lambda: the rows' responses summed per hinge (root axes: wave sums; leg hinges:
   // LDS adds, the rows of a leg are few), then root-to-leaf over the factors
   float* const acc = dual_acc(s);                // [NLEG * NDL leg hinges | 6 root axes]
-  for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
-  WSYNC();
+  // Leg hinges: the direction lanes put their products into G's LDS (dead from here on: the elimination and the noslip pass
+  // are over) and lane (leg, hinge) adds those of its leg's contacts — contacts are sorted by body, a leg's are one range —
+  // in contact order.  (Rounds 4-5a: one LDS float atomic per hinge and direction lane, eleven instructions that serialise on
+  // the lanes of a leg: 1.1 k cycles, and a pass to clear the sums first.)  Skeletons whose products do not fit G keep the atomics.
+  constexpr bool kProdInG = 64 * NDL <= dual_g_floats(NC);
+  SUB_RESET();
+  if constexpr (!kProdInG) {
+    for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
+    WSYNC();
+  }
+  SUB(36);
   {
     // the rows' multipliers as forces along the contact's directions (lane k < 3 of a quad: n, t1, t2): the response vectors
     // in registers are the directions'
     const float l0 = on ? lam : 0.f;
     const float q0 = NMF_DPP(l0, 0x00), q1 = NMF_DPP(l0, 0x55), q2 = NMF_DPP(l0, 0xAA), q3 = NMF_DPP(l0, 0xFF);
     const float fdir = k == 0 ? (q0 + q1) + (q2 + q3) : k == 1 ? mu * (q0 - q1) : k == 2 ? mu * (q2 - q3) : 0.f;
-    if (fdir != 0.f && leg >= 0) {
+    if constexpr (kProdInG) {
+      WSYNC();      // (G's last readers are done)
+      if (on && k < 3) {
+#pragma unroll
+        for (int d = 0; d < NDL; ++d) Gm[lane * NDL + d] = fdir * ul[d];
+      }
+      WSYNC();
+      for (int i = lane; i < NLEG * NDL; i += kWave) {
+        const int g = i / NDL, d = i - g * NDL;
+        const int c0 = (int)s.body_cstart[TP::LB0 + g * TP::NBL], c1 = (int)s.body_cstart[TP::LB0 + (g + 1) * TP::NBL];
+        float sum = 0.f;
+        for (int c = c0; c < c1; ++c) sum += (Gm[(4 * c) * NDL + d] + Gm[(4 * c + 1) * NDL + d]) + Gm[(4 * c + 2) * NDL + d];
+        acc[i] = sum;
+      }
+    } else if (fdir != 0.f && leg >= 0) {
 #pragma unroll
       for (int d = 0; d < NDL; ++d) if (d <= dlast) (void)__hip_atomic_fetch_add(&acc[leg * NDL + d], fdir * ul[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    SUB(37);
     float rsum[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) rsum[i] = wave_sum(fdir * ur[i]);
@@ -543,12 +573,27 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     }
   }
   WSYNC();
+  SUB(38);
   {
+    // (everything the two dependent chains below read is fetched first: with the reads inside the chain every step waited for
+    // its own LDS round trip — 170-200 cycles per hinge against the 60 of the group sum it is made of)
     const LaneRole L = lane_role<TP>(lane);
+    const int jb = TP::LD0 + L.lg * NDL;
+    float rf6[6], rfr[6], racc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { rf6[i] = DFroot[i][6]; rfr[i] = L.mask * DFroot[i][L.rr]; racc[i] = acc[NLEG * NDL + i]; }
+    float lf6[NDL], lfr[NDL], lacc[NDL], lS[NDL], lbase[NDL];
+#pragma unroll
+    for (int d = 0; d < NDL; ++d) {
+      if constexpr (kDualGlob<TP>) { const gptr<float> q = G((const float*)DFleg) + (L.lg * NDL + d) * 8; lf6[d] = q[6]; lfr[d] = L.mask * q[L.rr]; }
+      else { lf6[d] = DFleg[L.lg * NDL + d][6]; lfr[d] = L.mask * DFleg[L.lg * NDL + d][L.rr]; }
+      lacc[d] = acc[L.lg * NDL + d]; lS[d] = s.S[jb + d][L.rr];
+      lbase[d] = s.qacc_smooth[jb + d] + (kWarm ? c_ws * s.vA[jb + d] : 0.f);
+    }
     float a = 0.f, xw[6];
     static_for<6>([&](auto II) {
       constexpr int i = 5 - decltype(II)::value, e = dual_root_axis(i);
-      const float xe = DFroot[i][6] * (acc[NLEG * NDL + i] - grp8_sum(L.mask * DFroot[i][L.rr] * a));
+      const float xe = rf6[i] * (racc[i] - grp8_sum(rfr[i] * a));
       xw[e] = xe;
       a = L.rr == e ? a + xe : a;
     });
@@ -556,16 +601,14 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       s.qacc[lane] = s.qacc_smooth[lane] + (kWarm ? c_ws * s.vA[lane] : 0.f) + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
       s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + (kWarm ? c_ws * s.vA[3 + lane] : 0.f) + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
     }
-    const int jb = TP::LD0 + L.lg * NDL;
+    SUB(39);
     static_for<NDL>([&](auto DD) {
       constexpr int d = decltype(DD)::value;
-      float f6, fr;
-      if constexpr (kDualGlob<TP>) { const gptr<float> q = G((const float*)DFleg) + (L.lg * NDL + d) * 8; f6 = q[6]; fr = q[L.rr]; }
-      else { f6 = DFleg[L.lg * NDL + d][6]; fr = DFleg[L.lg * NDL + d][L.rr]; }
-      const float xj = f6 * (acc[L.lg * NDL + d] - grp8_sum(L.mask * fr * a));
-      s.qacc[jb + d] = s.qacc_smooth[jb + d] + (kWarm ? c_ws * s.vA[jb + d] : 0.f) + xj;
-      a = fmaf(xj, s.S[jb + d][L.rr], a);
+      const float xj = lf6[d] * (lacc[d] - grp8_sum(lfr[d] * a));
+      s.qacc[jb + d] = lbase[d] + xj;
+      a = fmaf(xj, lS[d], a);
     });
+    SUB(40);
     if constexpr (kDualH<TP>) {
       // the rest of the body follows the root: its accelerations are the unconstrained ones + the response of the smooth
       // solve's cached factors to the root's change (one root-to-leaf pass, as at the end of the primal loop's reduced problem)

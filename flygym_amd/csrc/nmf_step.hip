@@ -64,7 +64,7 @@ constexpr float kDualResidMax = 1e-3f;
 // Optional per-stage cycle accounting (s_memtime deltas of wave 0 / lane 0), built only with
 // -DNMF_STAGE_PROFILE into a separate diagnostic library; the product build has no trace of it.
 #ifdef NMF_STAGE_PROFILE
-#define NMF_NSTAGE 36
+#define NMF_NSTAGE 48
 __device__ unsigned long long g_stage_cycles[NMF_NSTAGE];
 struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE_INIT() __shared__ unsigned long long stage_acc_[NMF_NSTAGE]; StageClock sc_; sc_.acc = stage_acc_; \
@@ -75,6 +75,7 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define STAGE(k) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sc_.acc[k] += t_ - sc_.last; sc_.last = clock64(); } } while (0)
 // sub-stages inside a non-inlined function (block 0 only, straight to the global accumulators 18..27)
 #define SUB_T0() unsigned long long sub_t_ = clock64()
+#define SUB_RESET() sub_t_ = clock64()
 #define SUB(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); g_stage_cycles[k] += t_ - sub_t_; sub_t_ = clock64(); } } while (0)
 #define SUB_COUNT(k, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stage_cycles[k] += (unsigned long long)(n); } while (0)
 #define SUBH_T0() unsigned long long subh_t_ = clock64()
@@ -83,6 +84,7 @@ struct StageClock { unsigned long long last; unsigned long long* acc; };
 #define SUBH_T0()
 #define SUBH(k)
 #define SUB_T0()
+#define SUB_RESET()
 #define SUB(k)
 #define SUB_COUNT(k, n)
 #define STAGE_INIT()

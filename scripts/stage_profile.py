@@ -37,17 +37,18 @@ else:
 ids = sim._ids_by_fly[fly.name]["actuators"][ActuatorType.POSITION]
 sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
 sim.step(500); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 36)()
-L.nmf_debug_stage_cycles(buf, 36, 1)
+buf = (ctypes.c_ulonglong * 48)()
+L.nmf_debug_stage_cycles(buf, 48, 1)
 steps = next((int(a.split('=')[1]) for a in sys.argv if a.startswith('--steps=')), 500)
 sim.step_replay(table, ids, 0, steps); torch.cuda.synchronize()
-L.nmf_debug_stage_cycles(buf, 36, 1)
+L.nmf_debug_stage_cycles(buf, 48, 1)
 names = ["ctrl load", "kinematics", "inertia", "collision", "contact params", "velocity+bias", "actuation+project",
          "ABA smooth", "solver start (primal: first gradient; dual: j0, je, e.M.e)", "primal: test/exit; dual: responses + A", "primal: ABA(H); dual: elimination", "newton: jv, g1, g2 / row sums", "newton: linesearch",
          "newton: move", "final forces (dual: qacc expansion + wrenches)", "integrate (ABA Euler)", "write outputs", "sensors",
          "(all ABA) rest up", "(all ABA) legs + root", "(all ABA) rest down",
          "(collision) parameters + cull + capsules", "(collision) hull scans", "(collision) slots + contact ranges", "(collision) hulls scanned per step", "(collision) scans without a contact per step", "(collision) their summed dmin [nm]", "(collision) scans with contacts per step",
-         "(hull) setup", "(hull) first scan + argmin", "(hull) patch scans", "(hull) contact output", "(hull) one-cell hulls per step", "(hull) vertices scanned per step", "(hull) patch scans over the candidate list per step", "-"]
+         "(hull) setup", "(hull) first scan + argmin", "(hull) patch scans", "(hull) contact output", "(hull) one-cell hulls per step", "(hull) vertices scanned per step", "(hull) patch scans over the candidate list per step", "-",
+         "(expansion) clear the hinge sums", "(expansion) direction forces + LDS adds per hinge", "(expansion) six wave sums for the root", "(expansion) root", "(expansion) legs, root to leaf", "-", "-", "(contact space) direction responses, leaf to root", "(contact space) Gram matrix of the directions"]
 cyc = np.array(list(buf)[:len(names)], dtype=np.float64) / steps
 tot = cyc[:18].sum()
 print(f"n_worlds {n}: wave-0 cycles per step = {tot:.0f}  (iters {sim.field('stats')[:,1].mean().item():.2f}, contacts {sim.field('stats')[:,0].mean().item():.2f})")
