@@ -1181,9 +1181,12 @@ __device__ void sweep_twists(FlyLds<TP>& s, const float* x, float (*T)[row_width
   for (int j = 0; j < 6; ++j) t += x[j] * s.S[j][L.rr];
   if (lane < 6) T[0][lane] = t;
   const int j0 = TP::LD0 + L.lg * TP::NDL, b0 = TP::LB0 + L.lg * TP::NBL;
+  float px[TP::NDL];      // (the chain's inputs first: see the velocity stage)
+#pragma unroll
+  for (int d = 0; d < TP::NDL; ++d) px[d] = x[j0 + d] * s.S[j0 + d][L.rr];
   static_for<TP::NDL>([&](auto D) {
     constexpr int d = decltype(D)::value;
-    t += x[j0 + d] * s.S[j0 + d][L.rr];
+    t += px[d];
     if constexpr (TP::is_last(d)) T[b0 + TP::lbody(d)][L.rr] = t;
   });
   WSYNC();
@@ -1201,11 +1204,16 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_widt
   const LaneRole L = lane_role<TP>(lane);
   const int b0 = TP::LB0 + L.lg * TP::NBL;
   float acc = 0.f;
-  static_for<TP::NBL>([&](auto I) {
-    constexpr int l = TP::NBL - 1 - decltype(I)::value;
-    acc += W[b0 + l][L.rr];
-    W[b0 + l][L.rr] = acc;
-  });
+  {
+    float pw[TP::NBL];
+#pragma unroll
+    for (int l = 0; l < TP::NBL; ++l) pw[l] = W[b0 + l][L.rr];
+    static_for<TP::NBL>([&](auto I) {
+      constexpr int l = TP::NBL - 1 - decltype(I)::value;
+      acc += pw[l];
+      W[b0 + l][L.rr] = acc;
+    });
+  }
   // root = own + the six leg bases (group sums are free: every group holds its base in acc)
   WSYNC();
   if (lane < 6) {
@@ -1518,37 +1526,58 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
   SUB(18);
   float IA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float pA = 0.f;
-  // ---- backward sweep along the leg
+  // ---- backward sweep along the leg.  What a hinge reads — its motion subspace, diagonal term and force, and at a body's last
+  // hinge the body's inertia row — does not depend on the chain, but LDS takes a wave's operations in order and the sweep also
+  // stores (the factors the contact-space solve keeps): a read issued where it is used waits for its own round trip, three
+  // times per hinge.  So the reads run ONE HINGE AHEAD of the arithmetic (software pipeline, written out: the stores may alias
+  // for all the compiler knows, it will not move a read across them).
+  float n_sj[6], n_sown = 0.f, n_delta = 0.f, n_tau = 0.f, n_row[6];
+  auto fetch_hinge = [&](auto DN) {
+    constexpr int dn = decltype(DN)::value;
+#pragma unroll
+    for (int i = 0; i < 6; i++) n_sj[i] = Sleg[dn * SW + i];
+    n_sown = Sown[dn * SW];
+    n_delta = dof_delta(s, m, j0 + dn, hdamp);
+    n_tau = tau[j0 + dn];
+    if constexpr (TP::is_last(dn) && kHasIsym<TP>) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) n_row[c] = s.Isym[b0 + TP::lbody(dn)][so[c]];
+    }
+  };
+  fetch_hinge(std::integral_constant<int, TP::NDL - 1>{});
   static_for<TP::NDL>([&](auto DD) {
     constexpr int d = TP::NDL - 1 - decltype(DD)::value;
-    const int j = j0 + d;
+    float sj[6], row[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sj[i] = n_sj[i]; row[i] = n_row[i]; }
+    const float sown = n_sown, delta = n_delta, tj = n_tau;
+    if constexpr (d > 0) fetch_hinge(std::integral_constant<int, (d > 0 ? d - 1 : 0)>{});
     if constexpr (TP::is_last(d)) {          // entering a new body (going towards the root)
       const int b = b0 + TP::lbody(d);
       if constexpr (kHasIsym<TP>) {
-        float row[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) row[c] = s.Isym[b][so[c]];
         if constexpr (kDual<TP>) {
-          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
+          if (withF) {
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
+          }
         }
         if (withK) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(row, s, c, KL, fr, L.rr, walls);
         add6(IA, row);
       } else {
         add_inertia_row(IA, s, b, IM);
         if constexpr (kDual<TP>) {
-          if (withF) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
+          if (withF) {
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) pA -= dual_wrench(s)[c][L.rr];
+          }
         }
         if (withK) for (int c = cs[TP::lbody(d)]; c < cs[TP::lbody(d) + 1]; ++c) add_contact_K_row(IA, s, c, KL, fr, L.rr, walls);
       }
     }
-    float sj[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) sj[i] = Sleg[d * SW + i];
-    const float sown = Sown[d * SW];
     const float sr = kShadow0 ? sown : L.mask * sown;
     if constexpr (kKeepS) Sreg[d] = sown;        // shadow rows: zero (kShadow0), else row 5's (same T word, same value)
     float Uraw, invDraw;
-    aba_step_scaled<kShadow0>(IA, pA, sj, sr, L.mask, dof_delta(s, m, j, hdamp), tau[j], Ureg[d], ureg[d], Uraw, invDraw);
+    aba_step_scaled<kShadow0>(IA, pA, sj, sr, L.mask, delta, tj, Ureg[d], ureg[d], Uraw, invDraw);
     if constexpr (kDual<TP>) {
       if (store) {      // rows 0..5: U / sqrt D; lanes 6, 7 of the group: 1 / sqrt D
         const float rs = __builtin_sqrtf(invDraw);
@@ -2064,12 +2093,19 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 #pragma unroll
     for (int j = 3; j < 6; ++j) { if (lane < 6) vb[j][lane] = vt; v += s.qvel[j] * s.S[j][L.rr]; }
     if (lane < 6) s.W[0][lane] = v;
-    static_for<TP::NDL>([&](auto D) {
-      constexpr int d = decltype(D)::value;
-      vb[j0 + d][L.rr] = v;
-      v += s.qvel[j0 + d] * s.S[j0 + d][L.rr];
-      if constexpr (TP::is_last(d)) s.W[b0 + TP::lbody(d)][L.rr] = v;
-    });
+    {
+      // (the chain's inputs first: LDS takes a wave's operations in order, so a read issued behind the chain's stores waits
+      // for its own round trip at every hinge)
+      float pq[TP::NDL];
+#pragma unroll
+      for (int d = 0; d < TP::NDL; ++d) pq[d] = s.qvel[j0 + d] * s.S[j0 + d][L.rr];
+      static_for<TP::NDL>([&](auto D) {
+        constexpr int d = decltype(D)::value;
+        vb[j0 + d][L.rr] = v;
+        v += pq[d];
+        if constexpr (TP::is_last(d)) s.W[b0 + TP::lbody(d)][L.rr] = v;
+      });
+    }
     WSYNC();
     // reference acceleration of the contact rows needs the body velocities (still in W here)
     if (c.on) {
@@ -2090,11 +2126,16 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
 #pragma unroll
     for (int j = 3; j < 6; ++j) a += vb[j][L.rr];
     if (lane < 6) s.T[0][lane] = a;
-    static_for<TP::NDL>([&](auto D) {
-      constexpr int d = decltype(D)::value;
-      a += vb[j0 + d][L.rr];
-      if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
-    });
+    {
+      float pv[TP::NDL];
+#pragma unroll
+      for (int d = 0; d < TP::NDL; ++d) pv[d] = vb[j0 + d][L.rr];
+      static_for<TP::NDL>([&](auto D) {
+        constexpr int d = decltype(D)::value;
+        a += pv[d];
+        if constexpr (TP::is_last(d)) s.T[b0 + TP::lbody(d)][L.rr] = a;
+      });
+    }
   }
   WSYNC();
   for (int b = lane; b < s.nb(); b += kWave) {
