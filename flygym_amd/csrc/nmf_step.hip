@@ -2444,8 +2444,11 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         for (int k = 0; k < 4; k++) ff[k] = nsbuf[kNoslipRows * kNoslipRows + kNoslipRows + 4 * opaque(lane) + k];
       }
       contact_project<TP, false>(s, c, wr, fr, ff, -wr.D * wr.jar, 0.f, m, lane, walls, [&](int j, float v) { s.vD[j] = v; s.vA[j] = s.qfrc_smooth[j] + v; });
-      aba_solve<TP, WELD>(s, V_A, V_QACC, false, 0.f, m, lane);
+      // (into vB: qacc keeps the main solver's result, which is the next step's warm start — MuJoCo saves it before its noslip
+      // pass, mj_fwdConstraint; the acceleration with the noslip forces is a pure output of the launch's last step)
+      aba_solve<TP, WELD>(s, V_A, V_B, false, 0.f, m, lane);
       contact_reload(c, s, lane);
+      if (last) { for (int j = lane; j < s.nv(); j += kWave) st.qacc[(size_t)w * s.nv() + opaque(j)] = s.vB[j]; }
       report &= ~kExitNoNoslip;
     }
   }
@@ -2604,11 +2607,14 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
     return;
   }
   if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < hist_words<TP>(m) ? s.act_hist[lane < kHistLds<TP> ? lane : 0] : 0u; }
+  // CPU flavour, last step in contact and solved by the primal loop: its noslip pass has written the step's acceleration itself
+  // (s.qacc is the warm start)
+  const bool noslip_qacc = m.noslip_iter > 0 && st.noslip_buf && s.ncon > 0 && ((unsigned int)s.iters & kExitPrimal) != 0u;
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);
     st_state(&st.qacc_ws[(size_t)w * s.nv() + i], s.qacc[i]);
-    if (final) st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
+    if (final && !noslip_qacc) st.qacc[(size_t)w * s.nv() + i] = s.qacc[i];
   }
   for (int i = lane; i < m.nu; i += kWave) {
     st_state(&st.ctrl[(size_t)w * m.nu + i], s.ctrl[i]);

@@ -1118,9 +1118,10 @@ EXPORT void SFX(nmfo_forward)(const void* mv, void* dv) {
   memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(real) * (size_t)nv);
   solve_tree(m, d->L, d->Ld, d->qacc_smooth);
   solve_constraints(m, d);
+  /* the next step's warm start is the main solver's result: MuJoCo saves it before the noslip post-pass (mj_fwdConstraint) */
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * (size_t)nv);
   noslip(m, d);
   contact_sensors(m, d);
-  memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * (size_t)nv);
 }
 
 static void integrate(const omodel* m, odata* d) {
