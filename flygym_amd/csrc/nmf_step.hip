@@ -1711,6 +1711,9 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
 }
 
 // ------------------------------------------------------------------ contact rows held in registers
+// leg-chain kernels (star topology, no rest of the body): the passes over the dofs visit dof lane + 64 i in turn i
+template <class TP> constexpr bool dual_hybrid_free() { if constexpr (TP::kStar) return TP::REST_V == 0; else return false; }
+template <class TP> constexpr int spring_regs() { if constexpr (dual_hybrid_free<TP>()) return (TP::NV + kWave - 1) / kWave; else return 1; }
 struct ContactRegs {
   bool on;
   V3 r;
@@ -2006,18 +2009,29 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     if (walls) rows_of_twist(c, contact_frame(info_fid(c.info), fr), t, out); else rows_of_twist(c, fr, t, out);
   };
   c.on = lane < ncon;
+  // the contact's pair parameters come from the model (L2): loaded here, turned into the row constants behind the first velocity
+  // pass (leg-chain kernels), which needs none of them
+  float cp_solref[2] = {0.f, 0.f}, cp_solimp[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, cp_tran = 0.f;
+  int cp_info0 = 0;
   if (c.on) {
-    const int info0 = s.c_info[lane];
-    c.r = ld3(s.c_r[lane]); c.body = info_body(info0); c.geom = info_geom(info0); c.dist = s.c_D[lane];
-    int g = c.geom;
-    c.info = info_pack(g, m.geom_sensor[g], c.body, 0) | (info0 & (7 << 24));      // the contact's frame id stays with it
+    cp_info0 = s.c_info[lane];
+    c.r = ld3(s.c_r[lane]); c.body = info_body(cp_info0); c.geom = info_geom(cp_info0); c.dist = s.c_D[lane];
+    const int g = c.geom;
+    c.info = info_pack(g, m.geom_sensor[g], c.body, 0) | (cp_info0 & (7 << 24));      // the contact's frame id stays with it
     c.mu = m.pair_friction[5 * g];
     c.margin = m.pair_margin[g];
-    const float* solref = &m.pair_solref[2 * g];
-    const float* solimp = &m.pair_solimp[5 * g];
+    cp_solref[0] = m.pair_solref[2 * g]; cp_solref[1] = m.pair_solref[2 * g + 1];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cp_solimp[i] = m.pair_solimp[5 * g + i];
+    cp_tran = m.geom_invweight0[g];
+  }
+  auto contact_constants = [&]() {
+    if (!c.on) return;
+    const float* solref = cp_solref;
+    const float* solimp = cp_solimp;
     float r = c.dist - c.margin;
     c.imp = impedance(solimp, r);
-    float tran = m.geom_invweight0[g];
+    float tran = cp_tran;
     float diagA = tran + c.mu * c.mu * tran;
     float Rn = fmaxf((1.f - c.imp) * diagA / c.imp, kMinVal);
     float Rpy = fmaxf(m.sem_pyramid_plain ? Rn : 2.f * c.mu * c.mu * Rn, kMinVal);
@@ -2030,7 +2044,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       c.B = 2.0f / (dmax * tc);
     } else { c.K = -tc / (solimp[1] * solimp[1]); c.B = -dr / solimp[1]; }
     s.c_D[lane] = c.D; s.c_mu[lane] = c.mu; s.c_info[lane] = c.info;
-  }
+  };
 
   // ---- tether weld rows (lanes 48..53); without a tether their stiffness and wrench are zero
   WeldRow wr;
@@ -2058,6 +2072,28 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     s.weld_w[wr.comp] = 0.f;
   }
   STAGE(4);
+  // ---- launch constants the actuation and passive-force passes need (the lane's actuator, its dofs' springs): loaded here, a
+  // stage ahead of their use — the round trip to L2 runs behind the velocity passes instead of in front of the actuation
+  struct ActModel { int lim_f, lim_c, type, trn; float gain, b0, b1, c0, c1, f0, f1; };
+  auto load_act = [&](int u) {
+    ActModel a;
+    a.lim_f = m.act_limited[2 * u]; a.lim_c = m.act_limited[2 * u + 1]; a.type = m.act_type[u]; a.trn = m.act_trn[u];
+    a.gain = m.act_gain[u]; a.b0 = m.act_bias[2 * u]; a.b1 = m.act_bias[2 * u + 1];
+    a.c0 = m.act_ctrlrange[2 * u]; a.c1 = m.act_ctrlrange[2 * u + 1]; a.f0 = m.act_forcerange[2 * u]; a.f1 = m.act_forcerange[2 * u + 1];
+    return a;
+  };
+  ActModel act0{};
+  if (lane < m.nu) act0 = load_act(lane);
+  constexpr bool kSpringPre = dual_hybrid_free<TP>();              // leg-chain kernels (the hybrids' passes over the dofs are compacted: not lane + 64 i)
+  constexpr int kSpringN = spring_regs<TP>();
+  float spring_k[kSpringN], spring_ref[kSpringN];
+  if constexpr (kSpringPre) {
+#pragma unroll
+    for (int i = 0; i < kSpringN; ++i) {
+      const int j = lane + kWave * i;
+      spring_k[i] = j < TP::NV ? m.dof_stiffness[j] : 0.f; spring_ref[i] = j < TP::NV ? m.dof_springref[j] : 0.f;
+    }
+  }
   // ---- velocities and bias accelerations: three passes over the chains
   // (CPU flavour: the rows' reference accelerations also go to the world's noslip scratch — noslip_primal reads them back)
   float* const nsbuf = m.noslip_iter > 0 && st.noslip_buf ? st.noslip_buf + (size_t)w * kNoslipFloats : nullptr;
@@ -2069,6 +2105,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     }
   };
   if constexpr (!TP::kStar) {
+    contact_constants();
     tree_velocity_bias(s, m, lane);
     if (c.on) {
       float velrow[4];
@@ -2107,6 +2144,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
       });
     }
     WSYNC();
+    contact_constants();
     // reference acceleration of the contact rows needs the body velocities (still in W here)
     if (c.on) {
       float velrow[4];
@@ -2148,14 +2186,15 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   STAGE(5);
   // ---- actuation
   for (int u = lane; u < m.nu; u += kWave) {
+    const ActModel am = u < kWave ? act0 : load_act(u);
     float ctrl = s.ctrl[u];
-    if (m.act_limited[2 * u + 1]) ctrl = fminf(fmaxf(ctrl, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
+    if (am.lim_c) ctrl = fminf(fmaxf(ctrl, am.c0), am.c1);
     float f;
-    if (m.act_type[u] == ACT_ADHESION) {
-      f = m.act_gain[u] * ctrl;
+    if (am.type == ACT_ADHESION) {
+      f = am.gain * ctrl;
       // pulls through the contacts of the adhesion segment's own geom (the MJCF body the actuator names, reference
       // fly.py:434-439); sem_adhesion_fused: through every contact of the dynamic body the segment was merged into
-      const int body = m.act_trn[u], ag = m.sem_adhesion_fused ? -2 : m.act_geom[u];
+      const int body = am.trn, ag = m.sem_adhesion_fused ? -2 : m.act_geom[u];
       const int c0 = s.body_cstart[body], c1 = s.body_cstart[body + 1];
       int cnt = 0;
       for (int cc = c0; cc < c1; ++cc) cnt += (ag == -2 || info_geom(s.c_info[cc]) == ag) ? 1 : 0;
@@ -2171,9 +2210,9 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         stsv(s.W[body], acc);
       }
     } else {
-      int j = m.act_trn[u];
-      f = m.act_gain[u] * ctrl + m.act_bias[2 * u] * s.qpos[j + 1] + m.act_bias[2 * u + 1] * s.qvel[j];
-      if (m.act_limited[2 * u]) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
+      int j = am.trn;
+      f = am.gain * ctrl + am.b0 * s.qpos[j + 1] + am.b1 * s.qvel[j];
+      if (am.lim_f) f = fminf(fmaxf(f, am.f0), am.f1);
       s.vA[j] += f;
     }
     if (last) st.actuator_force[(size_t)w * m.nu + opaque(u)] = f;     // pure output: only the launch's last step stores it
@@ -2181,7 +2220,13 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   }
   WSYNC();
   sweep_project(s, s.W, m, lane, [&](int j, float v) {
-    float passive = j < 6 ? 0.f : -m.dof_stiffness[j] * (s.qpos[j + 1] - m.dof_springref[j]) - dof_damp(s, m, j) * s.qvel[j];
+    float kj, rj;
+    if constexpr (kSpringPre) {
+      kj = spring_k[0]; rj = spring_ref[0];
+#pragma unroll
+      for (int i = 1; i < kSpringN; ++i) { kj = j >= kWave * i ? spring_k[i] : kj; rj = j >= kWave * i ? spring_ref[i] : rj; }
+    } else { kj = m.dof_stiffness[j]; rj = m.dof_springref[j]; }
+    float passive = j < 6 ? 0.f : -kj * (s.qpos[j + 1] - rj) - dof_damp(s, m, j) * s.qvel[j];
     s.qfrc_smooth[j] = v + passive + s.vA[j];
   });
   STAGE(6);
