@@ -1045,13 +1045,14 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   A.sampled = p->rays_per_ommatidium;
   if (build_eye_plan(b, id_map_dev, p->height, p->width, p->fov_deg, n_ommatidia) != 0) return -1;
   const int mode = A.sampled ? 2 : frames_out_dev ? 1 : 0;
-#define NMF_EYE_LAUNCH(SAMPLED)                                                                                                      \
-  hipLaunchKernelGGL(nmf::nmf_eye_kernel<SAMPLED>, dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A, \
+#define NMF_EYE_LAUNCH(SAMPLED, RELIEF, FRAMES)                                                                                      \
+  hipLaunchKernelGGL((nmf::nmf_eye_kernel<SAMPLED, RELIEF, FRAMES>), dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A, \
                      b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,                           \
                      capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),                               \
                      b->eye_plan.visit[mode], b->eye_plan.cones[mode], reinterpret_cast<const float4*>(b->eye_plan.chunk_cones[mode]), b->eye_plan.n_groups[mode], \
                      id_map_dev, b->eye_plan.slot_omm, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev)
-  if (A.sampled) NMF_EYE_LAUNCH(true); else NMF_EYE_LAUNCH(false);
+  if (A.terrain_kind != 0) { if (A.sampled) NMF_EYE_LAUNCH(true, true, false); else if (frames_out_dev) NMF_EYE_LAUNCH(false, true, true); else NMF_EYE_LAUNCH(false, true, false); }
+  else { if (A.sampled) NMF_EYE_LAUNCH(true, false, false); else if (frames_out_dev) NMF_EYE_LAUNCH(false, false, true); else NMF_EYE_LAUNCH(false, false, false); }
 #undef NMF_EYE_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;

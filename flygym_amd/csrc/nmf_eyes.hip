@@ -95,6 +95,25 @@ __device__ __forceinline__ V3 eye_ray(int row, int col, float cx, float cy, floa
   return v3(st * u * rinv, -st * v * rinv, -ct);          // x right, y up, looks along -z
 }
 
+// floor(x) as an integer in one instruction (saturating, NaN -> 0: no guard needed for rays that miss)
+__device__ __forceinline__ int floor_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// sin(theta) / theta and cos(theta) as polynomials in x = theta^2 for theta <= 2.1 (a lens up to 240 degrees): near-minimax fits of
+// degree 4 and 5 (Chebyshev nodes over [0, 4.41]; 7.6e-8 and 6.9e-9 from the functions in exact arithmetic, 2-3e-7 evaluated in
+// float32 — the rounding of the evaluation itself; the Taylor polynomials of degree 7 and 8 they replace were no closer in
+// float32 and cost six more multiply-adds per ray).  One definition: the pixel-exact and the sampled kernel must agree bit for bit.
+__device__ __forceinline__ void lens_poly(float x, float& sc, float& cs) {
+  sc = 2.4920499623e-06f;
+  sc = fmaf(sc, x, -1.9741108406e-04f); sc = fmaf(sc, x, 8.3317681782e-03f); sc = fmaf(sc, x, -1.6666580795e-01f); sc = fmaf(sc, x, 9.9999992450e-01f);
+  cs = -2.4918686236e-07f;
+  cs = fmaf(cs, x, 2.4672689480e-05f); cs = fmaf(cs, x, -1.3885964226e-03f); cs = fmaf(cs, x, 4.1666365781e-02f); cs = fmaf(cs, x, -4.9999988662e-01f);
+  cs = fmaf(cs, x, 9.9999999307e-01f);
+}
+
 // Waves per SIMD the register allocation aims at (measured per 8192 views with the own body: 5 waves 2.88 ms, 6 waves
 // 2.71, 7 waves 2.55 — with 24 spilled registers, still the fastest —, 8 waves 3.00): latency hiding beats the spills until
 // the allocation drops to 64 registers.
@@ -103,7 +122,11 @@ __device__ __forceinline__ V3 eye_ray(int row, int col, float cx, float cy, floa
 #endif
 // SAMPLED: the sampled mode (nmf_eye_params::rays_per_ommatidium = 16) as an instantiation of its own — the pixel-exact kernel
 // keeps its register allocation, this one has few live values and takes eight waves per SIMD.
-template <bool SAMPLED>
+// RELIEF: the world has a terrain (flygym_amd/compose/world.py kinds 1-3) — the cell-by-cell walk of a ray through it exists in
+// these instantiations only; flat worlds run without its code and registers.
+// FRAMES: the call also wants the raw frames (inspection, parity tests); the readings-only instantiations carry neither the frame
+// bytes' registers nor their code through the pixel loop.
+template <bool SAMPLED, bool RELIEF, bool FRAMES>
 __global__ void __launch_bounds__(kEyeThreads) __attribute__((amdgpu_waves_per_eu(SAMPLED ? 8 : NMF_EYE_WAVES, SAMPLED ? 8 : NMF_EYE_WAVES)))
 nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __restrict__ seg_xquat, int nseg,
                const float* __restrict__ spheres, const int* __restrict__ cap_seg, const float* __restrict__ cap_geom,
@@ -127,6 +150,9 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
   if (threadIdx.x < 6 + kMaxSpheres)
     mats[threadIdx.x] = threadIdx.x == 0 ? 0u : *reinterpret_cast<const unsigned int*>(A.rgb[threadIdx.x - 1]);
   __syncthreads();
+  // the common materials' rgb words, wave-uniform: scalar registers
+  auto rgb_word = [&](int mtl) { unsigned int v; __builtin_memcpy(&v, A.rgb[mtl], 4); return v; };      // (kernel argument: a scalar load)
+  const unsigned int w_sky = rgb_word(0), w_ga = rgb_word(1), w_gb = rgb_word(2), w_wall = rgb_word(3), w_body = rgb_word(4), w_gx = w_ga ^ w_gb;
   // camera pose (uniform over the workgroup)
   const int sg = A.eye_seg[eye];
   float Rs[9];
@@ -197,7 +223,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     }
   }
   __syncthreads();
-  uint8_t* fout = frames_out ? frames_out + (size_t)blockIdx.x * n_pix * 3 : nullptr;
+  uint8_t* const fout = FRAMES && frames_out ? frames_out + (size_t)blockIdx.x * n_pix * 3 : nullptr;
   // the visit plan lists the chunks to render (readings only: those that touch an ommatidium — 43 % of the frame lies outside
   // the lattice) in groups of 64, one group per wave and turn
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,18 +243,21 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     // does a cone (axis a, half-angle by cos / sin) meet a disc of angular radius (qc, qs) about the unit direction q?
     auto meets = [](V3 a, float c_cos, float c_sin, float qx, float qy, float qz, float qc, float qs) {
       const float ca = qx * a.x + qy * a.y + qz * a.z;
-      return qc < -1.5f || ca >= c_cos * qc - c_sin * qs || c_sin * qc + c_cos * qs <= 0.f;      // (last: the two angles add up to pi or more)
+      // (no short-circuit: three compares and two scalar ors cost less than the branches around them)
+      return (int)(qc < -1.5f) | (int)(ca >= c_cos * qc - c_sin * qs) | (int)(c_sin * qc + c_cos * qs <= 0.f);      // (last: the two angles add up to pi or more)
     };
     auto cone_sees = [&](float qx, float qy, float qz, float qc, float qs) {
-      return meets(gw[0], g_cos[0], g_sin[0], qx, qy, qz, qc, qs) || (two && meets(gw[1], g_cos[1], g_sin[1], qx, qy, qz, qc, qs));
+      int r = meets(gw[0], g_cos[0], g_sin[0], qx, qy, qz, qc, qs);
+      if (two) r |= meets(gw[1], g_cos[1], g_sin[1], qx, qy, qz, qc, qs);         // (wave-uniform)
+      return r;
     };
-    bool sees_cap = false;
+    int sees_cap = 0;
     if (lane < A.n_caps) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { const float* cq = capc[lane][i]; sees_cap = sees_cap || cone_sees(cq[0], cq[1], cq[2], cq[3], cq[4]); }
+      for (int i = 0; i < 3; ++i) { const float* cq = capc[lane][i]; sees_cap |= cone_sees(cq[0], cq[1], cq[2], cq[3], cq[4]); }
     }
-    const unsigned long long grp_caps = __ballot(sees_cap);
-    const unsigned int grp_sph = (unsigned int)__ballot(lane < A.n_spheres && cone_sees(sphc[lane < A.n_spheres ? lane : 0][0], sphc[lane < A.n_spheres ? lane : 0][1],
+    const unsigned long long grp_caps = __ballot(sees_cap != 0);
+    const unsigned int grp_sph = (unsigned int)__ballot(lane < A.n_spheres && 0 != cone_sees(sphc[lane < A.n_spheres ? lane : 0][0], sphc[lane < A.n_spheres ? lane : 0][1],
                                                                                       sphc[lane < A.n_spheres ? lane : 0][2], sphc[lane < A.n_spheres ? lane : 0][3], sphc[lane < A.n_spheres ? lane : 0][4]));
     // some ray of the group points below the horizon (a cone wider than a hemisphere always does: sin falls again beyond 90 degrees)
     const bool grp_ground = g_cos[0] <= 0.f || gw[0].z < g_sin[0] + 1e-3f || (two && (g_cos[1] <= 0.f || gw[1].z < g_sin[1] + 1e-3f));
@@ -262,14 +291,15 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       }
       for (unsigned long long gm = grp_caps; gm; gm &= gm - 1ull) {
         const int c = __ffsll((long long)gm) - 1;
-        bool hit = false;
+        int hit = 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const float* cq = capc[c][i];
-          hit = hit || meets(cw[0], c_cos[0], c_sin[0], cq[0], cq[1], cq[2], cq[3], cq[4]) || (two && meets(cw[1], c_cos[1], c_sin[1], cq[0], cq[1], cq[2], cq[3], cq[4]));
+          hit |= meets(cw[0], c_cos[0], c_sin[0], cq[0], cq[1], cq[2], cq[3], cq[4]);
+          if (two) hit |= meets(cw[1], c_cos[1], c_sin[1], cq[0], cq[1], cq[2], cq[3], cq[4]);
         }
         if (hit) cand |= 1ull << c;
-        if (__any(hit)) ucand |= 1ull << c;
+        if (__any(hit != 0)) ucand |= 1ull << c;
       }
     }
 #ifdef NMF_EYE_STATS
@@ -279,18 +309,24 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
 #endif
     // what a world-axis ray sees: ground plane (checker) where the group's cone reaches below the horizon, then the spheres
     // and capsules the group can see; the nearest positive hit wins
+    // (returns the material's rgb word: the sky's and the ground's — nearly every ray's — are in scalar registers; black = 0)
+    // (objs: the group sees a sphere or a capsule at all — wave-uniform, a scalar branch per ray; without one the ground's distance
+    // is never compared with anything)
+    const bool objs = __builtin_amdgcn_readfirstlane((grp_sph != 0u || ucand != 0ull || (RELIEF && A.terrain_kind != 0)) ? 1 : 0) != 0;
     auto scene = [&](const V3 d) {
-      int mat = 0;
+      unsigned int rgb = w_sky;
       float tbest = INFINITY;
       if (grp_ground) {
         const float t = -hz * __builtin_amdgcn_rcpf(d.z);
         const bool ghit = d.z < 0.f && t > 0.f;
         const float gx = (cam.x + t * d.x) * inv_cs, gy = (cam.y + t * d.y) * inv_cs;
-        const int par = ((int)floorf(ghit ? gx : 0.f) + (int)floorf(ghit ? gy : 0.f)) & 1;
-        mat = ghit ? 1 + par : 0;
-        tbest = ghit ? t : INFINITY;
+        // checker parity as a mask (bit 0 of the cell sum, sign-extended): ground A xor (mask and (A xor B)) — no select between two scalars
+        const unsigned int pm = (unsigned int)(((floor_int(gx) + floor_int(gy)) << 31) >> 31);
+        rgb = ghit ? (w_ga ^ (pm & w_gx)) : w_sky;
+        if (objs) tbest = ghit ? t : INFINITY;
       }
-      if (grp_ground && A.terrain_kind != 0 && d.z < 0.f) {
+      if (!objs) return rgb;
+      if constexpr (RELIEF) if (grp_ground && A.terrain_kind != 0 && d.z < 0.f) {
         // relief: follow the ray through the cells of h(x, y) from the highest level down; a cell entered below its level
         // is a side wall, else its top is hit if the ray reaches the level before leaving the cell
         const float rdz = 1.0f / d.z;
@@ -301,14 +337,14 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           const TerrainCell c = terrain_cell(A.terrain_kind, A.terrain, cam.x + tp * d.x, cam.y + tp * d.y);
           const float h = c.h + A.ground_z;
           const float z_in = cam.z + tc * d.z;
-          if (z_in < h - kTerrainWallTol) { tbest = tc; mat = 3; break; }
+          if (z_in < h - kTerrainWallTol) { tbest = tc; rgb = w_wall; break; }
           const float tx = d.x > 0.f ? (c.x1 - cam.x) / d.x : (d.x < 0.f ? (c.x0 - cam.x) / d.x : INFINITY);
           const float ty = d.y > 0.f ? (c.y1 - cam.y) / d.y : (d.y < 0.f ? (c.y0 - cam.y) / d.y : INFINITY);
           const float t_out = fminf(tx, ty);
           const float t_h = (h - cam.z) * rdz;
           if (t_h <= t_out) {
             const float qx = (cam.x + t_h * d.x) * inv_cs, qy = (cam.y + t_h * d.y) * inv_cs;
-            tbest = t_h; mat = 1 + (((int)floorf(qx) + (int)floorf(qy)) & 1);
+            tbest = t_h; rgb = ((floor_int(qx) + floor_int(qy)) & 1) ? w_gb : w_ga;
             break;
           }
           tc = t_out;
@@ -320,7 +356,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
         const float disc = b * b - sph[s][3];
         const float ts = -b - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
         const bool ok = disc > 0.f && ts > 0.f && ts < tbest;
-        tbest = ok ? ts : tbest; mat = ok ? 5 + s : mat;
+        tbest = ok ? ts : tbest; rgb = ok ? mats[6 + s] : rgb;
       }
       for (unsigned long long cm = ucand; cm; cm &= cm - 1ull) {
         const int ci = __ffsll((long long)cm) - 1;
@@ -343,9 +379,9 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           const float te = -bb - sqrtf(fmaxf(hh, 0.f));
           if (hh > 0.f && te > 0.f) tcap = te;
         }
-        if (tcap < tbest) { tbest = tcap; mat = 4; }
+        if (tcap < tbest) { tbest = tcap; rgb = w_body; }
       }
-      return mat;
+      return rgb;
     };
     if constexpr (SAMPLED) {
       // Sampled mode: a lane's ray is a pixel of the raw frame — computed exactly as the pixel-exact mode computes that pixel
@@ -367,31 +403,26 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           const int prow = px / A.width, pcol = px - prow * A.width;
           const bool wraps = (pchunk * 16) / A.width != (pchunk * 16 + 15) / A.width;
           const bool pplanned = !(reinterpret_cast<const unsigned int*>(plan)[4 * pchunk + 1] & 0x10000u);
-          int mat;
+          unsigned int rgbw;
           if (!wraps && pplanned && cn[9] != 0.f) {
             const float vv = ((float)prow + 0.5f - cy) * inv_half_h;
             const float v2 = vv * vv;
             const V3 rowv = v3(-vv * R[1], -vv * R[4], -vv * R[7]);
             const float u = ((float)pcol + 0.5f - cx) * inv_half_h;
             const float x = fmaf(u, u, v2) * hf2;
-            float sc = -1.0f / 1307674368000.f;
-            sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
-            sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
-            float cs = 1.0f / 20922789888000.f;
-            cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
-            cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
+            float sc, cs;
+            lens_poly(x, sc, cs);
             const float s1 = sc * A.half_fov;
             const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
-            mat = scene(d);
+            rgbw = scene(d);
           } else {
             float theta;
             const V3 dc = eye_ray(prow, pcol, cx, cy, inv_half_h, A.half_fov, theta);
             const float dx = dc.x, dy = dc.y, dz = dc.z;
             const V3 d = v3(R[0] * dx + R[1] * dy + R[2] * dz, R[3] * dx + R[4] * dy + R[5] * dz, R[6] * dx + R[7] * dy + R[8] * dz);
-            mat = scene(d);
-            mat = theta > 3.14159265f ? -1 : mat;
+            rgbw = scene(d);
+            rgbw = theta > 3.14159265f ? 0u : rgbw;
           }
-          const unsigned int rgbw = mats[mat + 1];
           val = pale[omm] ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
         }
         // sum over the 16 lanes of the row (row_shr 8, 4, 2, 1 with zero fill: the row's last lane ends up with the total)
@@ -421,7 +452,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           if (id > 0) atomicAdd(&acc[id - 1], ((pm >> k) & 1u) ? skyB : skyG);
         }
       }
-      if (fout) {
+      if (FRAMES && fout) {
         const unsigned int r0 = sky & 0xffu, r1 = skyG, r2 = skyB;
         const unsigned int w0 = r0 | (r1 << 8) | (r2 << 16) | (r0 << 24), w1 = r1 | (r2 << 8) | (r0 << 16) | (r1 << 24), w2 = r2 | (r0 << 8) | (r1 << 16) | (r2 << 24);
         unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48);
@@ -431,7 +462,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
     } else if (!two && planned && cn[9] != 0.f) {
       // The common case — a chunk inside one image row, three or fewer runs, the whole image within the lens polynomials' range
       // (cn[9]; both are properties of the chunk / the lens, so a pixel takes the same path whatever the call renders) — on a diet: the row's part of the ray is hoisted, sin(theta) / rho and cos(theta) are polynomials in
-      // theta^2 (theta <= 2.1 for a lens up to 240 degrees: truncation < 1e-7, no rsq / sin / cos), the chosen colour byte
+      // theta^2 (lens_poly: no rsq / sin / cos), the chosen colour byte
       // of a pixel goes into packed words with one v_perm each and the run sums are v_dot4 against the plan's masks.
       const float vv = ((float)row + 0.5f - cy) * inv_half_h;
       const float hf2 = A.half_fov * A.half_fov, v2 = vv * vv;
@@ -439,26 +470,24 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       // (four pixels per turn of a rolled loop: the scene code exists four times, not sixteen — the kernel has to fit the
       // instruction cache too)
       auto chunk_pixels = [&](auto&& colour_of) {      // colour_of(ray) -> the material's rgb word
+        // ((float)(col + k) + 0.5 - cx = ((float)col + 0.5 - cx) + k exactly: multiples of 0.5 far below 2^24)
+        float uc = (float)col + 0.5f - cx;
 #pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g, uc += 4.f) {
           unsigned int G4 = 0u, B4 = 0u, raw[3] = {0u, 0u, 0u};
 #pragma unroll
           for (int k4 = 0; k4 < 4; ++k4) {
-            const float u = ((float)(col + 4 * g + k4) + 0.5f - cx) * inv_half_h;
+            const float u = (uc + (float)k4) * inv_half_h;
             const float x = fmaf(u, u, v2) * hf2;               // theta^2
-            float sc = -1.0f / 1307674368000.f;                 // sin(theta) / theta
-            sc = fmaf(sc, x, 1.0f / 6227020800.f); sc = fmaf(sc, x, -1.0f / 39916800.f); sc = fmaf(sc, x, 1.0f / 362880.f);
-            sc = fmaf(sc, x, -1.0f / 5040.f); sc = fmaf(sc, x, 1.0f / 120.f); sc = fmaf(sc, x, -1.0f / 6.f); sc = fmaf(sc, x, 1.0f);
-            float cs = 1.0f / 20922789888000.f;                 // cos(theta)
-            cs = fmaf(cs, x, -1.0f / 87178291200.f); cs = fmaf(cs, x, 1.0f / 479001600.f); cs = fmaf(cs, x, -1.0f / 3628800.f);
-            cs = fmaf(cs, x, 1.0f / 40320.f); cs = fmaf(cs, x, -1.0f / 720.f); cs = fmaf(cs, x, 1.0f / 24.f); cs = fmaf(cs, x, -0.5f); cs = fmaf(cs, x, 1.0f);
+            float sc, cs;                                       // sin(theta) / theta, cos(theta)
+            lens_poly(x, sc, cs);
             const float s1 = sc * A.half_fov;                   // sin(theta) / rho
             const V3 d = v3(fmaf(s1, fmaf(u, R[0], rowv.x), -cs * R[2]), fmaf(s1, fmaf(u, R[3], rowv.y), -cs * R[5]), fmaf(s1, fmaf(u, R[6], rowv.z), -cs * R[8]));
             const unsigned int rgbw = colour_of(d);
             constexpr unsigned int keep = 0x03020100u;
             G4 = __builtin_amdgcn_perm(rgbw, G4, (keep & ~(0xffu << (8 * k4))) | (5u << (8 * k4)));
             B4 = __builtin_amdgcn_perm(rgbw, B4, (keep & ~(0xffu << (8 * k4))) | (6u << (8 * k4)));
-            if (fout) {
+            if (FRAMES && fout) {
 #pragma unroll
               for (int cidx = 0; cidx < 3; ++cidx) {
                 const int bpos = 3 * k4 + cidx;
@@ -471,7 +500,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           tot = __builtin_amdgcn_udot4(V4, 0x01010101u, tot, false);
           sA = __builtin_amdgcn_udot4(V4, (((pl.w >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sA, false);
           sAB = __builtin_amdgcn_udot4(V4, (((pl.w >> (16 + 4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u, sAB, false);
-          if (fout) {
+          if (FRAMES && fout) {
             unsigned int* o = reinterpret_cast<unsigned int*>(fout + (size_t)ch * 48) + 3 * g;
             o[0] = raw[0]; o[1] = raw[1]; o[2] = raw[2];
           }
@@ -480,7 +509,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       // (Tried, round 5: a straight-line loop for the groups that can only see the checker or the sky — more than half of them —
       // with the three colours in registers: 49 spilled registers at this occupancy, 2.96 ms against 2.43, and bytes that differ
       // from scene()'s at checker edges, which the sampled mode's bit-equality with these frames does not allow.)
-      chunk_pixels([&](const V3 d) { return mats[scene(d) + 1]; });
+      chunk_pixels([&](const V3 d) { return scene(d); });
     } else {
       // everything else (a chunk that wraps to the next row, more than three runs, a lens beyond the polynomials' range): per
       // pixel, rolled
@@ -490,9 +519,8 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
         const V3 dc = eye_ray(row, col, cx, cy, inv_half_h, A.half_fov, theta);
         const float dx = dc.x, dy = dc.y, dz = dc.z;
         const V3 d = v3(R[0] * dx + R[1] * dy + R[2] * dz, R[3] * dx + R[4] * dy + R[5] * dz, R[6] * dx + R[7] * dy + R[8] * dz);
-        int mat = scene(d);
-        mat = theta > 3.14159265f ? -1 : mat;                                  // behind the fisheye's full sphere: black
-        const unsigned int rgbw = mats[mat + 1];
+        unsigned int rgbw = scene(d);
+        rgbw = theta > 3.14159265f ? 0u : rgbw;                                // behind the fisheye's full sphere: black
         const unsigned int val = ((pl.z >> k) & 1u) ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
         if (planned) {
           tot += val;
@@ -503,7 +531,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
           const int id = (int)(tid & 0x7fffu);
           if (id > 0) atomicAdd(&acc[id - 1], val);
         }
-        if (fout) {
+        if (FRAMES && fout) {
           uint8_t* o = fout + (size_t)ch * 48 + 3 * k;
           o[0] = (uint8_t)(rgbw & 0xffu); o[1] = (uint8_t)((rgbw >> 8) & 0xffu); o[2] = (uint8_t)((rgbw >> 16) & 0xffu);
         }
