@@ -182,6 +182,49 @@ def test_batch_info_names_what_runs(torch_mod, monkeypatch):
     assert info["kernel_family"] == 4 and info["contact_space_flavour"] == 2 and info["contact_space_max_contacts"] == 13 and info["flies_per_cu"] == 8
 
 
+def test_round5_entry_points_refuse_bad_arguments(torch_mod):
+    """The C ABI of the round-5 entry points fails loudly (non-zero return + ``nmf_last_error``) and leaves the batch as it
+    was: zero or negative step counts, an observation interval of zero, a null ring, a ring row too short for the block it
+    is asked to hold, more joints / actuators than the model has, a replay table without ids, an options struct of a size this
+    library does not know, a null info array."""
+    torch = torch_mod
+    import ctypes
+    from flygym_amd import HIPSimulation, _native, make_model
+
+    fly, world, _ = make_model()
+    sim = HIPSimulation(world, n_worlds=4, device=0)
+    lib, h = sim._lib, sim._batch_h
+    sim.step(3)
+    before = {k: sim.field(k).clone() for k in STATE}
+    ring = torch.zeros((2, 4, 270), device=sim.device)
+    ok_args = dict(table=None, table_steps=0, n_act_table=0, ids=None, start=0, n_steps=2, obs_every=1, n_joint=66, n_act=42, ring=ring.data_ptr(), stride=270)
+
+    def record(**kw):
+        a = dict(ok_args, **kw)
+        return lib.nmf_step_record(h, a["table"], a["table_steps"], a["n_act_table"], a["ids"], a["start"], a["n_steps"], a["obs_every"],
+                                   a["n_joint"], a["n_act"], a["ring"], a["stride"], None)
+
+    bad = [dict(n_steps=0), dict(n_steps=-4), dict(obs_every=0), dict(ring=None), dict(stride=269), dict(n_joint=67), dict(n_act=49), dict(n_joint=-1),
+           dict(table=ring.data_ptr(), table_steps=10, n_act_table=42, ids=None), dict(table=ring.data_ptr(), table_steps=0, n_act_table=42, ids=ring.data_ptr())]
+    for kw in bad:
+        assert record(**kw) != 0, kw
+        assert b"nmf_step_record" in lib.nmf_last_error(), kw
+    assert lib.nmf_step(h, 0, None) != 0 and lib.nmf_step(h, -1, None) != 0
+    assert lib.nmf_batch_info(h, None) != 0 and lib.nmf_batch_info(None, (ctypes.c_int32 * 16)()) != 0
+    torch.cuda.synchronize()
+    for k in STATE:
+        assert torch.equal(sim.field(k), before[k]), k             # nothing ran
+    opts = _native.BatchOptions.make()
+    opts.struct_size = ctypes.sizeof(opts) + 8
+    assert not lib.nmf_batch_create_ex(sim._model_h, 4, 0, ctypes.byref(opts)) and b"struct_size" in lib.nmf_last_error()
+    opts.struct_size = 2
+    assert not lib.nmf_batch_create_ex(sim._model_h, 4, 0, ctypes.byref(opts))
+    assert not lib.nmf_batch_create_ex(sim._model_h, 0, 0, None)
+    assert record() == 0                                            # and the batch still steps
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ring).all()) and float(ring.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("kind", ["all_biological", "all_possible", "custom_tree", "tethered", "legs_only_on_blocks"])
 def test_cpu_flavour_runs_noslip_on_every_kernel_family(torch_mod, oracle_lib, kind):
     """``flygym_amd.Simulation`` keeps ``option/noslip_iterations = 5`` (reference mujoco_globals.yaml:15) for EVERY model the
