@@ -863,7 +863,7 @@ extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 // Visit plan of the eye renderer: the chunks (16 consecutive raw pixels) to render, sorted by 32 x 32-pixel tile and cut
 // into groups of 64 (one wave's turn), each group with the bounding cone of its rays in the camera frame (axis, cos and
 // sin of the half-angle) — so that a wave can decide per group what it can see at all.  Built on the host once per id map.
-static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w, float fov_deg, int n_omm) {
+static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, int h, int w, float fov_deg, int n_omm) {
   auto& P = b->eye_plan;
   if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg && P.n_omm == n_omm) return 0;
   // another id map (or lens): the previous plan's buffers go back (hipFree waits for the kernels that read them) — two
@@ -953,7 +953,16 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w,
     // sampled_pixels).  One lane per ray, an ommatidium's 16 rays in one DPP row.  The ommatidia are visited in 64 x 64
     // pixel tiles of their cells' centres, 16 (a 4 x 4 patch of the lattice) to a group: one bounding cone and one culling
     // for the group's 256 rays.  slot_omm[s] = the ommatidium in slot s.
+    // Both lists carry what a ray would otherwise look up behind them (the sampled kernel waits for memory, not for arithmetic:
+    // three dependent round trips per turn were visit -> the chunk's plan word, slot -> ommatidium -> pale): a visit entry is the
+    // pixel | bit 30 "its chunk lies inside one image row and has a run plan" (the lens-polynomial path of the pixel-exact
+    // kernel, nmf_eyes.hip); a slot entry is the ommatidium | bit 30 "pale".
     constexpr int K = nmf::kEyeRays, S = nmf::kEyeSlots;
+    std::vector<uint32_t> planw((size_t)n_chunk * 4);
+    std::vector<uint8_t> pale_h((size_t)n_omm);
+    HIP_OK(hipDeviceSynchronize());        // (the plan was built on the caller's stream)
+    HIP_OK(hipMemcpy(planw.data(), plan_dev, sizeof(uint32_t) * planw.size(), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(pale_h.data(), pale_dev, pale_h.size(), hipMemcpyDeviceToHost));
     std::vector<std::vector<int>> cell((size_t)n_omm);
     for (int i = 0; i < n_pix; ++i) { const int id = ids[(size_t)i] & 0x7fff; if (id > 0 && id <= n_omm) cell[(size_t)id - 1].push_back(i); }
     std::vector<int> order((size_t)n_omm);
@@ -971,14 +980,19 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, int h, int w,
     std::vector<int> visit((size_t)n_groups * S * K, -1), slots((size_t)n_groups * S, 0);
     for (int sl = 0; sl < n_omm; ++sl) {
       const int o = order[(size_t)sl];
-      slots[(size_t)sl] = o;
+      slots[(size_t)sl] = o | (pale_h[(size_t)o] ? (1 << 30) : 0);
       const long long n = (long long)cell[(size_t)o].size();
-      for (int j = 0; j < K && n > 0; ++j) visit[(size_t)sl * K + j] = cell[(size_t)o][(size_t)(((2 * j + 1) * n) / (2 * K))];
+      for (int j = 0; j < K && n > 0; ++j) {
+        const int px = cell[(size_t)o][(size_t)(((2 * j + 1) * n) / (2 * K))];
+        const int pchunk = px >> 4;
+        const bool one_row = (pchunk * 16) / w == (pchunk * 16 + 15) / w, planned = !(planw[(size_t)pchunk * 4 + 1] & 0x10000u);
+        visit[(size_t)sl * K + j] = px | (one_row && planned ? (1 << 30) : 0);
+      }
     }
     std::vector<float> cones((size_t)n_groups * 12, 0.f);
     for (int g = 0; g < n_groups; ++g) {
       std::vector<size_t> gp;
-      for (int l = 0; l < S * K; ++l) if (visit[(size_t)g * S * K + l] >= 0) gp.push_back((size_t)visit[(size_t)g * S * K + l]);
+      for (int l = 0; l < S * K; ++l) if (visit[(size_t)g * S * K + l] >= 0) gp.push_back((size_t)(visit[(size_t)g * S * K + l] & 0xffffff));
       cone_of(gp, 1e-4, &cones[(size_t)g * 12]);
       cones[(size_t)g * 12 + 9] = lens_ok ? 1.f : 0.f;
     }
@@ -1043,7 +1057,7 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   if (p->rays_per_ommatidium != 0 && p->rays_per_ommatidium != nmf::kEyeRays) return fail("nmf_eye_render: rays_per_ommatidium must be 0 (every pixel) or 16");
   if (p->rays_per_ommatidium != 0 && frames_out_dev) return fail("nmf_eye_render: the sampled mode renders no frames (rays_per_ommatidium = 0 does)");
   A.sampled = p->rays_per_ommatidium;
-  if (build_eye_plan(b, id_map_dev, p->height, p->width, p->fov_deg, n_ommatidia) != 0) return -1;
+  if (build_eye_plan(b, id_map_dev, plan_dev, pale_dev, p->height, p->width, p->fov_deg, n_ommatidia) != 0) return -1;
   const int mode = A.sampled ? 2 : frames_out_dev ? 1 : 0;
 #define NMF_EYE_LAUNCH(SAMPLED, RELIEF, FRAMES)                                                                                      \
   hipLaunchKernelGGL((nmf::nmf_eye_kernel<SAMPLED, RELIEF, FRAMES>), dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A, \

@@ -270,7 +270,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
 #ifdef NMF_EYE_STATS
     if (lane == 0) atomicAdd(&g_eye_stats[7], (sky_only ? 1ull : 0ull) | ((!grp_ground && grp_sph == 0u) ? 1ull << 32 : 0ull));
 #endif
-    const int chunk = sampled ? (ch < 0 ? 0 : ch >> 4) : ch;
+    const int chunk = sampled ? (ch < 0 ? 0 : (ch & 0xffffff) >> 4) : ch;      // (sampled: a visit entry is pixel | flags)
     const u32x4 pl = plan[chunk];
     const bool planned = !(pl.y & 0x10000u);
     int row = (chunk * 16) / A.width, col = chunk * 16 - row * A.width;
@@ -389,22 +389,30 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       // colour is the frame's.  The kEyeRays lanes of an ommatidium form one DPP row: their chosen colour bytes are summed
       // across the row and the row's last lane adds them to the ommatidium.
       const float hf2 = A.half_fov * A.half_fov;
+      // (the plan's lists carry the pixel's path and the ommatidium's pale flag with them, and the next turn's two words are
+      // requested while this turn's rays are cast: one memory round trip per turn behind arithmetic instead of three in front of it)
+      int pxw = ch;
+      int slw = (grp * (kEyeSlots / 4)) * 4 + (lane >> 4) < n_omm ? slot_omm[(grp * (kEyeSlots / 4)) * 4 + (lane >> 4)] : 0;
 #pragma unroll 1
       for (int turn = 0; turn < kEyeSlots / 4; ++turn) {
         const int slot = (grp * (kEyeSlots / 4) + turn) * 4 + (lane >> 4);
-        const int px = turn == 0 ? ch : visit[(grp * (kEyeSlots / 4) + turn) * 64 + lane];
-        const int omm = slot < n_omm ? slot_omm[slot] : 0;
+        const int pxw_cur = pxw, slw_cur = slw;
+        if (turn + 1 < kEyeSlots / 4) {
+          pxw = visit[(grp * (kEyeSlots / 4) + turn + 1) * 64 + lane];
+          slw = slot + 4 < n_omm ? slot_omm[slot + 4] : 0;
+        }
+        const int px = pxw_cur < 0 ? -1 : (pxw_cur & 0xffffff);
+        const bool poly = pxw_cur >= 0 && ((pxw_cur >> 30) & 1) != 0;       // inside one image row, run plan: the polynomial path
+        const int omm = slw_cur & 0xffff;
+        const bool is_pale = ((slw_cur >> 30) & 1) != 0;
         unsigned int val = 0u;
-        if (px >= 0 && sky_only && (px >> 4) * 16 / A.width == ((px >> 4) * 16 + 15) / A.width && !(reinterpret_cast<const unsigned int*>(plan)[4 * (px >> 4) + 1] & 0x10000u)) {
-          const unsigned int rgbw = mats[1];          // (a pixel of the polynomial path in a group that sees the sky only)
-          val = pale[omm] ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
+        if (px >= 0 && sky_only && poly) {
+          const unsigned int rgbw = w_sky;            // (a pixel of the polynomial path in a group that sees the sky only)
+          val = is_pale ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
         } else if (px >= 0) {
-          const int pchunk = px >> 4;
           const int prow = px / A.width, pcol = px - prow * A.width;
-          const bool wraps = (pchunk * 16) / A.width != (pchunk * 16 + 15) / A.width;
-          const bool pplanned = !(reinterpret_cast<const unsigned int*>(plan)[4 * pchunk + 1] & 0x10000u);
           unsigned int rgbw;
-          if (!wraps && pplanned && cn[9] != 0.f) {
+          if (poly && cn[9] != 0.f) {
             const float vv = ((float)prow + 0.5f - cy) * inv_half_h;
             const float v2 = vv * vv;
             const V3 rowv = v3(-vv * R[1], -vv * R[4], -vv * R[7]);
@@ -423,7 +431,7 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
             rgbw = scene(d);
             rgbw = theta > 3.14159265f ? 0u : rgbw;
           }
-          val = pale[omm] ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
+          val = is_pale ? ((rgbw >> 16) & 0xffu) : ((rgbw >> 8) & 0xffu);
         }
         // sum over the 16 lanes of the row (row_shr 8, 4, 2, 1 with zero fill: the row's last lane ends up with the total)
         int v = (int)val;
