@@ -876,7 +876,7 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* p
       if (it != b->allocs.end()) b->allocs.erase(it);
       (void)hipFree(q);
     };
-    for (int mode = 0; mode < 3; ++mode) { drop(P.visit[mode]); drop(P.cones[mode]); if (mode < 2) drop(P.chunk_cones[mode]); P.visit[mode] = nullptr; P.cones[mode] = nullptr; P.chunk_cones[mode] = nullptr; P.n_groups[mode] = 0; }
+    for (int mode = 0; mode < 3; ++mode) { drop(P.visit[mode]); drop(P.cones[mode]); drop(P.chunk_cones[mode]); P.visit[mode] = nullptr; P.cones[mode] = nullptr; P.chunk_cones[mode] = nullptr; P.n_groups[mode] = 0; }
     drop(P.slot_omm); P.slot_omm = nullptr; P.id_map = nullptr;
   }
   const int n_pix = h * w, n_chunk = n_pix / 16;
@@ -989,22 +989,30 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* p
         visit[(size_t)sl * K + j] = px | (one_row && planned ? (1 << 30) : 0);
       }
     }
-    std::vector<float> cones((size_t)n_groups * 12, 0.f);
+    // ... and one cone per TURN (64 rays = four ommatidia): every ray tests all the capsules its culling lets through, so the
+    // sampled kernel culls a second time per turn (`chunk_cones` of this mode: axis + cos of the half-angle, camera frame)
+    std::vector<float> cones((size_t)n_groups * 12, 0.f), tcones((size_t)n_groups * (S / 4) * 4, 0.f);
     for (int g = 0; g < n_groups; ++g) {
       std::vector<size_t> gp;
       for (int l = 0; l < S * K; ++l) if (visit[(size_t)g * S * K + l] >= 0) gp.push_back((size_t)(visit[(size_t)g * S * K + l] & 0xffffff));
       cone_of(gp, 1e-4, &cones[(size_t)g * 12]);
       cones[(size_t)g * 12 + 9] = lens_ok ? 1.f : 0.f;
+      for (int t = 0; t < S / 4; ++t) {
+        std::vector<size_t> tp;
+        for (int l = 64 * t; l < 64 * (t + 1); ++l) if (visit[(size_t)g * S * K + l] >= 0) tp.push_back((size_t)(visit[(size_t)g * S * K + l] & 0xffffff));
+        cone_of(tp, 1e-4, &tcones[((size_t)g * (S / 4) + t) * 4]);
+      }
     }
-    void* pv = nullptr; void* pc = nullptr; void* ps = nullptr;
+    void* pv = nullptr; void* pc = nullptr; void* ps = nullptr; void* pt = nullptr;
     if (hipMalloc(&pv, sizeof(int) * visit.size()) != hipSuccess || hipMalloc(&pc, sizeof(float) * cones.size()) != hipSuccess ||
-        hipMalloc(&ps, sizeof(int) * slots.size()) != hipSuccess)
+        hipMalloc(&ps, sizeof(int) * slots.size()) != hipSuccess || hipMalloc(&pt, sizeof(float) * tcones.size()) != hipSuccess)
       return fail("nmf_eye_render: out of device memory for the sampling plan");
-    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(ps);
+    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(ps); b->allocs.push_back(pt);
+    HIP_OK(hipMemcpy(pt, tcones.data(), sizeof(float) * tcones.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pv, visit.data(), sizeof(int) * visit.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pc, cones.data(), sizeof(float) * cones.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ps, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice));
-    P.visit[2] = (int*)pv; P.cones[2] = (float*)pc; P.chunk_cones[2] = P.chunk_cones[0]; P.n_groups[2] = n_groups; P.slot_omm = (int*)ps;
+    P.visit[2] = (int*)pv; P.cones[2] = (float*)pc; P.chunk_cones[2] = (float*)pt; P.n_groups[2] = n_groups; P.slot_omm = (int*)ps;
   }
   P.id_map = id_map_dev; P.h = h; P.w = w; P.fov = fov_deg; P.n_omm = n_omm;
   return 0;

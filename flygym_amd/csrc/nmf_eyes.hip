@@ -397,6 +397,17 @@ nmf_eye_kernel(EyeArgs A, const float* __restrict__ seg_xpos, const float* __res
       for (int turn = 0; turn < kEyeSlots / 4; ++turn) {
         const int slot = (grp * (kEyeSlots / 4) + turn) * 4 + (lane >> 4);
         const int pxw_cur = pxw, slw_cur = slw;
+        if (grp_caps) {      // the capsules this TURN's 64 rays can meet (wave-uniform: lane = capsule, as for the group)
+          const float4 tcn = chunk_cones[__builtin_amdgcn_readfirstlane(grp * (kEyeSlots / 4) + turn)];
+          const V3 tw = v3(R[0] * tcn.x + R[1] * tcn.y + R[2] * tcn.z, R[3] * tcn.x + R[4] * tcn.y + R[5] * tcn.z, R[6] * tcn.x + R[7] * tcn.y + R[8] * tcn.z);
+          const float t_cos = tcn.w, t_sin = sqrtf(fmaxf(1.f - tcn.w * tcn.w, 0.f));
+          int sees = 0;
+          if (lane < A.n_caps) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const float* cq = capc[lane][i]; sees |= meets(tw, t_cos, t_sin, cq[0], cq[1], cq[2], cq[3], cq[4]); }
+          }
+          cand = __ballot(sees != 0) & grp_caps; ucand = cand;
+        }
         if (turn + 1 < kEyeSlots / 4) {
           pxw = visit[(grp * (kEyeSlots / 4) + turn + 1) * 64 + lane];
           slw = slot + 4 < n_omm ? slot_omm[slot + 4] : 0;
