@@ -434,6 +434,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, wave_reduce_bits(__builtin_bit_cast(int, v), (int)0xff800000, [](int a, int b) {
     return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); }));
 }
+// inclusive prefix minimum over the wave's lanes 0..lane (row_shr ladder inside the 16-lane rows, then the rows' totals)
+__device__ __forceinline__ int wave_prefix_min_int(int v) {
+  constexpr int big = 0x7fffffff;
+  auto mn = [](int a, int b) { return a < b ? a : b; };
+  v = mn(v, NMF_DPP_OLD(big, v, 0x111, 0xf));      // row_shr:1 (lanes without a source keep the identity)
+  v = mn(v, NMF_DPP_OLD(big, v, 0x112, 0xf));
+  v = mn(v, NMF_DPP_OLD(big, v, 0x114, 0xf));
+  v = mn(v, NMF_DPP_OLD(big, v, 0x118, 0xf));
+  v = mn(v, NMF_DPP_OLD(big, v, 0x142, 0xa));      // row_bcast15 into rows 1 and 3
+  v = mn(v, NMF_DPP_OLD(big, v, 0x143, 0xc));      // row_bcast31 into rows 2 and 3
+  return v;
+}
 __device__ __forceinline__ int wave_min_int(int v) {
   return wave_reduce_bits(v, 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
 }

@@ -1114,10 +1114,31 @@ __device__ __noinline__ void stage_collision(FlyLds<TP>& s, const GModel& m, int
       if (lane == 0) s.nwall = __popcll(wf);
     }
   }
-  for (int b = lane; b <= s.nb(); b += kWave) {
-    int c_before = 0;
-    for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
-    s.body_cstart[b] = (typename FlyLds<TP>::cstart_t)c_before;
+  // body_cstart[b] = number of contacts on bodies before b = the first contact of a body >= b (the list is in geom order,
+  // geoms in body order).  Skeletons of up to 63 bodies: lane c marks where a body's range starts, lane 63 - b takes a
+  // prefix minimum over the starts of the bodies from b on — two LDS round trips and six DPP steps, where a count over
+  // the whole list per body was a dependent LDS read per contact (round 5: a sixth of this stage's cycles on flat ground,
+  // more on the blocks' 7.4 contacts).
+  bool ranged = false;
+  if constexpr (TP::kStar) { if constexpr (TP::NB + 1 <= kWave) {
+    ranged = true;
+    const int e = lane < ncon ? info_body(s.c_info[lane]) : 0x7fffffff;
+    const int e_prev = lane > 0 && lane - 1 < ncon ? info_body(s.c_info[lane > 0 ? lane - 1 : 0]) : -1;
+    if (lane <= TP::NB) s.body_cstart[lane] = (typename FlyLds<TP>::cstart_t)ncon;
+    WSYNC();
+    if (lane < ncon && e != e_prev) s.body_cstart[e] = (typename FlyLds<TP>::cstart_t)lane;
+    WSYNC();
+    const int b = kWave - 1 - lane;
+    const int first = wave_prefix_min_int(b <= TP::NB ? (int)s.body_cstart[b <= TP::NB ? b : 0] : 0x7fffffff);
+    WSYNC();
+    if (b <= TP::NB) s.body_cstart[b] = (typename FlyLds<TP>::cstart_t)first;
+  } }
+  if (!ranged) {
+    for (int b = lane; b <= s.nb(); b += kWave) {
+      int c_before = 0;
+      for (int c = 0; c < ncon; ++c) c_before += info_body(s.c_info[c]) < b ? 1 : 0;
+      s.body_cstart[b] = (typename FlyLds<TP>::cstart_t)c_before;
+    }
   }
   WSYNC();
   SUB(23);

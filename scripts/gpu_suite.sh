@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the whole GPU suite, then the bench as the driver runs it (with other_configs) and at its default arguments
+# the whole GPU suite, then the bench as the driver runs it (with other_configs) and at its default arguments
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
