@@ -233,12 +233,21 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   float c_ws;      // the scalar c: 1 = warm start, 0 = unconstrained acceleration
   float gauss, ccost;
   if constexpr (kWarm) {
-    for (int j = lane; j < TP::NV; j += kWave) s.vA[j] = s.qacc[j] - s.qacc_smooth[j];
+    // (e for this lane's dofs stays in registers for the armature term; both turns of the wave read before the first turn stores)
+    static_assert(TP::NV <= 2 * kWave, "the warm-start term keeps a lane's dofs in two registers");
+    const int jb = lane + kWave;
+    const bool two = jb < TP::NV;
+    const float ea = lane < TP::NV ? s.qacc[lane < TP::NV ? lane : 0] - s.qacc_smooth[lane < TP::NV ? lane : 0] : 0.f;
+    const float eb = two ? s.qacc[two ? jb : 0] - s.qacc_smooth[two ? jb : 0] : 0.f;
+    const float arm_a = lane < TP::NV ? s.arm[lane < TP::NV ? lane : 0] : 0.f, arm_b = two ? s.arm[two ? jb : 0] : 0.f;
+    if (lane < TP::NV) s.vA[lane] = ea;
+    if (two) s.vA[jb] = eb;
     WSYNC();
     sweep_twists(s, s.vA, s.T, m, lane);
     if (on) je = dot(wrow, ldsv(s.T[body]));
     for (int b = lane; b < TP::NB; b += kWave) { const SV tb = ldsv(s.T[b]); eMe += dot(tb, inert_mul(s.Ib[b], tb)); }
-    for (int j = lane; j < TP::NV; j += kWave) eMe += s.arm[j] * s.vA[j] * s.vA[j];
+    eMe += arm_a * ea * ea;
+    eMe += arm_b * eb * eb;
     const float x1 = j0 + je;
     const float v_ws = on && x1 < 0.f ? 0.5f * D * x1 * x1 : 0.f, v_sm = on && j0 < 0.f ? 0.5f * D * j0 * j0 : 0.f;
     eMe = wave_sum(eMe);

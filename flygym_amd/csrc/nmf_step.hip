@@ -1247,9 +1247,20 @@ __device__ __forceinline__ void sweep_project(FlyLds<TP>& s, float (*W)[row_widt
     W[0][lane] = a0;
   }
   WSYNC();
-  for_dofs(s, red, lane, [&](int j) {         // reduced problem: the rest's dofs are not in it
-    emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
-  });
+  if constexpr (TP::REST_V == 0 && TP::NV > kWave && TP::NV <= 2 * kWave) {
+    // (leg-chain kernels: both turns' products before the first turn's emit — emit stores, see the velocity stage's pass 2)
+    const int jb = lane + kWave;
+    const bool two = jb < TP::NV;
+    const float pa = dot(ldsv(s.S[lane]), ldsv(W[dof_body_of<TP>(lane)]));
+    float pb = 0.f;
+    if (two) pb = dot(ldsv(s.S[jb]), ldsv(W[dof_body_of<TP>(jb)]));
+    emit(lane, pa);
+    if (two) emit(jb, pb);
+  } else {
+    for_dofs(s, red, lane, [&](int j) {         // reduced problem: the rest's dofs are not in it
+      emit(j, dot(ldsv(s.S[j]), ldsv(W[j >= TP::LD0 || j < 6 ? dof_body_of<TP>(j) : tbl_dofbody(s, j)])));
+    });
+  }
   WSYNC();
   }
 }
@@ -2177,8 +2188,20 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     stash_aref();
     if (wr.on) wr.aref = -weld_B * s.W[0][wr.comp] - weld_KI * weld_res;
     // pass 2: per dof, Sdot_j qd_j = (v_before x S_j) qd_j
-    for (int j = 3 + lane; j < s.nv(); j += kWave)
-      if (TP::REST_V == 0 || j < 6 || j >= TP::LD0) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
+    if constexpr (dual_hybrid_free<TP>() && TP::NV - 3 > kWave && TP::NV - 3 <= 2 * kWave) {
+      // (leg-chain kernels: 69 dofs are two turns of the wave, the second for five lanes — both turns' reads are issued before
+      // the first turn's stores, which the second's reads may alias for all the compiler knows)
+      const int ja = 3 + lane, jb = 3 + lane + kWave;
+      const bool two = jb < TP::NV;
+      const SV ra = s.qvel[ja] * cross_motion(ldsv(vb[ja]), ldsv(s.S[ja]));
+      SV rb = ra;
+      if (two) rb = s.qvel[jb] * cross_motion(ldsv(vb[jb]), ldsv(s.S[jb]));
+      stsv(vb[ja], ra);
+      if (two) stsv(vb[jb], rb);
+    } else {
+      for (int j = 3 + lane; j < s.nv(); j += kWave)
+        if (TP::REST_V == 0 || j < 6 || j >= TP::LD0) stsv(vb[j], s.qvel[j] * cross_motion(ldsv(vb[j]), ldsv(s.S[j])));
+    }
     WSYNC();
     // pass 3: component-wise prefix of bias accelerations (root parent acceleration = -gravity)
     float a = L.rr >= 3 ? -m.gravity[L.rr - 3] : 0.f;
@@ -2598,22 +2621,48 @@ __device__ void physics_integrate(FlyLds<TP>& s, const GModel& m, int lane, bool
     WSYNC();
     aba_solve<TP, WELD, !kDual<TP>>(s, V_A, V_B, false, h, m, lane);
   }
-  for (int j = lane; j < s.nv(); j += kWave) s.qvel[j] += h * s.vB[j];
-  WSYNC();
-  if (lane == 0) {
-    for (int k = 0; k < 3; k++) s.qpos[k] += h * s.qvel[k];
-    V3 w = ld3(&s.qvel[3]);
-    float wn = sqrtf(dot(w, w));
-    Q4 q = ldq(&s.qpos[3]);
+  // Semi-implicit Euler in one pass: qvel += h a, then positions with the NEW velocities — a hinge's own (the same lane holds
+  // it), the root's from lanes 0..5 through scalar registers (no second trip through LDS, no lane working alone while 63 wait:
+  // every lane computes the root's quaternion from the same scalars, lane 0 stores it).  Two turns of the wave (72 dofs) read
+  // both turns' operands before the first turn's stores.
+  const Q4 q0 = ldq(&s.qpos[3]);
+  float v0 = 0.f;      // the first turn's new velocity: lanes 0..5 hold the root's
+  if constexpr (TP::kStar) {
+    if constexpr (TP::NV > kWave && TP::NV <= 2 * kWave) {
+      const int jb = lane + kWave;
+      const bool two = jb < TP::NV;
+      const float va = s.qvel[lane] + h * s.vB[lane];
+      const float pa = lane >= 6 ? s.qpos[lane + 1] : 0.f;
+      float vb2 = 0.f, pb = 0.f;
+      if (two) { vb2 = s.qvel[jb] + h * s.vB[jb]; pb = s.qpos[jb + 1]; }
+      s.qvel[lane] = va;
+      if (lane >= 6) s.qpos[lane + 1] = pa + h * va;
+      if (two) { s.qvel[jb] = vb2; s.qpos[jb + 1] = pb + h * vb2; }
+      v0 = va;
+    }
+  }
+  if (!(TP::kStar && TP::NV > kWave && TP::NV <= 2 * kWave)) {
+    for (int j = lane; j < s.nv(); j += kWave) {
+      const float v = s.qvel[j] + h * s.vB[j];
+      s.qvel[j] = v;
+      if (j >= 6) s.qpos[j + 1] += h * v;
+      if (j < kWave) v0 = v;
+    }
+  }
+  {
+    const V3 w = v3(readlane_f(v0, 3), readlane_f(v0, 4), readlane_f(v0, 5));
+    if (lane < 3) s.qpos[lane] += h * v0;
+    const float wn = sqrtf(dot(w, w));
+    Q4 q = q0;
     if (wn > kMinVal) {
       float sn, cs;
       sincos_bounded(0.5f * h * wn, &sn, &cs);
       V3 ax = (sn / wn) * w;
       q = qmul(q, Q4{cs, ax.x, ax.y, ax.z});
     }
-    stq(&s.qpos[3], qnorm(q));
+    q = qnorm(q);
+    if (lane == 0) stq(&s.qpos[3], q);
   }
-  for (int j = 6 + lane; j < s.nv(); j += kWave) s.qpos[j + 1] += h * s.qvel[j];
   WSYNC();
 }
 
