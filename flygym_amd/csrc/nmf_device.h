@@ -434,6 +434,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, wave_reduce_bits(__builtin_bit_cast(int, v), (int)0xff800000, [](int a, int b) {
     return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); }));
 }
+// Sum over the wave's eight 8-lane groups, lane r of every group ending up with the total of lanes r of all groups: three VALU
+// steps — rotate by 8 inside the 16-lane rows (DPP), then the gfx950 row and half swaps (v_permlane16_swap / v_permlane32_swap:
+// after swap(v, v) the two results hold each lane's own and its partner row's / half's value).
+__device__ __forceinline__ float groups_sum(float v) {
+  v += NMF_DPP(v, 0x128);                                                           // row_ror:8
+  // (inline assembly: with the same value in both operands the compiler's builtin returned the first result twice — ROCm 7.2;
+  // scripts/micro/groups_sum_test.hip checks the three steps on the GPU)
+  { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); v = a + b; }
+  { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); v = a + b; }
+  return v;
+}
 // inclusive prefix minimum over the wave's lanes 0..lane (row_shr ladder inside the 16-lane rows, then the rows' totals)
 __device__ __forceinline__ int wave_prefix_min_int(int v) {
   constexpr int big = 0x7fffffff;

@@ -1618,10 +1618,22 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
       }
     }
   });
+  // the legs' articulated inertias and bias forces meet at the root: summed over the wave's lane groups on the VALU (groups_sum;
+  // the two groups that shadow the last leg contribute zero) — every group then holds the total, which is what the redundant root
+  // elimination below wants.  (Until round 5 through LDS: 7 stores, then 42 reads per lane.)
+  constexpr bool kLegSumValu = TP::NLEG <= 8;
+  float legs_row[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, legs_pA = 0.f;
+  if constexpr (kLegSumValu) {
+    const float gm = L.grp < TP::NLEG ? 1.f : 0.f;
 #pragma unroll
-  for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
-  H.legpA[L.lg][L.rr] = pA;
-  WSYNC();
+    for (int i = 0; i < 6; i++) legs_row[i] = groups_sum(gm * IA[i]);
+    legs_pA = groups_sum(gm * pA);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) H.legIA[L.lg][L.rr][i] = IA[i];
+    H.legpA[L.lg][L.rr] = pA;
+    WSYNC();
+  }
   // ---- root: every group eliminates the six root dofs redundantly (no single-lane solve, no broadcast).
   // The free joint spans all six spatial directions, so the elimination runs in world axes (angular x, y, z about the
   // root origin, then linear x, y, z) instead of the joint's own (body-frame rotation axes): with unit axes U is a column
@@ -1645,10 +1657,13 @@ __device__ __noinline__ void aba_solve(FlyLds<TP>& s, int tau_id, int x_id, bool
     if constexpr (kDual<TP>) {
       if (withF) for (int c = cs_root0; c < cs_root1; ++c) pA -= dual_wrench(s)[c][L.rr];
     }
+    if constexpr (kLegSumValu) { add6(row, legs_row); pA += legs_pA; }
+    else {
 #pragma unroll
-    for (int k = 0; k < TP::NLEG; ++k) {
-      add6(row, H.legIA[k][L.rr]);
-      pA += H.legpA[k][L.rr];
+      for (int k = 0; k < TP::NLEG; ++k) {
+        add6(row, H.legIA[k][L.rr]);
+        pA += H.legpA[k][L.rr];
+      }
     }
     if constexpr (TP::REST_B > 0) {
       if (red) {
