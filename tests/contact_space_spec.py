@@ -84,3 +84,50 @@ def solve(M, J, aref, D, a_smooth, a_warm, guess=None, dtype=np.float64, max_ite
         mask = jar < 0
     qacc = a_s + c * e + MiJt @ lam
     return qacc.astype(np.float64), jar < 0, elim, searches, stalls
+
+
+# ---- the Gram matrix of the contacts' directions and the column read (csrc/nmf_dual.h: the G build's circulant rounds, DualCol) ----
+def gram_floats(ncon):
+    """LDS floats of G for ncon contacts: one 3 x 3 block per unordered pair (dual_g_floats)."""
+    return 9 * ncon * (ncon + 1) // 2
+
+
+def pack_gram(M, Jdir):
+    """G as the kernel lays it out.  ``Jdir``: (3 ncon, nv), rows (contact c, direction 0 normal / 1, 2 tangents).  Block (c, c'),
+    c >= c', sits at 9 (c (c + 1) / 2 + c') with entry [direction of c][direction of c'].  Written as the kernel writes it: in round
+    t the lanes of contact cc take contact c2 = cc - t (cyclically), t = 0 .. ncon / 2, lane (cc, kd) storing its three products
+    <kd of cc, d2 of c2> at base + stride d2 — base / stride pick the block's row side (cc >= c2) or its column side."""
+    ncon = Jdir.shape[0] // 3
+    Z = np.linalg.solve(M, Jdir.T)                      # responses M^-1 Jdir^T (the kernel: leaf-to-root through the kept factors)
+    full = Jdir @ Z                                     # <direction, direction'>
+    G = np.full(gram_floats(ncon), np.nan)
+    written = np.zeros(len(G), dtype=int)
+    for t in range(ncon // 2 + 1):
+        for cc in range(ncon):
+            c2 = cc - t
+            c2 = c2 + ncon if c2 < 0 else c2
+            ge = cc >= c2
+            for kd in range(3):
+                base = 9 * (cc * (cc + 1) // 2 + c2) + 3 * kd if ge else 9 * (c2 * (c2 + 1) // 2 + cc) + kd
+                stride = 1 if ge else 3
+                for d2 in range(3):
+                    G[base + stride * d2] = full[3 * cc + kd, 3 * c2 + d2]
+                    written[base + stride * d2] += 1
+    return G, written
+
+
+def dual_col(G, mu, lane, kk):
+    """Entry (row ``lane``, column ``kk``) of A = J M^-1 J^T out of G — the arithmetic of DualCol::fetch / value, offsets in floats.
+    Pyramid row k of contact c is n + s mu t with s = +1 for even k, t = t1 for k < 2 else t2."""
+    cc, c2 = lane >> 2, kk >> 2
+    td, td2 = 1 + ((lane >> 1) & 1), 1 + ((kk >> 1) & 1)
+    smu = -mu[cc] if lane & 1 else mu[cc]
+    smu2 = -mu[c2] if kk & 1 else mu[c2]
+    lo = 9 * (cc * (cc + 1) // 2) + 9 * c2              # block (cc, c2): the lane's contact on the row side
+    up = 9 * cc + 9 * (c2 * (c2 + 1) // 2)              # block (c2, cc): ... on the column side
+    ge = cc >= c2
+    base = lo if ge else up
+    o_nt = (1 if ge else 3) * td2
+    o_tn = 3 * td if ge else td
+    nn, nt, tn, tt = G[base], G[base + o_nt], G[base + o_tn], G[base + o_tn + o_nt]
+    return nn + smu2 * nt + smu * (tn + smu2 * tt)

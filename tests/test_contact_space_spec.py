@@ -7,12 +7,12 @@ from contact_space_spec import solve
 
 
 @pytest.fixture(scope="module")
-def walking_problems(bench_model, oracle_lib):
+def walking_problems(bench_blob, oracle_lib):
     """Constraint problems of a walking fly as the float64 oracle sets them up: (M, J, aref, D, qacc_smooth, warm start,
     the oracle's qacc, its iteration count, contact geoms) for 60 consecutive-ish steps."""
     from flygym_amd.controllers import TripodCPG
 
-    fly, _, m = bench_model
+    fly, m = bench_blob
     o = oracle_lib.Oracle(m.to_blob(), "f64")
     o.ctrl[42:] = 1.0
     o.step(500)
@@ -82,3 +82,34 @@ def test_a_wrong_guess_costs_iterations_not_the_answer(walking_problems):
         # and without the warm-start term (the hybrid kernels' flavour)
         qa = solve(p["M"], p["J"], p["aref"], p["D"], p["a_s"], p["ws"], warm=False)[0]
         assert np.abs(qa - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+def test_gram_blocks_and_the_column_read_give_the_oracles_A(walking_problems):
+    """Round 5 replaced A's row triangle by G, the Gram matrix of the contacts' DIRECTIONS (3 per contact, one 3 x 3 block per unordered
+    pair).  On the oracle's own problems: G packed in the kernel's block layout by the kernel's circulant rounds covers every word
+    exactly once per pair (diagonal blocks: every word at least once, consistently), and the column read — four words of one block
+    and three multiply-adds, row side or column side of the block by the contacts' order (``DualCol``) — reproduces
+    A = J M^-1 J^T of the oracle's dense Jacobian, every entry of every problem (round-5 advisor: a CPU-only test of the G-to-A
+    mapping and of the block addressing)."""
+    from contact_space_spec import dual_col, gram_floats, pack_gram
+
+    checked, most = 0, 0
+    for p in walking_problems:
+        J, M = p["J"], p["M"]
+        ncon = J.shape[0] // 4
+        most = max(most, ncon)
+        # directions out of the pyramid rows (n + mu t1, n - mu t1, n + mu t2, n - mu t2) with the benchmark's mu = 1
+        mu = np.ones(ncon)
+        Jn = 0.5 * (J[0::4] + J[1::4])
+        assert np.allclose(Jn, 0.5 * (J[2::4] + J[3::4]), atol=1e-12)          # the oracle's row order is the kernel's
+        Jt1, Jt2 = (J[0::4] - J[1::4]) / (2 * mu[:, None]), (J[2::4] - J[3::4]) / (2 * mu[:, None])
+        Jdir = np.empty((3 * ncon, J.shape[1]))
+        Jdir[0::3], Jdir[1::3], Jdir[2::3] = Jn, Jt1, Jt2
+        G, written = pack_gram(M, Jdir)
+        assert len(G) == gram_floats(ncon) and np.isfinite(G).all() and written.min() >= 1
+        A = J @ np.linalg.solve(M, J.T)
+        got = np.array([[dual_col(G, mu, i, kk) for kk in range(4 * ncon)] for i in range(4 * ncon)])
+        assert np.abs(got - A).max() <= 1e-12 * np.abs(A).max(), (ncon, np.abs(got - A).max())
+        checked += got.size
+    assert checked > 15000 and most >= 7
+    assert gram_floats(16) == 1224 and gram_floats(13) == 819                      # DESIGN section 2: the LDS the star / hybrid kernels give G

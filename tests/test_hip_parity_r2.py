@@ -186,6 +186,10 @@ def test_worlds_of_the_full_batch_follow_the_oracle(torch_mod, bench_model, orac
     assert (errs < 5e-5).mean() >= 0.6
     followed, followed_ctl = int((errs < 5e-5).sum()), int((np.array(errs_ctl) < 5e-5).sum())
     print(f"control (primal loop) followed {followed_ctl} / {len(errs)}")
+    from ledger import report
+    report("worlds_of_the_full_batch_follow_the_oracle", followed=followed, followed_primal_control=followed_ctl, picks=len(errs),
+           chaotic_partitions=int(((errs >= 5e-5) & explained).sum()), unexplained=int((~explained).sum()), median_vs_f64=float(np.median(errs64)),
+           worst_vs_f64=float(errs64.max()))
     assert followed >= followed_ctl - 2, (followed, followed_ctl)         # not worse than round 3's solver on the same picks (two worlds of slack: which chaotic partition a build leaves is its rounding's)
     assert np.median(errs64) < 5e-6 and errs64.max() < 5e-3, np.sort(errs64)[-6:]
     same_contacts = np.array(same_contacts)

@@ -651,6 +651,10 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
           f"max {devs[:, 0].max():.1e} (float32 oracle: median {np.median(devs[:, 1]):.1e}, max {devs[:, 1].max():.1e}); wall contacts {walls}")
     # round 4: the bars are what the test sees (72 / 72 lists on every configuration, median deviation 1e-4), with one step
     # of slack for a contact within rounding of its margin — not the 90 % / 80 % of round 3
+    from ledger import report
+    report("full_size_batches_from_their_own_states", config=config, lists_equal=same, total=total, comparable=close, median=float(np.median(devs[:, 0])),
+           worst=float(devs[:, 0].max()), f32_oracle_median=float(np.median(devs[:, 1])), f32_oracle_worst=float(devs[:, 1].max()),
+           beyond_tight_bar=int(beyond_tight), beyond_2e3_absolute=int((devs[:, 0] >= 2e-3).sum()), wall_contacts=int(walls))
     assert np.median(devs[:, 0]) < 2e-4 and beyond_tight <= 1
     assert total == 72 and same >= total - 1, f"{config}: contact lists equal to an oracle's in {same} of {total} steps"
     assert close >= total - 2, f"{config}: {close} of {total} steps comparable with the float64 oracle"
@@ -791,6 +795,12 @@ def test_collapsing_flies_with_every_segment_in_contact_step_like_the_oracle(tor
     summary = (f"collapse: contact lists equal in {same}/{total}, compared {len(devs)}, within the per-state bar {close}; beyond 3e-3 of the scale: kernel {int((devs > 3e-3).sum())}, "
                f"float32 oracle {int((devs32 > 3e-3).sum())}; medians {np.median(devs):.2e} / {np.median(devs32):.2e}; up to {most} contacts, {rest_contacts} on head / abdomen / wings / thorax")
     print(summary)
+    from ledger import report
+    # (round 6: the per-state bar of rounds 3-4 — 3e-3 of the scale or twice the float32 oracle's own error — as a reported count)
+    report("collapsing_flies", lists_equal=same, total=total, compared=len(devs), beyond_per_state_bar_of_round4=int(len(devs) - close),
+           beyond_3e3_kernel=int((devs > 3e-3).sum()), beyond_3e3_f32_oracle=int((devs32 > 3e-3).sum()), beyond_5e3_kernel=int((devs > 5e-3).sum()),
+           beyond_5e3_f32_oracle=int((devs32 > 5e-3).sum()), median_kernel=float(np.median(devs)), median_f32_oracle=float(np.median(devs32)),
+           worst_kernel=float(devs.max()), worst_f32_oracle=float(devs32.max()), most_contacts=int(most))
     assert same >= total - 3 and len(devs) >= 0.9 * total and close >= 0.9 * len(devs), summary
     # the kernel errs like a float32 implementation of the reference algorithm: no more states beyond the bar than the float32 oracle
     # has (x 1.5 + 4 for the count's own scatter), the same typical error

@@ -6,8 +6,8 @@ import pytest
 
 
 @pytest.fixture(scope="module")
-def settled(bench_model, oracle_lib):
-    _, _, m = bench_model
+def settled(bench_blob, oracle_lib):
+    _, m = bench_blob
     o = oracle_lib.Oracle(m.to_blob(), "f64")
     o.ctrl[42:] = 1.0
     o.step(1500)
