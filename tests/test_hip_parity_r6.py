@@ -103,7 +103,10 @@ def test_config1_rollout_runs_the_cpu_class(torch_mod, oracle_lib):
     report("config1_cpu_flavour_rollout", after_warmup=after_warmup, free_running=free, segments=n_seg, segments_tight=tight,
            segments_where_the_f32_oracle_leaves_too=by_oracle, unexplained=len(off), worst_segment=worst)
     assert not off, off
-    assert tight >= n_seg - 6, (tight, n_seg)
+    # (measured, round 6: all 60 segments within 8.3e-7, the free-running rollout within 3.2e-6 of the oracle's through all 700 driven
+    # steps — this input is not chaotic over the horizon, so the free run is held to float32 rounding too)
+    assert tight >= n_seg - 2, (tight, n_seg)
+    assert max(free.values()) < 5e-5, free
     # the reference's own invariants on this object (tests/core/test_simulation.py)
     active, force, torque, pos, normal, tangent = sim.get_ground_contact_info(fly.name)
     assert active.shape == (6,) and force.shape == (6, 3) and tangent.shape == (6, 3)
