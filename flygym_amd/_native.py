@@ -145,6 +145,9 @@ def lib():
             "nmf_retina_resample": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp]),
             "nmf_eye_params_size": (ctypes.c_size_t, []),
             "nmf_eye_render": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]),
+            "nmf_eye_plan_create": (vp, [vp, vp, vp, vp, ci, ci, cf, ci, ci]),
+            "nmf_eye_plan_destroy": (None, [vp]),
+            "nmf_eye_render_planned": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
             "nmf_odor_intensity": (ci, [vp, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
             "nmf_replay_resample": (ci, [vp, ci, ci, ctypes.c_double, ctypes.c_double, vp, ci, ci, vp, vp]),
         }

@@ -75,6 +75,23 @@ struct nmf_model {
   }
 };
 
+// Visit plan of the eye renderer (nmf_eye_plan_create): everything the kernel reads that depends on the id map, the lens and the
+// ommatidia types — with its OWN device copies of the id map, the retina run plan, the pale flags and the normalisation, so that
+// a render call is pure stream-ordered work whatever the caller does with its buffers afterwards.
+struct nmf_eye_plan {
+  int device = 0, h = 0, w = 0, n_omm = 0;
+  float fov = 0.f;
+  int n_groups[3] = {0, 0, 0};                 // [0] chunks that feed an ommatidium, [1] all chunks (frames), [2] sampled mode: pixels
+  int* visit[3] = {nullptr, nullptr, nullptr};
+  float* cones[3] = {nullptr, nullptr, nullptr};
+  float* chunk_cones[3] = {nullptr, nullptr, nullptr};
+  int* slot_omm = nullptr;
+  int16_t* id_map = nullptr; void* rplan = nullptr; uint8_t* pale = nullptr; float* inv_norm = nullptr;      // the plan's copies
+  std::vector<void*> allocs;
+  // cache key of nmf_eye_render's implicit plans: the caller's buffer addresses
+  const void* key[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct nmf_batch {
   const nmf_model* model = nullptr;
   int n_worlds = 0, device = 0, topo = 0;
@@ -91,7 +108,8 @@ struct nmf_batch {
   nmf::ChunkSched* csched_buf = nullptr;   // chunked launches (see nmf_step_kernel): ticket / completion / epoch counters
   unsigned long long* handoff_buf = nullptr;   // chunk hand-off granules (nmf_step_kernel); allocated with the batch
   // eye renderer: the visit plan of the last id map it was called with ([0] chunks that touch an ommatidium, [1] all chunks)
-  struct EyeVisitPlan { const void* id_map = nullptr; int h = 0, w = 0, n_omm = 0; float fov = 0.f; int n_groups[3] = {0, 0, 0}; int* visit[3] = {nullptr, nullptr, nullptr}; float* cones[3] = {nullptr, nullptr, nullptr}; float* chunk_cones[3] = {nullptr, nullptr, nullptr}; int* slot_omm = nullptr; } eye_plan;      // [0] chunks that feed an ommatidium, [1] all chunks (frames), [2] sampled mode: pixels
+  // nmf_eye_render (the entry without an explicit plan handle) keeps the plans it has built: a few, least recently used first out
+  std::vector<nmf_eye_plan*> eye_plans;
   int handoff_stride = 0;
   unsigned long long* clock_probe_buf = nullptr;
   const void* step_fn = nullptr; // the stepping kernel this batch launches (nmf_batch_info)
@@ -649,6 +667,7 @@ extern "C" void nmf_batch_destroy(nmf_batch* b) {
   if (!b) return;
   DeviceGuard guard(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
+  for (nmf_eye_plan* q : b->eye_plans) nmf_eye_plan_destroy(q);
   delete b;
 }
 
@@ -721,6 +740,7 @@ extern "C" int nmf_step_record(nmf_batch* b, const float* table_dev, int table_s
                                int n_steps, int obs_every, int n_joint, int n_act, float* ring_dev, int row_stride, void* stream) {
   if (!b) return fail("nmf_step_record: null batch");
   if (n_steps <= 0 || obs_every <= 0) return fail("nmf_step_record: n_steps and obs_every must be positive");
+  if (n_steps % obs_every) return fail("nmf_step_record: n_steps must be a multiple of obs_every (the trailing steps would not be recorded)");
   if (!ring_dev) return fail("nmf_step_record: null ring");
   const nmf_model* m = b->model;
   if (n_joint < 0 || n_joint > m->nv - 6 || n_act < 0 || n_act > m->nu || row_stride < 2 * n_joint + n_act + 96)
@@ -863,22 +883,18 @@ extern "C" size_t nmf_eye_params_size(void) { return sizeof(nmf_eye_params); }
 // Visit plan of the eye renderer: the chunks (16 consecutive raw pixels) to render, sorted by 32 x 32-pixel tile and cut
 // into groups of 64 (one wave's turn), each group with the bounding cone of its rays in the camera frame (axis, cos and
 // sin of the half-angle) — so that a wave can decide per group what it can see at all.  Built on the host once per id map.
-static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, int h, int w, float fov_deg, int n_omm) {
-  auto& P = b->eye_plan;
-  if (P.id_map == id_map_dev && P.h == h && P.w == w && P.fov == fov_deg && P.n_omm == n_omm) return 0;
-  // another id map (or lens): the previous plan's buffers go back (hipFree waits for the kernels that read them) — two
-  // renderers alternating on one batch rebuild every call, but no longer grow the batch's memory (round-4 advisor finding).
-  // The key is the id map's ADDRESS and shape: a caller must keep the tensor alive while it renders with it (EyeRenderer does).
-  {
-    auto drop = [&](void* q) {
-      if (!q) return;
-      auto it = std::find(b->allocs.begin(), b->allocs.end(), q);
-      if (it != b->allocs.end()) b->allocs.erase(it);
-      (void)hipFree(q);
-    };
-    for (int mode = 0; mode < 3; ++mode) { drop(P.visit[mode]); drop(P.cones[mode]); drop(P.chunk_cones[mode]); P.visit[mode] = nullptr; P.cones[mode] = nullptr; P.chunk_cones[mode] = nullptr; P.n_groups[mode] = 0; }
-    drop(P.slot_omm); P.slot_omm = nullptr; P.id_map = nullptr;
-  }
+extern "C" void nmf_eye_plan_destroy(nmf_eye_plan* P) {
+  if (!P) return;
+  DeviceGuard guard(P->device);
+  for (void* q : P->allocs) (void)hipFree(q);      // (hipFree waits for the kernels that read them)
+  delete P;
+}
+
+// NOT stream-ordered: device-to-host copies of the id map / run plan / pale flags, host-side sorting, allocations and uploads — once
+// per (id map, lens, ommatidia types).  Every failure path gives back what was allocated (nmf_eye_plan_destroy).
+static int fill_eye_plan(nmf_eye_plan* Pp, const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int h, int w, float fov_deg, int n_omm) {
+  nmf_eye_plan& P = *Pp;
+  auto dev_alloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; P.allocs.push_back(q); return q; };
   const int n_pix = h * w, n_chunk = n_pix / 16;
   std::vector<int16_t> ids((size_t)n_pix);
   HIP_OK(hipMemcpy(ids.data(), id_map_dev, sizeof(int16_t) * (size_t)n_pix, hipMemcpyDeviceToHost));
@@ -937,11 +953,8 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* p
       cones[(size_t)g * 12 + 8] = g >= g_plain ? 1.f : 0.f;
       cones[(size_t)g * 12 + 9] = lens_ok ? 1.f : 0.f;      // [9]: every ray of the IMAGE within the range of the kernel's lens polynomials
     }
-    void* pv = nullptr; void* pc = nullptr; void* pcc = nullptr;
-    if (hipMalloc(&pv, sizeof(int) * visit.size()) != hipSuccess || hipMalloc(&pc, sizeof(float) * cones.size()) != hipSuccess ||
-        hipMalloc(&pcc, sizeof(float) * ccones.size()) != hipSuccess)
-      return fail("nmf_eye_render: out of device memory for the visit plan");
-    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(pcc);
+    void* pv = dev_alloc(sizeof(int) * visit.size()); void* pc = dev_alloc(sizeof(float) * cones.size()); void* pcc = dev_alloc(sizeof(float) * ccones.size());
+    if (!pv || !pc || !pcc) return fail("nmf_eye_plan_create: out of device memory for the visit plan");
     HIP_OK(hipMemcpy(pv, visit.data(), sizeof(int) * visit.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pc, cones.data(), sizeof(float) * cones.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pcc, ccones.data(), sizeof(float) * ccones.size(), hipMemcpyHostToDevice));
@@ -960,7 +973,7 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* p
     constexpr int K = nmf::kEyeRays, S = nmf::kEyeSlots;
     std::vector<uint32_t> planw((size_t)n_chunk * 4);
     std::vector<uint8_t> pale_h((size_t)n_omm);
-    HIP_OK(hipDeviceSynchronize());        // (the plan was built on the caller's stream)
+    HIP_OK(hipDeviceSynchronize());        // (the caller's run plan was built on a stream of its own)
     HIP_OK(hipMemcpy(planw.data(), plan_dev, sizeof(uint32_t) * planw.size(), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(pale_h.data(), pale_dev, pale_h.size(), hipMemcpyDeviceToHost));
     std::vector<std::vector<int>> cell((size_t)n_omm);
@@ -1003,27 +1016,62 @@ static int build_eye_plan(nmf_batch* b, const int16_t* id_map_dev, const void* p
         cone_of(tp, 1e-4, &tcones[((size_t)g * (S / 4) + t) * 4]);
       }
     }
-    void* pv = nullptr; void* pc = nullptr; void* ps = nullptr; void* pt = nullptr;
-    if (hipMalloc(&pv, sizeof(int) * visit.size()) != hipSuccess || hipMalloc(&pc, sizeof(float) * cones.size()) != hipSuccess ||
-        hipMalloc(&ps, sizeof(int) * slots.size()) != hipSuccess || hipMalloc(&pt, sizeof(float) * tcones.size()) != hipSuccess)
-      return fail("nmf_eye_render: out of device memory for the sampling plan");
-    b->allocs.push_back(pv); b->allocs.push_back(pc); b->allocs.push_back(ps); b->allocs.push_back(pt);
+    void* pv = dev_alloc(sizeof(int) * visit.size()); void* pc = dev_alloc(sizeof(float) * cones.size());
+    void* ps = dev_alloc(sizeof(int) * slots.size()); void* pt = dev_alloc(sizeof(float) * tcones.size());
+    if (!pv || !pc || !ps || !pt) return fail("nmf_eye_plan_create: out of device memory for the sampling plan");
     HIP_OK(hipMemcpy(pt, tcones.data(), sizeof(float) * tcones.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pv, visit.data(), sizeof(int) * visit.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pc, cones.data(), sizeof(float) * cones.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ps, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice));
     P.visit[2] = (int*)pv; P.cones[2] = (float*)pc; P.chunk_cones[2] = (float*)pt; P.n_groups[2] = n_groups; P.slot_omm = (int*)ps;
   }
-  P.id_map = id_map_dev; P.h = h; P.w = w; P.fov = fov_deg; P.n_omm = n_omm;
+  // the plan's own copies of what the kernel reads from the caller's buffers
+  {
+    const size_t rbytes = nmf_retina_plan_bytes(n_pix);
+    P.id_map = (int16_t*)dev_alloc(sizeof(int16_t) * (size_t)n_pix); P.rplan = dev_alloc(rbytes);
+    P.pale = (uint8_t*)dev_alloc(((size_t)n_omm + 15) & ~(size_t)15); P.inv_norm = (float*)dev_alloc(sizeof(float) * (size_t)n_omm);
+    if (!P.id_map || !P.rplan || !P.pale || !P.inv_norm) return fail("nmf_eye_plan_create: out of device memory for the plan's copies");
+    HIP_OK(hipMemcpy(P.id_map, id_map_dev, sizeof(int16_t) * (size_t)n_pix, hipMemcpyDeviceToDevice));
+    HIP_OK(hipMemcpy(P.rplan, plan_dev, rbytes, hipMemcpyDeviceToDevice));
+    HIP_OK(hipMemcpy(P.pale, pale_dev, (size_t)n_omm, hipMemcpyDeviceToDevice));
+    HIP_OK(hipMemcpy(P.inv_norm, inv_norm_dev, sizeof(float) * (size_t)n_omm, hipMemcpyDeviceToDevice));
+    HIP_OK(hipDeviceSynchronize());
+  }
+  P.h = h; P.w = w; P.fov = fov_deg; P.n_omm = n_omm;
   return 0;
 }
 
-extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int32_t* capsule_seg_dev,
-                              const float* capsule_geom_dev, const int16_t* id_map_dev,
-                              const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
-                              uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {
-  if (!b || !p) return fail("nmf_eye_render: null batch / params");
-  if (!id_map_dev || !plan_dev || !pale_dev || !inv_norm_dev) return fail("nmf_eye_render: id map, plan, pale and inv_norm are required");
+extern "C" nmf_eye_plan* nmf_eye_plan_create(const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev,
+                                             int height, int width, float fov_deg, int n_ommatidia, int device) {
+  if (!id_map_dev || !plan_dev || !pale_dev || !inv_norm_dev) { fail("nmf_eye_plan_create: id map, plan, pale and inv_norm are required"); return nullptr; }
+  if (height <= 0 || width <= 0 || (height * width) % 16) { fail("nmf_eye_plan_create: height * width must be a positive multiple of 16"); return nullptr; }
+  if (n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia) { fail("nmf_eye_plan_create: need 0 < n_ommatidia <= 1024"); return nullptr; }
+  if (!(fov_deg > 0.f) || fov_deg > 360.f) { fail("nmf_eye_plan_create: bad field of view"); return nullptr; }
+  if (reinterpret_cast<uintptr_t>(plan_dev) & 15u) { fail("nmf_eye_plan_create: the run plan must be 16-byte aligned"); return nullptr; }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) { fail("nmf_eye_plan_create: no such device"); return nullptr; }
+  DeviceGuard guard(device);
+  nmf_eye_plan* P = new nmf_eye_plan();
+  P->device = device;
+  if (fill_eye_plan(P, id_map_dev, plan_dev, pale_dev, inv_norm_dev, height, width, fov_deg, n_ommatidia) != 0) {
+    const std::string keep = g_err;
+    nmf_eye_plan_destroy(P);
+    g_err = keep;
+    return nullptr;
+  }
+  return P;
+}
+
+// Pure stream-ordered work: argument checks on the host, one kernel launch.  Everything the kernel reads besides the batch's poses and
+// the caller's sphere / capsule lists belongs to the plan.
+extern "C" int nmf_eye_render_planned(nmf_batch* b, const nmf_eye_params* p, const nmf_eye_plan* plan, const float* spheres_dev,
+                                      const int32_t* capsule_seg_dev, const float* capsule_geom_dev,
+                                      uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {
+  if (!b || !p || !plan) return fail("nmf_eye_render: null batch / params / plan");
+  if (plan->device != b->device) return fail("nmf_eye_render: the plan lives on another device than the batch");
+  if (plan->h != p->height || plan->w != p->width || plan->fov != p->fov_deg) return fail("nmf_eye_render: the plan was made for another frame size / field of view");
+  const int n_ommatidia = plan->n_omm;
+  const int16_t* const id_map_dev = plan->id_map; const void* const plan_dev = plan->rplan; const uint8_t* const pale_dev = plan->pale; const float* const inv_norm_dev = plan->inv_norm;
   if (!frames_out_dev && !omm_out_dev) return fail("nmf_eye_render: nothing to write");
   if (p->height <= 0 || p->width <= 0 || (p->height * p->width) % 16) return fail("nmf_eye_render: height * width must be a positive multiple of 16");
   if (n_ommatidia <= 0 || n_ommatidia > nmf::kMaxOmmatidia) return fail("nmf_eye_render: need 0 < n_ommatidia <= 1024");
@@ -1065,19 +1113,45 @@ extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float
   if (p->rays_per_ommatidium != 0 && p->rays_per_ommatidium != nmf::kEyeRays) return fail("nmf_eye_render: rays_per_ommatidium must be 0 (every pixel) or 16");
   if (p->rays_per_ommatidium != 0 && frames_out_dev) return fail("nmf_eye_render: the sampled mode renders no frames (rays_per_ommatidium = 0 does)");
   A.sampled = p->rays_per_ommatidium;
-  if (build_eye_plan(b, id_map_dev, plan_dev, pale_dev, p->height, p->width, p->fov_deg, n_ommatidia) != 0) return -1;
   const int mode = A.sampled ? 2 : frames_out_dev ? 1 : 0;
 #define NMF_EYE_LAUNCH(SAMPLED, RELIEF, FRAMES)                                                                                      \
   hipLaunchKernelGGL((nmf::nmf_eye_kernel<SAMPLED, RELIEF, FRAMES>), dim3((unsigned)(2 * b->n_worlds)), dim3(nmf::kEyeThreads), 0, (hipStream_t)stream, A, \
                      b->st.seg_xpos, b->st.seg_xquat, m->nseg, spheres_dev ? spheres_dev : b->st.seg_xpos,                           \
                      capsule_seg_dev, capsule_geom_dev, reinterpret_cast<const nmf::u32x4*>(plan_dev),                               \
-                     b->eye_plan.visit[mode], b->eye_plan.cones[mode], reinterpret_cast<const float4*>(b->eye_plan.chunk_cones[mode]), b->eye_plan.n_groups[mode], \
-                     id_map_dev, b->eye_plan.slot_omm, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev)
+                     plan->visit[mode], plan->cones[mode], reinterpret_cast<const float4*>(plan->chunk_cones[mode]), plan->n_groups[mode], \
+                     id_map_dev, plan->slot_omm, pale_dev, inv_norm_dev, n_ommatidia, frames_out_dev, omm_out_dev)
   if (A.terrain_kind != 0) { if (A.sampled) NMF_EYE_LAUNCH(true, true, false); else if (frames_out_dev) NMF_EYE_LAUNCH(false, true, true); else NMF_EYE_LAUNCH(false, true, false); }
   else { if (A.sampled) NMF_EYE_LAUNCH(true, false, false); else if (frames_out_dev) NMF_EYE_LAUNCH(false, false, true); else NMF_EYE_LAUNCH(false, false, false); }
 #undef NMF_EYE_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// The entry without a plan handle: plans are built on first use and kept per batch (up to four, least recently used first out), keyed
+// on the ADDRESSES of the four buffers + shape + lens.  The first call with a new key is therefore NOT stream-ordered (see
+// nmf_eye_plan_create) and must not sit inside a stream capture, and a caller that rewrites a buffer in place must make a new
+// plan (nmf_eye_plan_create) — include/nmf.h says so at the declaration.
+extern "C" int nmf_eye_render(nmf_batch* b, const nmf_eye_params* p, const float* spheres_dev, const int32_t* capsule_seg_dev,
+                              const float* capsule_geom_dev, const int16_t* id_map_dev,
+                              const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev, int n_ommatidia,
+                              uint8_t* frames_out_dev, float* omm_out_dev, void* stream) {
+  if (!b || !p) return fail("nmf_eye_render: null batch / params");
+  if (!id_map_dev || !plan_dev || !pale_dev || !inv_norm_dev) return fail("nmf_eye_render: id map, plan, pale and inv_norm are required");
+  auto& L = b->eye_plans;
+  nmf_eye_plan* plan = nullptr;
+  for (size_t i = 0; i < L.size(); ++i) {
+    nmf_eye_plan* q = L[i];
+    if (q->key[0] == id_map_dev && q->key[1] == plan_dev && q->key[2] == pale_dev && q->key[3] == inv_norm_dev && q->h == p->height && q->w == p->width &&
+        q->fov == p->fov_deg && q->n_omm == n_ommatidia) { plan = q; L.erase(L.begin() + (long)i); L.push_back(q); break; }
+  }
+  if (!plan) {
+    plan = nmf_eye_plan_create(id_map_dev, plan_dev, pale_dev, inv_norm_dev, p->height, p->width, p->fov_deg, n_ommatidia, b->device);
+    if (!plan) return -1;
+    plan->key[0] = id_map_dev; plan->key[1] = plan_dev; plan->key[2] = pale_dev; plan->key[3] = inv_norm_dev;
+    if (L.size() >= 4) { nmf_eye_plan_destroy(L.front()); L.erase(L.begin()); }
+    L.push_back(plan);
+  }
+  return nmf_eye_render_planned(b, p, plan, spheres_dev, capsule_seg_dev, capsule_geom_dev, frames_out_dev, omm_out_dev, stream);
 }
 
 extern "C" int nmf_odor_intensity(nmf_batch* b, const int32_t* sensor_seg_dev, const float* sensor_rel_dev, int n_sensors,

@@ -223,8 +223,8 @@ class HIPSimulation:
     def _record(self, table, act_ids, start, n_steps, record_every, n_act):
         t = self._torch
         k = int(record_every)
-        if k < 1 or int(n_steps) < k:
-            raise ValueError(f"record_every must be in 1..n_steps, got {record_every} for {n_steps} steps")
+        if k < 1 or int(n_steps) < k or int(n_steps) % k:
+            raise ValueError(f"record_every must be in 1..n_steps and divide n_steps, got {record_every} for {n_steps} steps")
         width = 2 * (self.model.nv - 6) + int(n_act) + 96
         ring = t.empty((int(n_steps) // k, self.n_worlds, width), dtype=t.float32, device=self.device)
         return self.record_into(ring, table, act_ids, start, n_steps, k, n_act)
@@ -236,8 +236,8 @@ class HIPSimulation:
         nj = self.model.nv - 6
         width = 2 * nj + int(n_act) + 96
         k = int(record_every)
-        if k < 1 or int(n_steps) < k:
-            raise ValueError(f"record_every must be in 1..n_steps, got {record_every} for {n_steps} steps")
+        if k < 1 or int(n_steps) < k or int(n_steps) % k:
+            raise ValueError(f"record_every must be in 1..n_steps and divide n_steps, got {record_every} for {n_steps} steps")
         if ring.dtype != t.float32 or ring.device != self.device or ring.ndim != 3 or not ring.is_contiguous() \
                 or ring.shape[0] < int(n_steps) // k or ring.shape[1] != self.n_worlds or ring.shape[2] < width:
             raise ValueError(f"the observation ring must be a contiguous float32 ({int(n_steps) // k}+, {self.n_worlds}, {width}+) tensor on {self.device}")

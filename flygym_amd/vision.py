@@ -155,6 +155,24 @@ class EyeRenderer:
             raise _native.NativeError("nmf_eye_params layout mismatch between vision.py and libnmf_hip.so")
         self._params = p
         self._spheres = torch.as_tensor(self.scene.spheres, device=sim.device) if len(self.scene.spheres) else None
+        # the visit plan: an explicit handle of the library (nmf_eye_plan_create — synchronous, once), so that every render call is
+        # one stream-ordered kernel launch and a vision tick can be captured in a hipGraph
+        id_map, pale, inv_norm, plan = self.retina._device_constants(torch, sim.device)
+        if plan is None:
+            raise ValueError("the eye renderer needs a retina whose pixel count is a multiple of 16")
+        torch.cuda.synchronize(sim.device)
+        self._plan_h = _native.lib().nmf_eye_plan_create(id_map.data_ptr(), plan.data_ptr(), pale.data_ptr(), inv_norm.data_ptr(),
+                                                         p.height, p.width, p.fov_deg, self.retina.num_ommatidia, sim.device_index)
+        if not self._plan_h:
+            raise _native.NativeError(_native.lib().nmf_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan_h", None):
+                _native.lib().nmf_eye_plan_destroy(self._plan_h)
+                self._plan_h = None
+        except Exception:
+            pass
 
     def set_spheres(self, spheres) -> None:
         """Move the spheres: ``(n_spheres, 4)`` shared by all worlds or ``(n_worlds, n_spheres, 4)`` per world
@@ -171,17 +189,22 @@ class EyeRenderer:
         self._spheres = s
 
     def _call(self, frames, omm):
-        t = self.sim._torch
-        id_map, pale, inv_norm, plan = self.retina._device_constants(t, self.sim.device)
-        if plan is None:
-            raise ValueError("the eye renderer needs a retina whose pixel count is a multiple of 16")
-        _native.check(_native.lib().nmf_eye_render(
-            self.sim._batch_h, ctypes.byref(self._params),
+        _native.check(_native.lib().nmf_eye_render_planned(
+            self.sim._batch_h, ctypes.byref(self._params), self._plan_h,
             self._spheres.data_ptr() if self._spheres is not None else None,
             self._cap_seg.data_ptr() if self._cap_seg is not None else None,
             self._cap_geom.data_ptr() if self._cap_geom is not None else None,
-            id_map.data_ptr(), plan.data_ptr(), pale.data_ptr(), inv_norm.data_ptr(), self.retina.num_ommatidia,
             frames.data_ptr() if frames is not None else None, omm.data_ptr() if omm is not None else None, self.sim._stream()))
+
+    def render_into(self, omm):
+        """:meth:`render` into a caller-owned ``(n_worlds, 2, num_ommatidia, 2)`` float32 tensor: no allocation, one kernel
+        launch on the current stream — what a captured vision tick (``step(n)`` + this) replays."""
+        t = self.sim._torch
+        want = (self.sim.n_worlds, 2, self.retina.num_ommatidia, 2)
+        if tuple(omm.shape) != want or omm.dtype != t.float32 or omm.device != self.sim.device or not omm.is_contiguous():
+            raise ValueError(f"render_into needs a contiguous float32 {want} tensor on {self.sim.device}")
+        self._call(None, omm)
+        return omm
 
     def render(self):
         """Ommatidia readings ``(n_worlds, 2, num_ommatidia, 2)`` float32 (eye 0 = left)."""

@@ -24,6 +24,7 @@ extern "C" {
 
 typedef struct nmf_model nmf_model;
 typedef struct nmf_batch nmf_batch;
+typedef struct nmf_eye_plan nmf_eye_plan;
 
 /* Per-world fields addressable through nmf_field_ptr / nmf_gather_* */
 enum nmf_field {
@@ -75,7 +76,14 @@ int nmf_model_dims(const nmf_model* model, int32_t out[10]);
 int nmf_model_contact_bound(const nmf_model* model);
 
 /* Allocate the state of n_worlds identical worlds on `device` and reset them to the model's
- * "neutral" keyframe.  Replaces: mjw.put_data(nworld=...)  (warp/simulation.py:418-424). */
+ * "neutral" keyframe.  Replaces: mjw.put_data(nworld=...)  (warp/simulation.py:418-424).
+ * NOT stream-ordered (allocations, uploads, one synchronising reset).
+ * A model compiled with option/noslip_iterations > 0 (the reference's CPU class: mujoco_globals.yaml:15 under mujoco.mj_step,
+ * simulation.py:74-76) runs that friction-only post-pass on every step in contact — the engine of flygym_amd.Simulation, meant for
+ * ONE world: the batch then also allocates the pass's scratch, 198 x 200 floats = 158 400 bytes PER WORLD (4096 worlds: 649 MB;
+ * nmf_batch_info out[12] says whether), and a step that takes the primal path costs one articulated-body solve per constraint row more.  The
+ * reference's batched class strips the option before it compiles the model (warp/simulation.py:427-448) and so does
+ * flygym_amd.HIPSimulation; a C caller that wants the batched semantics compiles its model with noslip_iterations = 0. */
 nmf_batch* nmf_batch_create(const nmf_model* model, int n_worlds, int device);
 void nmf_batch_destroy(nmf_batch* batch);
 int nmf_batch_n_worlds(const nmf_batch* batch);
@@ -108,8 +116,9 @@ nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, int device,
  * only, 1 star flavour, 2 hybrid flavour), out[4] contacts it takes (steps with more go to the primal loop), out[5] flies
  * (workgroups) per CU, out[6] resident workgroups of the device, out[7] chunked launches (0 / 1), out[8] max chunks,
  * out[9] 1000 * chunk_div, out[10] world-order policy (0 in order, 1 costliest first, 2 none, 3 auto, -1 measured), out[11]
- * solver option bits in effect, out[12] noslip iterations, out[13] contact capacity, out[14] LDS bytes / out[15] vector
- * registers of the stepping kernel (from the loaded code object). */
+ * solver option bits in effect, out[12] noslip iterations (> 0: the CPU class's flavour — the batch holds 158 400 bytes of noslip
+ * scratch per world, see nmf_batch_create), out[13] contact capacity, out[14] LDS bytes / out[15] vector registers of the
+ * stepping kernel (from the loaded code object). */
 int nmf_batch_info(const nmf_batch* batch, int32_t out[16]);
 
 /* Contacts kept per world and step: min(max_contacts, 48); returns the capacity in effect (negative on error).  Contacts
@@ -144,7 +153,8 @@ int nmf_step_replay(nmf_batch* batch, const float* table_dev, int table_steps, i
  * in the layout of nmf_pack_observations — [joint angles | joint velocities | forces of the first n_act actuators | the 96
  * contact-sensor floats] — and with its values: each row is bit for bit what nmf_pack_observations gives when the launch ends at
  * that step.  ring_dev: float32 [n_steps / obs_every][n_worlds][row_stride].  The contact sensors and actuator forces are
- * evaluated on the recorded steps (and, as always, on the launch's last step for the batch's own arrays). */
+ * evaluated on the recorded steps (and, as always, on the launch's last step for the batch's own arrays).
+ * n_steps must be a multiple of obs_every (a trailing partial window would be stepped but never recorded: refused). */
 int nmf_step_record(nmf_batch* batch, const float* table_dev, int table_steps, int n_act_table, const int32_t* act_ids_dev, int start,
                     int n_steps, int obs_every, int n_joint, int n_act, float* ring_dev, int row_stride, void* stream);
 
@@ -231,7 +241,28 @@ typedef struct nmf_eye_params {
 /* sizeof(nmf_eye_params) as this library was compiled: lets a foreign-language binding verify its struct layout. */
 size_t nmf_eye_params_size(void);
 
-/* spheres_dev: (x, y, z, radius) per sphere, float32.  id_map / plan / pale / inv_norm as for nmf_retina_resample (the
+/* The visit plan of the renderer: which 16-pixel chunks feed an ommatidium, in which order, with the bounding cones of their rays,
+ * the sampled mode's pixel lists — and the plan's OWN device copies of the id map, the retina run plan (nmf_retina_plan), the pale
+ * flags and the normalisation, so that later changes to the caller's buffers cannot reach a render.  nmf_eye_plan_create is NOT
+ * stream-ordered and must not be called inside a stream capture: it synchronises the device, copies the id map / run plan / pale
+ * flags to the host, sorts there, allocates and uploads (tens of milliseconds, once per id map and lens).  The plan belongs to the
+ * device it was made on and to no batch: any batch on that device can render with it.  NULL on error (nmf_last_error). */
+nmf_eye_plan* nmf_eye_plan_create(const int16_t* id_map_dev, const void* plan_dev, const uint8_t* pale_dev, const float* inv_norm_dev,
+                                  int height, int width, float fov_deg, int n_ommatidia, int device);
+void nmf_eye_plan_destroy(nmf_eye_plan* plan);
+
+/* Render with an explicit plan: argument checks and ONE kernel launch — stream-ordered, hipGraph-capturable (a vision tick =
+ * nmf_step + nmf_eye_render_planned captures as one graph).  params->height / width / fov_deg must be the plan's. */
+int nmf_eye_render_planned(nmf_batch* batch, const nmf_eye_params* params, const nmf_eye_plan* plan, const float* spheres_dev,
+                           const int32_t* capsule_seg_dev, const float* capsule_geom_dev, uint8_t* frames_out_dev, float* omm_out_dev,
+                           void* stream);
+
+/* The same without a handle: the batch builds a plan on the first call with a new (id_map_dev, plan_dev, pale_dev, inv_norm_dev,
+ * shape, lens) — keyed on the buffer ADDRESSES — and keeps up to four of them (least recently used first out).  That first call
+ * is therefore NOT stream-ordered (see nmf_eye_plan_create) and not capturable; later calls with the same key are.  The plan holds
+ * copies: a caller that rewrites one of the four buffers in place keeps rendering with the old contents until it passes other
+ * addresses — use the explicit handle where that matters.
+ * spheres_dev: (x, y, z, radius) per sphere, float32.  id_map / plan / pale / inv_norm as for nmf_retina_resample (the
  * plan is required).  frames_out_dev: NULL or uint8 [n_worlds][2][height*width][3] raw eye frames;
  * omm_out_dev: NULL or float32 [n_worlds][2][n_ommatidia][2].  Rendering frames and resampling them with
  * nmf_retina_resample gives bit-identical ommatidia readings (integer sums).

@@ -204,7 +204,8 @@ def test_round5_entry_points_refuse_bad_arguments(torch_mod):
         return lib.nmf_step_record(h, a["table"], a["table_steps"], a["n_act_table"], a["ids"], a["start"], a["n_steps"], a["obs_every"],
                                    a["n_joint"], a["n_act"], a["ring"], a["stride"], None)
 
-    bad = [dict(n_steps=0), dict(n_steps=-4), dict(obs_every=0), dict(ring=None), dict(stride=269), dict(n_joint=67), dict(n_act=49), dict(n_joint=-1),
+    bad = [dict(n_steps=0), dict(n_steps=-4), dict(obs_every=0), dict(n_steps=3, obs_every=2),      # (round 6: a trailing partial window is refused)
+            dict(ring=None), dict(stride=269), dict(n_joint=67), dict(n_act=49), dict(n_joint=-1),
            dict(table=ring.data_ptr(), table_steps=10, n_act_table=42, ids=None), dict(table=ring.data_ptr(), table_steps=0, n_act_table=42, ids=ring.data_ptr())]
     for kw in bad:
         assert record(**kw) != 0, kw
