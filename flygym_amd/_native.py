@@ -21,7 +21,7 @@ INCLUDE = PKG.parent / "include"
 
 FIELDS = dict(
     qpos=0, qvel=1, ctrl=2, qacc_warmstart=3, seg_xpos=4, seg_xquat=5, site_xpos=6,
-    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12, stats_sum=13, contact_geom=14,
+    actuator_force=7, sensordata=8, time=9, stats=10, qacc=11, cost=12, stats_sum=13, contact_geom=14, act=15,
 )
 
 INT_FIELDS = frozenset({"stats_sum"})   # fields whose 32-bit words are unsigned integer counters, not floats
@@ -38,16 +38,17 @@ class BatchOptions(ctypes.Structure):
 
     _fields_ = [("struct_size", ctypes.c_int32), ("solver", ctypes.c_int32), ("sched", ctypes.c_int32), ("order", ctypes.c_int32),
                 ("max_chunks", ctypes.c_int32), ("min_chunk_steps", ctypes.c_int32), ("order_every", ctypes.c_int32),
-                ("rest_slow", ctypes.c_int32), ("chunk_div", ctypes.c_float)]
+                ("rest_slow", ctypes.c_int32), ("chunk_div", ctypes.c_float), ("flies_per_cu", ctypes.c_int32)]
 
     SOLVER = {"": 0, "default": 0, "primal": 1, "nohist": 2, "nofallback": 4}
     SCHED = {"": 0, "chunks": 0, "plain": 1}
     ORDER = {"": 0, "auto": 0, "inorder": 1, "costliest": 2, "none": 3, "policy": 4}
 
     @classmethod
-    def make(cls, solver="", sched="", order="", max_chunks=0, min_chunk_steps=0, order_every=0, rest_slow=False, chunk_div=0.0):
+    def make(cls, solver="", sched="", order="", max_chunks=0, min_chunk_steps=0, order_every=0, rest_slow=False, chunk_div=0.0,
+             flies_per_cu=0):
         return cls(ctypes.sizeof(cls), cls.SOLVER[solver], cls.SCHED[sched], cls.ORDER[order], int(max_chunks), int(min_chunk_steps),
-                   int(order_every), int(bool(rest_slow)), float(chunk_div))
+                   int(order_every), int(bool(rest_slow)), float(chunk_div), int(flies_per_cu))
 
 
 INFO_KEYS = ("kernel_family", "terrain_kernel", "tether_kernel", "contact_space_flavour", "contact_space_max_contacts", "flies_per_cu",

@@ -436,7 +436,28 @@ def compile_world(world) -> CompiledModel:
 
     # ---- actuators (MJCF order: in the order they were added) -----------------
     act_type, act_trn, act_gain, act_bias, act_frc, act_ctrl, act_lim = [], [], [], [], [], [], []
+    general_rows = {}          # actuator index -> its row of act_general (the types beyond the stateless affine ones)
+    affine_dofs = set()        # dofs the kernel's affine pass already writes: one actuator per dof there (lane = actuator, plain stores)
     for a in fly.actuators:
+        if a["kind"] != "adhesion" and a["kind"] not in _GENERAL_KINDS:
+            if dof_index[a["jointdof"]] in affine_dofs:
+                # a second actuator on a dof (the reference allows several types on one joint, compose/fly.py:310-312): the same
+                # affine law as a row of the general pass, which adds to the dof's force atomically
+                a = dict(a, kind="affine", jointdof_kind=a["kind"])
+            else:
+                affine_dofs.add(dof_index[a["jointdof"]])
+        if a["kind"] in _GENERAL_KINDS or a["kind"] == "affine":
+            # the stepping kernel's affine pass sees a motor of gain 0 without a force limit; the general pass (nmf_step.hip
+            # actuation_general, oracle general_actuator) computes the force from the act_general row
+            general_rows[len(act_type)] = _general_row(a, dof_index[a["jointdof"]])
+            act_type.append(ACT_MOTOR)
+            act_trn.append(dof_index[a["jointdof"]])
+            act_gain.append(0.0)
+            act_bias.append([0.0, 0.0])
+            act_frc.append(a["forcerange"])
+            act_ctrl.append(a["ctrlrange"])
+            act_lim.append([0, int(a["ctrllimited"])])
+            continue
         if a["kind"] == "adhesion":
             act_type.append(ACT_ADHESION)
             act_trn.append(int(dyn_of_seg[seg_index[a["segment"]]]))
@@ -591,6 +612,13 @@ def compile_world(world) -> CompiledModel:
             if s not in seg_dofs and s not in referenced:
                 seg_invw[s] = body_invw[int(dyn_of_seg[s])]
     m["seg_invweight0"] = seg_invw
+    if general_rows:
+        # acc0 of MuJoCo's actuators: |M^-1 moment| at qpos0 (the muscle model's peak force when `force` < 0 is scale / acc0)
+        gen = np.zeros((nu, _ACTGEN))
+        for u, row in general_rows.items():
+            row[31] = abs(row[5]) * float(np.linalg.norm(Minv[:, int(m["act_trn"][u])]))
+            gen[u] = row
+        m["act_general"] = gen
     m["geom_invweight0"] = seg_invw[contact_segs, 0].reshape(ng) if ng else np.zeros(0)
 
     # tether weld (TetheredWorld): six bilateral rows holding the root body at its spawn pose.  The reference welds
@@ -612,6 +640,61 @@ def compile_world(world) -> CompiledModel:
         "semantics": sem.as_dict(),
     }
     return m
+
+
+_GENERAL_KINDS = ("intvelocity", "damper", "cylinder", "muscle")
+_ACTGEN = 32
+
+
+def _general_row(a: dict, dof: int) -> np.ndarray:
+    """One row of ``act_general``: MuJoCo's general actuator (dyntype / gaintype / biastype with their parameter vectors) as the
+    actuator shortcuts of the XML reference expand to it (``XMLreference.html#actuator-intvelocity`` ... ``-muscle``; reference
+    ``compose/fly.py:65-77, 301-369`` forwards the shortcut and its attributes to MJCF).  Layout: 0 flags (1 on | 2
+    forcelimited | the actuated dof << 8 — the kernel's general pass takes the dof from here: the copy of ``act_trn`` it uploads
+    points these actuators at dof 0, so that the affine pass's plain store of their zero force races with nobody), 1 dyntype (0 none, 1 integrator, 2 filter, 3 filterexact, 4 muscle), 2 gaintype (0 fixed, 1 affine, 2 muscle),
+    3 biastype (0 none, 1 affine, 2 muscle), 4 actlimited, 5 gear, 6..8 dynprm, 9..17 gainprm, 18..26 biasprm, 27..28 actrange,
+    29..30 lengthrange, 31 acc0 (filled in by the caller)."""
+    r = np.zeros(_ACTGEN)
+    kind = a["kind"]
+    r[0] = 1 + (2 if a["forcelimited"] else 0) + (int(dof) << 8)
+    r[5] = a.get("gear", 1.0)
+    if kind == "affine":                # position / velocity / motor on a dof that another actuator already drives (see compile_world)
+        r[5] = 1.0                      # (a motor's gear is folded into its gain, as in the affine pass)
+        r[1], r[2], r[3] = 0, 0, 1
+        kp, kv = a.get("kp", 1.0), a.get("kv", 0.0)
+        if a["jointdof_kind"] == "position":
+            r[9], r[18:21] = kp, (0.0, -kp, -kv)
+        elif a["jointdof_kind"] == "velocity":
+            kv = a.get("kv", 1.0)
+            r[9], r[18:21] = kv, (0.0, 0.0, -kv)
+        else:
+            r[9] = a.get("gear", 1.0)
+    elif kind == "intvelocity":           # integrator; force = kp (act - q) - kv qd; the activation is clamped to actrange
+        kp, kv = a.get("kp", 1.0), a.get("kv", 0.0)
+        r[1], r[2], r[3], r[4] = 1, 0, 1, 1
+        r[9] = kp
+        r[18:21] = (0.0, -kp, -kv)
+        r[27:29] = a["actrange"]
+    elif kind == "damper":              # force = -kv * velocity * ctrl (affine gain, no bias), ctrl >= 0
+        r[1], r[2], r[3] = 0, 1, 0
+        r[9:12] = (0.0, 0.0, -a.get("kv", 1.0))
+    elif kind == "cylinder":            # first-order filter of the control; force = area * act + bias . (1, length, velocity)
+        r[1], r[2], r[3] = 2, 0, 1
+        r[6] = a.get("timeconst", 1.0)
+        r[9] = a.get("area", 1.0)
+        r[18:21] = a.get("bias", (0.0, 0.0, 0.0))
+    elif kind == "muscle":
+        r[1], r[2], r[3] = 4, 2, 2
+        r[6:8] = a.get("timeconst", (0.01, 0.04))
+        r[8] = a.get("tausmooth", 0.0)
+        prm = (*a.get("range", (0.75, 1.05)), a.get("force", -1.0), a.get("scale", 200.0), a.get("lmin", 0.5), a.get("lmax", 1.6),
+               a.get("vmax", 1.5), a.get("fpmax", 1.3), a.get("fvmax", 1.2))
+        r[9:18] = prm
+        r[18:27] = prm
+        r[29:31] = a["lengthrange"]
+    else:
+        raise ValueError(kind)
+    return r
 
 
 def _solimp5(t):

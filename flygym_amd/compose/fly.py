@@ -49,9 +49,18 @@ class ActuatorType(Enum):
 
 
 # Stateless affine actuators: force = gain ctrl + bias_q q + bias_v qd (MuJoCo's position: gain kp, bias (-kp, -kv);
-# velocity: gain kv, bias (0, -kv); motor: gain gear).  The stateful types (intvelocity, cylinder, muscle: an activation
-# state per actuator) and damper (gain proportional to the joint velocity) are refused loudly.
-_SUPPORTED_ACTUATORS = (ActuatorType.POSITION, ActuatorType.MOTOR, ActuatorType.VELOCITY)
+# velocity: gain kv, bias (0, -kv); motor: gain gear) run in the stepping kernel's affine pass.  The other joint actuators of the
+# reference's ActuatorType (compose/fly.py:65-77) — intvelocity, cylinder, muscle (an activation state per actuator) and damper
+# (gain proportional to the joint velocity) — are MuJoCo's general actuator (compiler/model.py::_general_row; round 6).
+_AFFINE_ACTUATORS = (ActuatorType.POSITION, ActuatorType.MOTOR, ActuatorType.VELOCITY)
+# attributes of the MJCF shortcuts this engine takes (XMLreference.html#actuator-*); anything else is refused by name
+_ACTUATOR_ATTRS = {
+    ActuatorType.POSITION: ("kp", "kv"), ActuatorType.VELOCITY: ("kv",), ActuatorType.MOTOR: ("gear",),
+    ActuatorType.INTVELOCITY: ("kp", "kv", "actrange", "gear"), ActuatorType.DAMPER: ("kv", "gear"),
+    ActuatorType.CYLINDER: ("timeconst", "area", "diameter", "bias", "gear"),
+    ActuatorType.MUSCLE: ("timeconst", "tausmooth", "range", "force", "scale", "lmin", "lmax", "vmax", "fpmax", "fvmax", "lengthrange", "gear"),
+}
+_VECTOR_ATTRS = {"actrange": 2, "bias": 3, "range": 2, "lengthrange": 2}
 
 
 class Fly:
@@ -226,10 +235,8 @@ class Fly:
         **kwargs: Any,
     ) -> dict[JointDOF, dict]:
         actuator_type = ActuatorType(actuator_type)
-        if actuator_type not in _SUPPORTED_ACTUATORS:
-            raise NotImplementedError(
-                f"actuator type '{actuator_type.value}' is not implemented in the MI355X engine"
-            )
+        if actuator_type == ActuatorType.ADHESION:
+            raise ValueError("adhesion actuators act on body segments: use add_leg_adhesion()")
         if neutral_input is None:
             neutral_input = {}
         if actuator_type == ActuatorType.POSITION:
@@ -240,11 +247,41 @@ class Fly:
                     self.skeleton.axis_order
                 ).joint_angles_lookup_rad
         ctrlrange = kwargs.pop("ctrlrange", None)
-        known = {k: float(kwargs.pop(k)) for k in ("kp", "kv", "gear") if k in kwargs}
+        known = {}
+        for k in _ACTUATOR_ATTRS[actuator_type]:
+            if k not in kwargs:
+                continue
+            v = kwargs.pop(k)
+            if k == "timeconst" and actuator_type == ActuatorType.MUSCLE:
+                known[k] = tuple(map(float, v))
+                if len(known[k]) != 2:
+                    raise ValueError("muscle timeconst takes (activation, deactivation) time constants")
+            elif k in _VECTOR_ATTRS:
+                known[k] = tuple(map(float, v))
+                if len(known[k]) != _VECTOR_ATTRS[k]:
+                    raise ValueError(f"actuator attribute {k} takes {_VECTOR_ATTRS[k]} numbers")
+            else:
+                known[k] = float(v)
         if kwargs:
             raise NotImplementedError(
                 f"actuator attributes {sorted(kwargs)} are not supported by the MI355X engine yet"
             )
+        # what MuJoCo's compiler checks for these shortcuts (same conditions, its wording where remembered)
+        if actuator_type == ActuatorType.INTVELOCITY:
+            if "actrange" not in known or not known["actrange"][0] < known["actrange"][1]:
+                raise ValueError("intvelocity actuators need actrange=(low, high) with low < high (their activation is clamped to it)")
+        if actuator_type == ActuatorType.DAMPER:
+            if known.get("kv", 1.0) < 0:
+                raise ValueError("damping coefficient cannot be negative")
+            if ctrlrange is None or min(ctrlrange) < 0:
+                raise ValueError("damper actuators need a non-negative ctrlrange (damper control range cannot be negative)")
+        if actuator_type == ActuatorType.CYLINDER and "diameter" in known:
+            known["area"] = float(np.pi / 4.0 * known.pop("diameter") ** 2)
+        if actuator_type == ActuatorType.MUSCLE:
+            if "lengthrange" not in known or not known["lengthrange"][0] < known["lengthrange"][1]:
+                raise NotImplementedError(
+                    "muscle actuators need lengthrange=(low, high) here: MuJoCo derives it by simulation at compile time "
+                    "(mj_setLengthRange) for joints without limits, which this engine does not reproduce")
         out = {}
         for dof in jointdofs:
             if dof not in self.joint_params:

@@ -49,28 +49,64 @@ class BaseWorld(ABC):
     def _attach_fly(self, fly: Fly, spawn_position, spawn_rotation: Rotation3D, *args, **kwargs) -> str:
         """Record how the fly hangs in this world; returns the free-joint name."""
 
+    # what one fly's attachment sets on the world (the single-fly attributes the compiler reads); a world with several flies keeps
+    # one record per fly and hands the compiler one fly at a time (single_fly_view)
+    _ATTACHMENT_FIELDS = ("spawn_position", "spawn_quat", "bodysegs_with_ground_contact", "ground_contact_params",
+                          "add_ground_contact_sensors", "legpos_to_groundcontactsensors_by_fly")
+
     def add_fly(self, fly: Fly, spawn_position, spawn_rotation: Rotation3D, *args: Any, **kwargs: Any) -> None:
+        """Attach a fly (reference ``compose/world.py:95-149``).  A world takes several flies, as the reference's does.  The
+        reference gives fly geoms ``contype = conaffinity = 0`` and adds explicit fly-ground pairs only (``compose/fly.py:609-610``,
+        ``compose/world.py:300-309``): flies of one world never touch each other, so each is its own dynamical system — the
+        simulation classes step one batch per fly (``simulation.py::MultiFlyHIPSimulation``)."""
         if fly.name in self._fly_lookup:
             raise ValueError(f"Fly with name '{fly.name}' already exists in the world.")
-        if self._fly_lookup:
-            raise NotImplementedError(
-                "one fly per world: the batch axis of HIPSimulation is the way to run many flies"
-            )
-        self._fly_lookup[fly.name] = fly
-        freejoint = self._attach_fly(fly, spawn_position, spawn_rotation, *args, **kwargs)
         if spawn_rotation.format != "quat":
             raise ValueError(
                 "Freejoint neutral rotation can only be specified in quaternion format "
                 f"for now. Got {spawn_rotation}."
             )
+        sensors_so_far = dict(self.legpos_to_groundcontactsensors_by_fly or {})
+        self._fly_lookup[fly.name] = fly
+        freejoint = self._attach_fly(fly, spawn_position, spawn_rotation, *args, **kwargs)
         self.spawn_position = np.asarray(spawn_position, dtype=np.float64)
         self.spawn_quat = spawn_rotation.as_quat()
         self.world_dof_neutral_states[freejoint] = [*self.spawn_position, *spawn_rotation.values]
+        if not hasattr(self, "_attachments"):
+            self._attachments = {}
+        self._attachments[fly.name] = {k: getattr(self, k) for k in self._ATTACHMENT_FIELDS}
+        if self.legpos_to_groundcontactsensors_by_fly is not None:       # the by-fly lookup of the whole world (reference name)
+            sensors_so_far.update(self.legpos_to_groundcontactsensors_by_fly)
+            self.legpos_to_groundcontactsensors_by_fly = sensors_so_far
         self._compiled = None
 
-    def compile_model(self):
-        """The engine's compiled model of this world (cached until the world changes)."""
+    def single_fly_view(self, fly_name: str) -> "BaseWorld":
+        """This world with ``fly_name`` as its only fly (a shallow copy: same terrain, options and semantics object): what the
+        compiler and one batch of a multi-fly simulation see."""
+        import copy
+
+        if fly_name not in self._fly_lookup:
+            raise KeyError(f"no fly named '{fly_name}' in world '{self.name}'")
+        view = copy.copy(self)
+        view._fly_lookup = {fly_name: self._fly_lookup[fly_name]}
+        for k, v in self._attachments[fly_name].items():
+            setattr(view, k, v)
+        view.world_dof_neutral_states = {k: v for k, v in self.world_dof_neutral_states.items() if k == f"{fly_name}/"}
+        view._compiled = None
+        return view
+
+    def compile_model(self, fly_name: str | None = None):
+        """The engine's compiled model of this world (cached until the world changes).  A world with several flies compiles one
+        model per fly (``fly_name``): its flies are independent dynamical systems (see :meth:`add_fly`)."""
         from ..compiler.model import compile_world
+
+        if len(self._fly_lookup) > 1:
+            if fly_name is None:
+                raise ValueError(f"world '{self.name}' holds {len(self._fly_lookup)} flies: compile_model(fly_name) compiles one of them "
+                                 f"({', '.join(self._fly_lookup)})")
+            return self.single_fly_view(fly_name).compile_model()
+        if fly_name is not None and fly_name not in self._fly_lookup:
+            raise KeyError(f"no fly named '{fly_name}' in world '{self.name}'")
 
         # the cache is only as good as what it was compiled from: world.semantics is a plain mutable object, so a flag set
         # after the first compile must not be silently ignored (ADVICE r2)

@@ -114,6 +114,7 @@ struct nmf_batch {
   unsigned long long* clock_probe_buf = nullptr;
   const void* step_fn = nullptr; // the stepping kernel this batch launches (nmf_batch_info)
   int per_cu = 0;                // workgroups of it a CU holds
+  unsigned lds_pad = 0;          // idle dynamic LDS per workgroup that holds the residency at options.flies_per_cu (0: none)
   bool chunking = true;          // options.sched = 1 keeps whole-launch work items
   // diagnostics: NMF_SCHED = chunks (default) | plain (= NMF_NO_CHUNKS=1); NMF_ORDER = auto (default) | costliest | inorder |
   // none (no order kernel, worlds in index order) | policy (rounds 1-2: in order or costliest first, whichever measured
@@ -324,7 +325,7 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
     if (policy < 0) b->st.sched = b->sched_buf;
   }
   const bool weld = b->dm.weld_active != 0, terrain = b->dm.terrain_type != 0;
-#define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, 0, stream, b->dm_dev, b->st, rp, n_steps)
+#define NMF_LAUNCH(TOPO, WELD) hipLaunchKernelGGL((nmf::nmf_step_kernel<TOPO, WELD>), grid, block, b->lds_pad, stream, b->dm_dev, b->st, rp, n_steps)
 #define NMF_LAUNCH_TOPO(K, TOPO) if (b->topo == K) { if (weld) NMF_LAUNCH(TOPO, true); else if (terrain) NMF_LAUNCH(nmf::Terrain<TOPO>, false); else NMF_LAUNCH(TOPO, false); }
 #if NMF_HAS_TOPO(0)
   NMF_LAUNCH_TOPO(0, nmf::FlyTopo)
@@ -482,6 +483,19 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
   UI(seg_body); UF(seg_pos); UF(seg_quat); UI(site_body); UF(site_pos);
   UI(act_type); UI(act_trn); UI(act_limited); UI(act_geom); UF(act_gain); UF(act_bias); UF(act_forcerange); UF(act_ctrlrange);
   UF(key_qpos); UF(key_ctrl);
+  d.act_general = nullptr;
+  if (const HostArray* ag = model->find("act_general")) {        // optional: models with intvelocity / damper / cylinder / muscle actuators or shared dofs
+    if (ag->is_int || (int)ag->f.size() != model->nu * nmf::kActGen) { rc |= fail("nmf_batch_create: act_general must be float [nu][32]"); }
+    else {
+      UF(act_general);
+      // the affine pass of the stepping kernel writes every actuator's force to its dof with a plain store (one lane per actuator,
+      // one actuator per dof): the general actuators' zero force goes to dof 0 — no affine actuator drives the root — instead of
+      // racing with the affine actuator that may share their dof; the general pass reads the dof from the row's flags
+      std::vector<int> trn = model->find("act_trn")->i;
+      for (int u = 0; u < model->nu; ++u) if ((int)ag->f[(size_t)u * nmf::kActGen] & 1) trn[(size_t)u] = 0;
+      rc |= upload(b, trn, reinterpret_cast<const int**>((void*)&d.act_trn));
+    }
+  }
   UI(geom_body); UI(geom_type); UI(geom_hulladr); UI(geom_hullnum); UI(geom_sensor);
   UF(geom_p0); UF(geom_p1); UF(geom_radius); UF(geom_bsphere); UF(geom_invweight0); UF(hull_vert);
   UF(pair_friction); UF(pair_solref); UF(pair_solimp); UF(pair_margin);
@@ -549,6 +563,7 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
   rc |= alloc_field(b, NMF_COST, 1, &st.cost);
   { float* p = nullptr; rc |= alloc_field(b, NMF_STATS_SUM, 16, &p); st.stats_sum = reinterpret_cast<unsigned int*>(p); }   // uint32 counters
   rc |= alloc_field(b, NMF_CONTACT_GEOM, nmf::kMaxCon, &st.contact_geom);
+  rc |= alloc_field(b, NMF_ACT, model->nu, &st.act);
   {
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(int) * (size_t)n_worlds) == hipSuccess) { b->allocs.push_back(p); b->order_buf = (int*)p; }
@@ -611,6 +626,9 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
     if (const char* e = dev_env("NMF_MAX_CHUNKS")) b->max_chunks = std::max(1, std::min(16, atoi(e)));
     if (const char* e = dev_env("NMF_CHUNK_DIV")) { b->chunk_div = std::max(1.0, atof(e)); b->chunk_div_short = false; }
     if (const char* e = dev_env("NMF_MIN_CHUNK_STEPS")) b->min_chunk_steps = std::max(1, atoi(e));
+    // (activations live in HBM and are advanced in place every step by the lane that owns the actuator: a world's steps must stay
+    // on one workgroup within a launch — whole-launch work items for the models that have general actuators)
+    if (d.act_general) b->chunking = false;
     p = nullptr;
     if (hipMalloc(&p, sizeof(nmf::SchedState)) == hipSuccess) {
       (void)hipMemset(p, 0, sizeof(nmf::SchedState));
@@ -650,6 +668,24 @@ extern "C" nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, 
       int nblk = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, nmf::kWave, 0) == hipSuccess && nblk > 0) per_cu = nblk;
       b->step_fn = fn;
+      // options.flies_per_cu below the kernel's own residency: idle LDS per workgroup so that k workgroups fit a CU and k + 1 do
+      // not — as little of it as that takes (allocation granule 512 B), so the CU keeps LDS for another stream's kernel
+      int want = opt.flies_per_cu;
+      if (const char* e = dev_env("NMF_FLIES_PER_CU")) want = atoi(e);
+      hipFuncAttributes fa;
+      if (want > 0 && want < per_cu && hipFuncGetAttributes(&fa, fn) == hipSuccess) {
+        int lds_cu = 0;
+        if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess || lds_cu <= 0) lds_cu = 160 * 1024;
+        const int granule = 512;
+        int per_wg = (lds_cu / (want + 1) / granule + 1) * granule;            // the smallest allocation of which want + 1 do not fit
+        if (per_wg * want <= lds_cu && per_wg > (int)fa.sharedSizeBytes) {
+          b->lds_pad = (unsigned)(per_wg - (int)fa.sharedSizeBytes);
+          int nblk2 = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk2, fn, nmf::kWave, b->lds_pad) == hipSuccess && nblk2 > 0) per_cu = std::min(per_cu, nblk2);
+          else per_cu = want;
+        }
+      }
+      if (const char* e = dev_env("NMF_LDS_PAD")) b->lds_pad = (unsigned)atoi(e);
       b->per_cu = per_cu;
     }
     b->resident_waves = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * per_cu;

@@ -146,6 +146,9 @@ struct DevModel {
   // warp/simulation.py:50-56): 1..kMaxCon.  Contacts beyond it — in geom order — are dropped and the step is counted as overflowed.
   int max_contacts;
   const NMF_G float *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
+  // [nu][32] or nullptr: MuJoCo's general actuator for the actuators the affine pass does not cover (intvelocity, damper,
+  // cylinder, muscle; later actuators of a shared dof) — flygym_amd/compiler/model.py::_general_row, nmf_step.hip actuation_general
+  const NMF_G float* act_general;
   const NMF_G float *key_qpos, *key_ctrl;
   const NMF_G int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
   const NMF_G float *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
@@ -158,6 +161,7 @@ struct DevState {
   int n_worlds;
   float *qpos, *qvel, *ctrl, *qacc_ws, *seg_xpos, *seg_xquat, *site_xpos, *actuator_force,
       *sensordata, *time, *stats, *qacc;
+  float* act;              // [n_worlds][nu] activation state of the stateful actuators (one slot per actuator, 0 for the stateless)
   unsigned int* stats_sum; // [n_worlds][16] since the last reset: physics steps, sum of contacts, sum of Newton iterations, overflow steps, 12 solve-report counters (include/nmf.h)
   float* contact_geom;     // [n_worlds][kMaxCon] geom index of contact c at the launch's last step (-1 beyond ncon)
   // [n_worlds][kActHistWords] the constraint solver's second warm start: the active pyramid rows (4 bits) of up to four contacts

@@ -2029,6 +2029,102 @@ struct CtrlPrefetch {
 };
 
 // ------------------------------------------------------------------ the step
+// ------------------------------------------------------------------ general actuators (cold: models that have them)
+// MuJoCo's general actuator for the reference's ActuatorType members beyond the stateless affine ones — intvelocity, damper,
+// cylinder, muscle (reference compose/fly.py:65-77, 301-369 forwards the MJCF shortcut; oracle: nmf_oracle.c general_actuator,
+// same formulas) — and for the second and later actuators of a dof that several drive.  The affine pass of physics_forward sees
+// these as motors of gain 0; this pass, one lane per actuator, computes force = gain(length, velocity) * input + bias(length,
+// velocity), input = the control or — stateful types — the activation at the START of the step (mj_fwdActuation, option actearly
+// off), clamps it, adds gear * force to the dof's direct force (an LDS atomic: dofs may be shared) and writes the NEXT activation
+// (mj_advance: act + h act_dot, filterexact's closed form, clamped to actrange) to the world's slot in HBM — nothing else in the step
+// reads it.  Off the hot path: a wave-uniform branch on m.act_general skips it for every model of BASELINE.json.
+constexpr int kActGen = 32;       // floats per actuator in DevModel::act_general (flygym_amd/compiler/model.py::_general_row)
+__device__ __forceinline__ float muscle_peak(const float* prm, float acc0) { return prm[2] < 0.f ? prm[3] / fmaxf(kMinVal, acc0) : prm[2]; }
+__device__ __forceinline__ float muscle_len(float len, float lr0, float lr1, const float* prm, float& L0) {
+  L0 = (lr1 - lr0) / fmaxf(kMinVal, prm[1] - prm[0]);
+  return prm[0] + (len - lr0) / fmaxf(kMinVal, L0);
+}
+template <class TP>
+__device__ __noinline__ void actuation_general(FlyLds<TP>& s, const GModel& m, int lane, float* __restrict__ act_w, float* __restrict__ force_out,
+                                               float* __restrict__ rec_out, int rec_n) {
+  typedef __attribute__((address_space(3))) float* lds_fptr;
+  const float h = m.timestep;
+  for (int u = lane; u < m.nu; u += kWave) {
+    const NMF_G float* g = m.act_general + (size_t)u * kActGen;
+    const int flags = (int)g[0];
+    if (!(flags & 1)) continue;
+    float prm[26];
+#pragma unroll
+    for (int i = 0; i < 26; ++i) prm[i] = g[6 + i];          // dynprm 0..2 | gainprm 3..11 | biasprm 12..20 | actrange 21, 22 | lengthrange 23, 24 | acc0 25
+    const int dyn = (int)g[1], gt = (int)g[2], bt = (int)g[3];
+    const float gear = g[5];
+    float ctrl = s.ctrl[u];
+    if (m.act_limited[2 * u + 1]) ctrl = fminf(fmaxf(ctrl, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
+    const int j = flags >> 8;        // (the uploaded act_trn points these actuators at dof 0: see nmf_batch_create)
+    const float len = gear * s.qpos[j + 1], vel = gear * s.qvel[j];
+    const float act = dyn ? act_w[u] : 0.f;
+    if (dyn) {
+      float act_dot;
+      if (dyn == 1) act_dot = ctrl;
+      else if (dyn == 4) {
+        const float cc = fminf(fmaxf(ctrl, 0.f), 1.f), ac = fminf(fmaxf(act, 0.f), 1.f);
+        const float ta = prm[0] * (0.5f + 1.5f * ac), td = prm[1] / (0.5f + 1.5f * ac), dc = cc - act;
+        float tau;
+        if (prm[2] < kMinVal) tau = dc > 0.f ? ta : td;
+        else {
+          const float x = dc / prm[2] + 0.5f;
+          const float sg = x <= 0.f ? 0.f : (x >= 1.f ? 1.f : x * x * x * (3.f * x * (2.f * x - 5.f) + 10.f));
+          tau = td + (ta - td) * sg;
+        }
+        act_dot = dc / fmaxf(kMinVal, tau);
+      } else act_dot = (ctrl - act) / fmaxf(kMinVal, prm[0]);
+      float nx;
+      if (dyn == 3) { const float tau = fmaxf(kMinVal, prm[0]); nx = act + act_dot * tau * (1.f - expf(-h / tau)); }
+      else nx = act + act_dot * h;
+      if (g[4] != 0.f) nx = fminf(fmaxf(nx, prm[21]), prm[22]);
+      act_w[u] = nx;
+    }
+    const float input = dyn ? act : ctrl;
+    const float* gp = prm + 3;
+    const float* bp = prm + 12;
+    float gain, f;
+    if (gt == 2) {
+      float L0;
+      const float L = muscle_len(len, prm[23], prm[24], gp, L0);
+      const float V = vel / fmaxf(kMinVal, L0 * gp[6]);
+      const float lmin = gp[4], lmax = gp[5], fvmax = gp[8];
+      const float a = 0.5f * (lmin + 1.f), b = 0.5f * (1.f + lmax);
+      float FL = 0.f, FV, x;
+      if (L >= lmin && L <= a) { x = (L - lmin) / fmaxf(kMinVal, a - lmin); FL = 0.5f * x * x; }
+      else if (L > a && L <= 1.f) { x = (1.f - L) / fmaxf(kMinVal, 1.f - a); FL = 1.f - 0.5f * x * x; }
+      else if (L > 1.f && L <= b) { x = (L - 1.f) / fmaxf(kMinVal, b - 1.f); FL = 1.f - 0.5f * x * x; }
+      else if (L > b && L <= lmax) { x = (lmax - L) / fmaxf(kMinVal, lmax - b); FL = 0.5f * x * x; }
+      const float y = fvmax - 1.f;
+      if (V <= -1.f) FV = 0.f;
+      else if (V <= 0.f) FV = (V + 1.f) * (V + 1.f);
+      else if (V <= y) FV = fvmax - (y - V) * (y - V) / fmaxf(kMinVal, y);
+      else FV = fvmax;
+      gain = -muscle_peak(gp, prm[25]) * FL * FV;
+    } else gain = gt == 1 ? gp[0] + gp[1] * len + gp[2] * vel : gp[0];
+    f = gain * input;
+    if (bt == 1) f += bp[0] + bp[1] * len + bp[2] * vel;
+    else if (bt == 2) {
+      float L0;
+      const float L = muscle_len(len, prm[23], prm[24], bp, L0);
+      const float lmax = bp[5], fpmax = bp[7], b = 0.5f * (1.f + lmax);
+      float FP = 0.f;
+      if (L > 1.f && L <= b) { const float x = (L - 1.f) / fmaxf(kMinVal, b - 1.f); FP = fpmax * 0.5f * x * x; }
+      else if (L > b) { const float x = (L - b) / fmaxf(kMinVal, b - 1.f); FP = fpmax * (0.5f + x); }
+      f -= muscle_peak(bp, prm[25]) * FP;
+    }
+    if (flags & 2) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
+    (void)__hip_atomic_fetch_add((lds_fptr)(void*)&s.vA[j], gear * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (force_out) force_out[u] = f;
+    if (rec_out && u < rec_n) rec_out[u] = f;
+  }
+  WSYNC();
+}
+
 template <class TP, bool WELD>
 __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const DevState& st, int w, bool last, float* rec, CtrlPrefetch& pf STAGE_ARG) {
   // hybrid kernels: per-lane addresses are rebuilt every step instead of living across the item loop — hoisted, they left
@@ -2278,6 +2374,9 @@ __device__ bool physics_forward(FlyLds<TP>& s, const GModel& m, int lane, const 
     if (rec && u < st.ring_nact) rec[2 * st.ring_nj + opaque(u)] = f;  // ... and the steps an observation ring records
   }
   WSYNC();
+  if (m.act_general)      // wave-uniform: models with intvelocity / damper / cylinder / muscle actuators, or dofs that several actuators drive
+    actuation_general(s, m, lane, st.act + (size_t)w * m.nu, last ? st.actuator_force + (size_t)w * m.nu : nullptr,
+                      rec ? rec + 2 * st.ring_nj : nullptr, st.ring_nact);
   sweep_project(s, s.W, m, lane, [&](int j, float v) {
     float kj, rj;
     if constexpr (kSpringPre) {
@@ -2866,7 +2965,7 @@ __global__ void __launch_bounds__(kWave) nmf_reset_kernel(const DevModel* __rest
   stage_launch_constants(s, m);
   for (int i = lane; i < s.nq(); i += kWave) s.qpos[i] = m.key_qpos[i];
   for (int i = lane; i < s.nv(); i += kWave) { s.qvel[i] = 0.f; s.qacc[i] = 0.f; }
-  for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; }
+  for (int i = lane; i < m.nu; i += kWave) { s.ctrl[i] = m.key_ctrl[i]; st.actuator_force[(size_t)w * m.nu + i] = 0.f; st.act[(size_t)w * m.nu + i] = 0.f; }
   for (int i = lane; i < 96; i += kWave) st.sensordata[(size_t)w * 96 + i] = 0.f;
   if (lane == 0) { s.ncon = 0; s.iters = 0; s.overflow = 0; s.solve_resid = 0.f; }
   WSYNC();

@@ -43,6 +43,12 @@ class HIPSimulation:
             ``order``, ``max_chunks``, ...).  What a batch runs is reported by :meth:`batch_info`.
     """
 
+    def __new__(cls, world=None, *args, **kwargs):
+        # a world with several flies (reference compose/world.py:95-149): one batch per fly behind the same surface
+        if cls is HIPSimulation and world is not None and len(getattr(world, "fly_lookup", {})) > 1:
+            return object.__new__(MultiFlyHIPSimulation)
+        return object.__new__(cls)
+
     def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
                  max_contacts: int = 500, device: int | None = None, strict_contacts: bool = False,
                  _cpu_flavour: bool = False, _options: dict | None = None) -> None:
@@ -443,6 +449,120 @@ class HIPSimulation:
                                    self._frames_rendered, self.timestep, self.n_worlds, 0)
 
 
+class MultiFlyHIPSimulation(HIPSimulation):
+    """``HIPSimulation(world, n_worlds)`` of a world that holds several flies (reference ``compose/world.py:95-149``;
+    ``GPUSimulation`` / ``Simulation`` address every query and input by ``fly_name``, ``simulation.py:142-243``).
+
+    The reference gives fly geoms ``contype = conaffinity = 0`` and adds fly-ground contact pairs only
+    (``compose/fly.py:609-610``, ``compose/world.py:300-309``): the flies of a world never touch each other, and MuJoCo's
+    constraint problem of such a world is block-diagonal — one block per fly, the blocks' optima independent (what they share in
+    MuJoCo is the stopping test of one joint Newton loop: tolerance-level).  So each fly is stepped as its own batch of
+    ``n_worlds`` worlds — ``sims[fly_name]``, an ordinary :class:`HIPSimulation` of ``world.single_fly_view(fly_name)`` — and this
+    class routes the per-fly calls, and fans ``step`` / ``reset`` / ``warmup`` out to all of them (launches of different flies are
+    independent kernels on the caller's stream).  Engine-level accessors that belong to one batch (``field``, ``step_replay``,
+    ``pack_observations``, ...) are reached through :meth:`for_fly`."""
+
+    def __init__(self, world: BaseWorld, n_worlds: int, max_constraints: int = 500,
+                 max_contacts: int = 500, device: int | None = None, strict_contacts: bool = False,
+                 _cpu_flavour: bool = False, _options: dict | None = None) -> None:
+        if not _cpu_flavour:
+            self._strip_unsupported_options(world)          # once, on the world itself: the views inherit it
+        self.world = world
+        self.n_worlds = int(n_worlds)
+        self.max_constraints, self.max_contacts = max_constraints, max_contacts
+        self.renderer = None
+        self.sims = {name: HIPSimulation(world.single_fly_view(name), n_worlds, max_constraints, max_contacts, device, strict_contacts,
+                                         _cpu_flavour, _options) for name in world.fly_lookup}
+        first = next(iter(self.sims.values()))
+        self.device, self.device_index, self._torch = first.device, first.device_index, first._torch
+        self._frames_rendered = 0
+        self._total_render_time_ns = 0
+
+    def __del__(self):
+        pass
+
+    def for_fly(self, fly_name: str) -> HIPSimulation:
+        """The batch that steps ``fly_name`` (its ``field`` views, ``step_replay``, ``batch_info``, ...)."""
+        return self.sims[fly_name]
+
+    def _each(self):
+        return self.sims.values()
+
+    # ---- fanned out --------------------------------------------------------------------
+    def reset(self) -> None:
+        for s in self._each(): s.reset()
+
+    def reset_worlds(self, mask) -> None:
+        for s in self._each(): s.reset_worlds(mask)
+
+    def step(self, n_steps: int = 1, record_every: int | None = None, n_act: int = 42):
+        out = {name: s.step(n_steps, record_every, n_act) for name, s in self.sims.items()}
+        return None if record_every is None else out
+
+    def step_with_profile(self) -> None:
+        for s in self._each(): s.step_with_profile()
+
+    def warmup(self, duration_s: float = 0.05) -> None:
+        for s in self._each(): s.warmup(duration_s)
+
+    @property
+    def _curr_step(self): return next(iter(self._each()))._curr_step
+
+    @property
+    def _total_physics_time_ns(self): return sum(s._total_physics_time_ns for s in self._each())
+
+    @property
+    def time(self) -> float: return next(iter(self._each())).time
+
+    @property
+    def timestep(self) -> float: return next(iter(self._each())).timestep
+
+    def overflow_steps(self) -> int: return sum(s.overflow_steps() for s in self._each())
+
+    def get_solver_stats(self): return {name: s.get_solver_stats() for name, s in self.sims.items()}
+
+    def get_solver_exits(self) -> dict: return {name: s.get_solver_exits() for name, s in self.sims.items()}
+
+    def batch_info(self) -> dict: return {name: s.batch_info() for name, s in self.sims.items()}
+
+    def print_performance_report(self) -> None:
+        from .utils.profiling import print_perf_report_parallel
+
+        print_perf_report_parallel(self._total_physics_time_ns, self._total_render_time_ns, self._curr_step,
+                                   self._frames_rendered, self.timestep, self.n_worlds, 0)
+
+    # ---- routed by fly name ------------------------------------------------------------
+    def get_joint_angles(self, fly_name: str): return self.sims[fly_name].get_joint_angles(fly_name)
+    def get_joint_velocities(self, fly_name: str): return self.sims[fly_name].get_joint_velocities(fly_name)
+    def get_body_positions(self, fly_name: str): return self.sims[fly_name].get_body_positions(fly_name)
+    def get_body_rotations(self, fly_name: str): return self.sims[fly_name].get_body_rotations(fly_name)
+    def get_site_positions(self, fly_name: str): return self.sims[fly_name].get_site_positions(fly_name)
+    def get_actuator_forces(self, fly_name: str, actuator_type): return self.sims[fly_name].get_actuator_forces(fly_name, actuator_type)
+    def get_ground_contact_info(self, fly_name: str): return self.sims[fly_name].get_ground_contact_info(fly_name)
+    def set_actuator_inputs(self, fly_name: str, actuator_type, inputs) -> None: self.sims[fly_name].set_actuator_inputs(fly_name, actuator_type, inputs)
+    def set_leg_adhesion_states(self, fly_name: str, leg_to_adhesion_state) -> None: self.sims[fly_name].set_leg_adhesion_states(fly_name, leg_to_adhesion_state)
+    def replay_ids(self, fly_name: str, with_adhesion: bool = False): return self.sims[fly_name].replay_ids(fly_name, with_adhesion)
+
+    # ---- one batch's business ------------------------------------------------------------
+    def _one_batch_only(self, what):
+        raise AttributeError(f"{what} belongs to one fly's batch: use sim.for_fly(fly_name).{what} ({', '.join(self.sims)})")
+
+    def field(self, name: str): self._one_batch_only("field")
+    def step_replay(self, *a, **k): self._one_batch_only("step_replay")
+    def record_into(self, *a, **k): self._one_batch_only("record_into")
+    def pack_observations(self, *a, **k): self._one_batch_only("pack_observations")
+    def shader_clock_hz(self, *a, **k): self._one_batch_only("shader_clock_hz")
+
+    @property
+    def model(self): self._one_batch_only("model")
+
+    @property
+    def mj_model(self): self._one_batch_only("mj_model")
+
+    @property
+    def mj_data(self): self._one_batch_only("mj_data")
+
+
 def _tensor_from_ptr(torch, ptr: int, shape, device):
     """Wrap a raw device pointer as a torch tensor without copying."""
     n = int(np.prod(shape))
@@ -495,7 +615,8 @@ class Simulation:
         self.batch = HIPSimulation(world, 1, device=device, _cpu_flavour=True)
         self.world = world
         self.renderer = None
-        self.mj_model, self.mj_data = self.batch.mj_model, self.batch.mj_data
+        # (a world with several flies has one compiled model per fly: batch.for_fly(name).mj_model)
+        self.mj_model, self.mj_data = getattr(self.batch, "mj_model", None), getattr(self.batch, "mj_data", None)
 
     # profiling counters of the reference class (simulation.py:52-56), kept by the batch object
     @property

@@ -56,7 +56,9 @@ enum nmf_field {
   NMF_CONTACT_GEOM = 14, /* [48]     contact list of the launch's last step: index (into the world's contact-geom list,
                                     reference compose/world.py:300-309 pair order sorted by body) of the geom of contact
                                     c, as a float; -1 beyond ncon                                                    */
-  NMF_FIELD_COUNT = 15
+  NMF_ACT = 15,         /* [nu]      activation state of the stateful actuators (intvelocity, cylinder, muscle: MuJoCo's act, here one
+                                    slot per actuator — 0 for the stateless ones); reset to 0; writable between launches       */
+  NMF_FIELD_COUNT = 16
 };
 
 /* Text of the last error raised on the calling thread ("" if none). */
@@ -107,6 +109,10 @@ typedef struct nmf_batch_options {
   int32_t order_every;      /* costliest-first order recomputed every n-th launch                                              */
   int32_t rest_slow;        /* 1: hybrid kernels use the table-driven level passes of the rest of the body                     */
   float chunk_div;          /* each chunk takes 1 / chunk_div of the steps that are left (> 1)                                 */
+  int32_t flies_per_cu;     /* > 0: at most this many of the stepping kernel's single-wave workgroups per CU (the kernel's own
+                               residency is the ceiling): the launch carries that much idle LDS per workgroup, which leaves LDS and
+                               vector registers of every CU to a kernel of ANOTHER stream — the eye renderer of the previous vision
+                               tick beside the next tick's physics (co-residency)                          */
 } nmf_batch_options;
 nmf_batch* nmf_batch_create_ex(const nmf_model* model, int n_worlds, int device, const nmf_batch_options* options);
 

@@ -46,6 +46,7 @@ typedef double real;
 #define R_SIN sin
 #define R_COS cos
 #define R_POW pow
+#define R_EXP exp
 #define R_EPS 2.220446049250313e-16
 #else
 typedef float real;
@@ -54,6 +55,7 @@ typedef float real;
 #define R_FABS fabsf
 #define R_SIN sinf
 #define R_COS cosf
+#define R_EXP expf
 #define R_POW powf
 #define R_EPS 1.1920929e-07f
 #endif
@@ -131,6 +133,12 @@ typedef struct {
   int* site_body; real* site_pos;
   int *act_type, *act_trn, *act_limited, *act_geom;
   real *act_gain, *act_bias, *act_forcerange, *act_ctrlrange;
+  /* optional blob entry act_general [nu][NMF_ACTGEN]: MuJoCo's general actuator for the types beyond the affine stateless ones
+   * (intvelocity, damper, cylinder, muscle; reference compose/fly.py:65-77, 301-369) — NULL when the model has none.  Row layout
+   * (flygym_amd/compiler/model.py::_general_row): 0 flags (1 on | 2 forcelimited | dof << 8; the legacy act_limited[u][0] is 0 for these), 1 dyntype (0 none, 1 integrator, 2 filter, 3 filterexact, 4 muscle),
+   * 2 gaintype (0 fixed, 1 affine, 2 muscle), 3 biastype (0 none, 1 affine, 2 muscle), 4 actlimited, 5 gear, 6..8 dynprm,
+   * 9..17 gainprm, 18..26 biasprm, 27..28 actrange, 29..30 lengthrange, 31 acc0 */
+  real *act_general;
   real *key_qpos, *key_ctrl;
   int *geom_body, *geom_type, *geom_hulladr, *geom_hullnum, *geom_sensor;
   real *geom_p0, *geom_p1, *geom_radius, *geom_bsphere, *geom_invweight0, *hull_vert;
@@ -144,6 +152,7 @@ typedef struct {
 typedef struct {
   /* state */
   real *qpos, *qvel, *ctrl, *qacc_warmstart;
+  real *act, *act_next;                /* nu: activation state of the stateful actuators (one slot per actuator; 0 for the stateless) */
   real time;
   /* position-dependent */
   real *xpos, *xquat, *xmat;          /* dynamic bodies */
@@ -223,6 +232,7 @@ EXPORT void* SFX(nmfo_model_create)(const uint8_t* blob, int64_t nbytes) {
   m->act_bias = blob_real(blob, "act_bias", NULL);
   m->act_forcerange = blob_real(blob, "act_forcerange", NULL);
   m->act_ctrlrange = blob_real(blob, "act_ctrlrange", NULL);
+  m->act_general = blob_find(blob, "act_general") ? blob_real(blob, "act_general", NULL) : NULL;
   m->key_qpos = blob_real(blob, "key_qpos", NULL);
   m->key_ctrl = blob_real(blob, "key_ctrl", NULL);
   m->geom_body = blob_int(blob, "geom_body", &c); m->ng = (int)c;
@@ -274,6 +284,7 @@ EXPORT void* SFX(nmfo_data_create)(const void* mv) {
   d->max_contacts = NMF_MAXCON;
   int nv = m->nv, nb = m->nb;
   d->qpos = ALLOC(m->nq); d->qvel = ALLOC(nv); d->ctrl = ALLOC(m->nu); d->qacc_warmstart = ALLOC(nv);
+  d->act = ALLOC(m->nu); d->act_next = ALLOC(m->nu);
   d->xpos = ALLOC(nb * 3); d->xquat = ALLOC(nb * 4); d->xmat = ALLOC(nb * 9);
   d->S = ALLOC(nv * 6); d->daxis = ALLOC(nv * 3); d->danchor = ALLOC(nv * 3);
   d->Ib = ALLOC(nb * 10); d->Ic = ALLOC(nb * 10);
@@ -848,6 +859,84 @@ static void velocity_and_bias(const omodel* m, odata* d) {
 }
 
 /* ------------------------------------------------------------------ stage: actuation */
+#define NMF_ACTGEN 32
+static inline real rmax(real a, real b) { return a > b ? a : b; }
+static inline real rclip(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* MuJoCo's muscle model as its documentation states it (computation/index.html#muscle-actuators, engine_util_misc.c
+ * mju_muscleGain / mju_muscleBias / mju_muscleDynamics; mujoco 3.6.0, absent from this image: restated, not linked).
+ * prm: range0 range1 force scale lmin lmax vmax fpmax fvmax */
+static real muscle_length(real len, const real* lr, const real* prm, real* L0out) {
+  real L0 = (lr[1] - lr[0]) / rmax((real)NMF_MINVAL, prm[1] - prm[0]);
+  if (L0out) *L0out = L0;
+  return prm[0] + (len - lr[0]) / rmax((real)NMF_MINVAL, L0);
+}
+static real muscle_peak(const real* prm, real acc0) { return prm[2] < 0 ? prm[3] / rmax((real)NMF_MINVAL, acc0) : prm[2]; }
+static real muscle_gain(real len, real vel, const real* lr, real acc0, const real* prm) {
+  real lmin = prm[4], lmax = prm[5], vmax = prm[6], fvmax = prm[8], L0;
+  real L = muscle_length(len, lr, prm, &L0);
+  real V = vel / rmax((real)NMF_MINVAL, L0 * vmax);
+  real a = (real)0.5 * (lmin + 1), b = (real)0.5 * (1 + lmax), FL = 0, FV, x;
+  if (L >= lmin && L <= a) { x = (L - lmin) / rmax((real)NMF_MINVAL, a - lmin); FL = (real)0.5 * x * x; }
+  else if (L > a && L <= 1) { x = (1 - L) / rmax((real)NMF_MINVAL, 1 - a); FL = 1 - (real)0.5 * x * x; }
+  else if (L > 1 && L <= b) { x = (L - 1) / rmax((real)NMF_MINVAL, b - 1); FL = 1 - (real)0.5 * x * x; }
+  else if (L > b && L <= lmax) { x = (lmax - L) / rmax((real)NMF_MINVAL, lmax - b); FL = (real)0.5 * x * x; }
+  real y = fvmax - 1;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V + 1) * (V + 1);
+  else if (V <= y) FV = fvmax - (y - V) * (y - V) / rmax((real)NMF_MINVAL, y);
+  else FV = fvmax;
+  return -muscle_peak(prm, acc0) * FL * FV;
+}
+static real muscle_bias(real len, const real* lr, real acc0, const real* prm) {
+  real lmax = prm[5], fpmax = prm[7];
+  real L = muscle_length(len, lr, prm, NULL);
+  real b = (real)0.5 * (1 + lmax), FP, x;
+  if (L <= 1) FP = 0;
+  else if (L <= b) { x = (L - 1) / rmax((real)NMF_MINVAL, b - 1); FP = fpmax * (real)0.5 * x * x; }
+  else { x = (L - b) / rmax((real)NMF_MINVAL, b - 1); FP = fpmax * ((real)0.5 + x); }
+  return -muscle_peak(prm, acc0) * FP;
+}
+static real muscle_dynamics(real ctrl, real act, const real* prm) {      /* prm: tau_act tau_deact tausmooth */
+  real cc = rclip(ctrl, 0, 1), ac = rclip(act, 0, 1);
+  real tau_act = prm[0] * ((real)0.5 + (real)1.5 * ac), tau_deact = prm[1] / ((real)0.5 + (real)1.5 * ac);
+  real dctrl = cc - act, tau;
+  if (prm[2] < (real)NMF_MINVAL) tau = dctrl > 0 ? tau_act : tau_deact;
+  else {          /* quintic sigmoid over the smoothing width */
+    real x = dctrl / prm[2] + (real)0.5, sg = x <= 0 ? 0 : (x >= 1 ? 1 : x * x * x * (3 * x * (2 * x - 5) + 10));
+    tau = tau_deact + (tau_act - tau_deact) * sg;
+  }
+  return dctrl / rmax((real)NMF_MINVAL, tau);
+}
+/* one general actuator on hinge dof j (mj_fwdActuation: activation derivative, then force = gain * input + bias, clamped;
+ * mj_advance / mj_nextActivation: the next activation, clamped to actrange) — the force uses the activation at the START of
+ * the step (option actearly off, MuJoCo's default) */
+static real general_actuator(const omodel* m, odata* d, int u, real ctrl) {
+  const real* g = m->act_general + (size_t)u * NMF_ACTGEN;
+  int j = m->act_trn[u], dyn = (int)g[1], gt = (int)g[2], bt = (int)g[3];
+  real gear = g[5], len = gear * d->qpos[j + 1], vel = gear * d->qvel[j], act = d->act[u], h = m->timestep;
+  const real *dynprm = g + 6, *gainprm = g + 9, *biasprm = g + 18, *lr = g + 29; real acc0 = g[31];
+  real act_dot = 0;
+  if (dyn == 1) act_dot = ctrl;
+  else if (dyn == 2 || dyn == 3) act_dot = (ctrl - act) / rmax((real)NMF_MINVAL, dynprm[0]);
+  else if (dyn == 4) act_dot = muscle_dynamics(ctrl, act, dynprm);
+  if (dyn) {
+    real nx;
+    if (dyn == 3) { real tau = rmax((real)NMF_MINVAL, dynprm[0]); nx = act + act_dot * tau * (1 - R_EXP(-h / tau)); }
+    else nx = act + act_dot * h;
+    if (g[4] != 0) nx = rclip(nx, g[27], g[28]);
+    d->act_next[u] = nx;
+  }
+  real input = dyn ? act : ctrl;
+  real gain = gt == 0 ? gainprm[0] : gt == 1 ? gainprm[0] + gainprm[1] * len + gainprm[2] * vel : muscle_gain(len, vel, lr, acc0, gainprm);
+  real f = gain * input;
+  if (bt == 1) f += biasprm[0] + biasprm[1] * len + biasprm[2] * vel;
+  else if (bt == 2) f += muscle_bias(len, lr, acc0, biasprm);
+  if ((int)g[0] & 2) f = rclip(f, m->act_forcerange[2 * u], m->act_forcerange[2 * u + 1]);
+  d->actuator_force[u] = f;
+  d->qfrc_actuator[j] += gear * f;
+  return f;
+}
+
 static void actuation(const omodel* m, odata* d) {
   int nv = m->nv;
   memset(d->qfrc_actuator, 0, sizeof(real) * (size_t)nv);
@@ -858,6 +947,8 @@ static void actuation(const omodel* m, odata* d) {
       if (ctrl > m->act_ctrlrange[2 * u + 1]) ctrl = m->act_ctrlrange[2 * u + 1];
     }
     real f;
+    d->act_next[u] = d->act[u];
+    if (m->act_general && m->act_general[(size_t)u * NMF_ACTGEN] != 0) { general_actuator(m, d, u, ctrl); continue; }
     if (m->act_type[u] == ACT_ADHESION) {
       f = m->act_gain[u] * ctrl;
       d->actuator_force[u] = f;
@@ -1144,6 +1235,7 @@ static void integrate(const omodel* m, odata* d) {
   }
   quat_norm(d->qpos + 3);
   for (int j = 6; j < nv; j++) d->qpos[j + 1] += h * d->qvel[j];
+  memcpy(d->act, d->act_next, sizeof(real) * (size_t)m->nu);      /* mj_advance: activations */
   d->time += h;
 }
 
@@ -1170,6 +1262,7 @@ EXPORT void SFX(nmfo_reset)(const void* mv, void* dv) {
   memset(d->qvel, 0, sizeof(real) * (size_t)m->nv);
   memset(d->qacc_warmstart, 0, sizeof(real) * (size_t)m->nv);
   memcpy(d->ctrl, m->key_ctrl, sizeof(real) * (size_t)m->nu);
+  memset(d->act, 0, sizeof(real) * (size_t)m->nu); memset(d->act_next, 0, sizeof(real) * (size_t)m->nu);
   memset(d->actuator_force, 0, sizeof(real) * (size_t)m->nu);
   memset(d->sensordata, 0, sizeof(real) * 96);
   d->time = 0; d->ncon = 0; d->nefc = 0; d->overflow = 0; d->solver_iter = 0;
@@ -1181,7 +1274,7 @@ EXPORT void SFX(nmfo_reset)(const void* mv, void* dv) {
 EXPORT void* SFX(nmfo_ptr)(const void* mv, void* dv, const char* name, int* count) {
   const omodel* m = (const omodel*)mv; odata* d = (odata*)dv; int nv = m->nv;
 #define F(n, p, c) if (strcmp(name, n) == 0) { *count = (c); return (void*)(p); }
-  F("qpos", d->qpos, m->nq) F("qvel", d->qvel, nv) F("ctrl", d->ctrl, m->nu)
+  F("qpos", d->qpos, m->nq) F("qvel", d->qvel, nv) F("ctrl", d->ctrl, m->nu) F("act", d->act, m->nu)
   F("qacc_warmstart", d->qacc_warmstart, nv) F("qacc", d->qacc, nv) F("qacc_smooth", d->qacc_smooth, nv)
   F("xpos", d->xpos, 3 * m->nb) F("xquat", d->xquat, 4 * m->nb) F("xmat", d->xmat, 9 * m->nb)
   F("M", d->M, nv * nv) F("qfrc_bias", d->qfrc_bias, nv) F("qfrc_passive", d->qfrc_passive, nv)

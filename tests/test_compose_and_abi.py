@@ -87,7 +87,9 @@ def test_compose_errors_and_variants():
 
 def test_actuator_types(oracle_lib):
     """Reference ``ActuatorType`` (compose/fly.py:65-77): the stateless affine servos are compiled — position (gain kp, bias
-    (-kp, -kv)), velocity (gain kv, bias (0, -kv)), motor — next to adhesion; the stateful ones and damper are refused loudly.
+    (-kp, -kv)), velocity (gain kv, bias (0, -kv)), motor — next to adhesion; several types may drive one joint
+    (compose/fly.py:310-312): the first actuator of a dof runs in the affine pass, later ones are rows of ``act_general`` with the
+    same law (round 6; the stateful types and damper: tests/test_oracle_actuator_types.py).
     A velocity-actuated leg joint in the oracle reports kv (ctrl - qd), clamped to the force range."""
     from flygym_amd.compose import ActuatorType
 
@@ -98,9 +100,6 @@ def test_actuator_types(oracle_lib):
     fly.add_actuators(dofs, ActuatorType.POSITION, kp=50.0, kv=0.5, neutral_input=KinematicPosePreset.NEUTRAL)
     fly.add_actuators(dofs[:3], "velocity", kv=2.0, forcerange=(-4.0, 4.0))
     fly.add_actuators(dofs[3:5], ActuatorType.MOTOR)
-    for ty in (ActuatorType.INTVELOCITY, ActuatorType.DAMPER, ActuatorType.CYLINDER, ActuatorType.MUSCLE):
-        with pytest.raises(NotImplementedError):
-            fly.add_actuators(dofs[:1], ty)
     world = FlatGroundWorld()
     world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
     m = world.compile_model()
@@ -108,10 +107,19 @@ def test_actuator_types(oracle_lib):
     assert m.nu == n + 5
     np.testing.assert_array_equal(m["act_gain"][:n], 50.0)
     np.testing.assert_array_equal(m["act_bias"][:n], np.tile([-50.0, -0.5], (n, 1)))
-    np.testing.assert_array_equal(m["act_gain"][n:n + 3], 2.0)
-    np.testing.assert_array_equal(m["act_bias"][n:n + 3], np.tile([0.0, -2.0], (3, 1)))
-    np.testing.assert_array_equal(m["act_gain"][n + 3:], 1.0)
-    np.testing.assert_array_equal(m["act_bias"][n + 3:], 0.0)
+    # the velocity and motor actuators sit on dofs the position actuators already drive: gain 0 in the affine pass, their law in
+    # act_general (flags, no dynamics, fixed gain, affine bias)
+    np.testing.assert_array_equal(m["act_gain"][n:], 0.0)
+    np.testing.assert_array_equal(m["act_bias"][n:], 0.0)
+    np.testing.assert_array_equal(m["act_limited"][n:, 0], 0)
+    g = m["act_general"]
+    assert g.shape == (m.nu, 32) and not g[:n].any()
+    np.testing.assert_array_equal(g[n:n + 3, 0], 3.0 + 256.0 * m["act_trn"][n:n + 3])          # on | forcelimited | dof << 8
+    np.testing.assert_array_equal(g[n:n + 3, 1:4], np.tile([0.0, 0.0, 1.0], (3, 1)))
+    np.testing.assert_array_equal(g[n:n + 3, 9], 2.0)
+    np.testing.assert_array_equal(g[n:n + 3, 18:21], np.tile([0.0, 0.0, -2.0], (3, 1)))
+    np.testing.assert_array_equal(g[n + 3:, 9], 1.0)
+    np.testing.assert_array_equal(g[n + 3:, 18:21], 0.0)
     assert [d.name for d in fly.get_actuated_jointdofs_order(ActuatorType.VELOCITY)] == [d.name for d in dofs[:3]]
     o = oracle_lib.Oracle(m.to_blob(), "f64")
     o.ctrl[n:n + 3] = [1.0, -0.5, 10.0]
@@ -272,3 +280,35 @@ def test_replay_device_path_falls_back_for_clips_the_kernel_cannot_hold():
     want = ms.get_joint_angles(1e-3, order).astype(np.float32)
     assert tuple(got.shape) == want.shape and got.dtype == torch.float32
     np.testing.assert_array_equal(got.numpy(), want)
+
+
+def test_a_world_takes_several_flies():
+    """Reference ``BaseWorld.add_fly`` (compose/world.py:95-149): several flies per world, unique names; each fly keeps its own
+    spawn pose, contact set and sensors, and compiles to its own model (the reference's flies never collide with each other:
+    compose/fly.py:609-610, compose/world.py:300-309)."""
+    def mk(name, preset):
+        f = Fly(name=name)
+        f.add_joints(A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=preset), neutral_pose=KinematicPosePreset.NEUTRAL)
+        f.add_actuators(f.skeleton.get_actuated_dofs_from_preset("legs_active_only"), "position", kp=50.0)
+        return f
+
+    w = FlatGroundWorld()
+    w.add_fly(mk("a", A.JointPreset.LEGS_ONLY), (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    w.add_fly(mk("b", A.JointPreset.LEGS_ACTIVE_ONLY), (5, 0, 1.0), Rotation3D("quat", (1, 0, 0, 0)), add_ground_contact_sensors=False,
+              ground_contact_params=ContactParams(sliding_friction=2.0))
+    with pytest.raises(ValueError, match="already exists"):
+        w.add_fly(mk("a", A.JointPreset.LEGS_ONLY), (0, 0, 1), Rotation3D("quat", (1, 0, 0, 0)))
+    assert list(w.fly_lookup) == ["a", "b"] and set(w.world_dof_neutral_states) == {"a/", "b/"}
+    with pytest.raises(ValueError, match="holds 2 flies"):
+        w.compile_model()
+    ma, mb = w.compile_model("a"), w.compile_model("b")
+    assert (ma.nv, mb.nv) == (72, 48)
+    np.testing.assert_allclose(ma["key_qpos"][:3], [0, 0, 0.8]); np.testing.assert_allclose(mb["key_qpos"][:3], [5, 0, 1.0])
+    assert int(ma["n_sensor"][0]) == 6 and int(mb["n_sensor"][0]) == 0
+    assert ma["pair_friction"][0][0] == 1.0 and mb["pair_friction"][0][0] == 2.0
+    # the view of one fly is the single-fly world: the same model as a world built with that fly alone
+    alone = FlatGroundWorld()
+    alone.add_fly(mk("a", A.JointPreset.LEGS_ONLY), (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    assert alone.compile_model().digest() == ma.digest()
+    with pytest.raises(KeyError):
+        w.compile_model("c")

@@ -288,3 +288,207 @@ def test_a_vision_tick_is_one_captured_graph(torch_mod):
     p2 = type(r._params).from_buffer(bad); p2.height = r._params.height // 2
     assert _native.lib().nmf_eye_render_planned(eager._batch_h, ctypes.byref(p2), r._plan_h, None, None, None, None, out2.data_ptr(), None) != 0
     assert b"plan" in _native.lib().nmf_last_error()
+
+
+def test_general_actuator_recurrences_on_the_kernel(torch_mod):
+    """tests/test_oracle_actuator_types.py on the HIP kernel: a hinge driven by a damper, an integrated-velocity servo, a pneumatic
+    cylinder and two muscles follows the closed-form recurrence of MuJoCo's documented general actuator step for step — force,
+    activation state (``NMF_ACT``) and joint angle (general-tree kernel; reference ``compose/fly.py:65-77``: the four
+    ``ActuatorType`` members the engine refused until round 6)."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    from tiny_models import TinyWorld, hinge_on_heavy_base
+    import test_oracle_actuator_types as at
+
+    for case, c in at.CASES.items():
+        par = dict(inertia_yy=2e-6, mass=1e-3, com=(0.5, 0.0, 0.0), armature=1e-6, damping=0.0, stiffness=0.0, springref=0.0, q0=0.0)
+        par.update(c["par"])
+        model = hinge_on_heavy_base(**par, forcerange=c.get("forcerange"), general=dict(kind=c["kind"], **c["attrs"]), ctrlrange=c.get("ctrlrange"))
+        sim = HIPSimulation(TinyWorld(model), n_worlds=2, device=0)
+        inertia = par["inertia_yy"] + par["mass"] * 0.25
+        acc0 = 1.0 / (inertia + par["armature"])
+        gear = c["attrs"].get("gear", 1.0)
+        n = 500
+        q, v, act = par["q0"], 0.0, 0.0
+        want = np.zeros((n, 3))
+        for k in range(n):
+            ctrl = float(c["ctrl"](k))
+            cc = min(max(ctrl, c["ctrlrange"][0]), c["ctrlrange"][1]) if c.get("ctrlrange") else ctrl
+            f, act = at.general_force(c["kind"], c["attrs"], q, v, cc, act, acc0)
+            if c.get("forcerange"):
+                f = min(max(f, c["forcerange"][0]), c["forcerange"][1])
+            tot = gear * f - par["stiffness"] * (q - par["springref"]) - par["damping"] * v
+            v = v + at.H * tot / (inertia + par["armature"] + at.H * par["damping"])
+            q = q + at.H * v
+            want[k] = (q, f, act)
+        ctrl = torch.as_tensor(np.array([c["ctrl"](k) for k in range(n)], dtype=np.float32), device=sim.device)
+        got = torch.zeros((n, 3), device=sim.device)
+        for k in range(n):
+            sim.field("ctrl")[:, 0] = ctrl[k]
+            sim.step(1)
+            got[k, 0], got[k, 1], got[k, 2] = sim.field("qpos")[0, 7], sim.field("actuator_force")[0, 0], sim.field("act")[0, 0]
+        got = got.cpu().numpy().astype(np.float64)
+        for col, name in enumerate(("joint angle", "force", "activation")):
+            scale = max(np.abs(want[:, col]).max(), 1e-9)
+            assert np.abs(got[:, col] - want[:, col]).max() < 2e-3 * scale, (case, name, np.abs(got[:, col] - want[:, col]).max() / scale)
+        # several steps in one launch advance the activation like single steps do; reset clears it
+        a1 = sim.field("act").clone()
+        sim.reset()
+        assert float(sim.field("act").abs().max()) == 0.0
+        sim.field("ctrl")[:, 0] = ctrl[0]
+        sim.step(25)
+        sim2 = HIPSimulation(TinyWorld(model), n_worlds=2, device=0)
+        sim2.field("ctrl")[:, 0] = ctrl[0]
+        for _ in range(25):
+            sim2.step(1)
+        assert torch.equal(sim.field("act"), sim2.field("act")) and torch.equal(sim.field("qpos"), sim2.field("qpos")), case
+        del a1
+
+
+@pytest.mark.parametrize("kind", ["damper", "intvelocity", "cylinder", "muscle", "position + velocity + motor on the same joints"])
+def test_flies_with_general_actuators_step_like_the_oracle(torch_mod, oracle_lib, kind):
+    """1024 flies whose 42 leg actuators are of each of the reference's remaining types (or — last case — three actuators of the
+    affine types on the same joints, which the kernel's affine pass alone would lose: one lane per actuator, plain stores), driven
+    with per-world controls from the spawn pose into ground contact in 20-step launches: the activation state, the actuator forces
+    and the next step's accelerations equal the f64 oracle's started from the kernel's own state, at several times and worlds."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation
+    import test_oracle_actuator_types as at
+
+    if kind in at.KW:
+        fly, world, model = at.fly_with(kind, **at.KW[kind])
+        ids = [i for i, a in enumerate(fly.actuators) if a["kind"] == kind]
+    else:
+        from flygym_amd.anatomy import ActuatedDOFPreset, AxisOrder, JointPreset, Skeleton
+        from flygym_amd.compose import FlatGroundWorld, Fly, KinematicPosePreset
+        from flygym_amd.utils.math import Rotation3D
+
+        fly = Fly(name="nmf")
+        fly.add_joints(Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.LEGS_ONLY), neutral_pose=KinematicPosePreset.NEUTRAL)
+        dofs = fly.skeleton.get_actuated_dofs_from_preset(ActuatedDOFPreset.LEGS_ACTIVE_ONLY)
+        fly.add_actuators(dofs, "position", kp=30.0, neutral_input=KinematicPosePreset.NEUTRAL)
+        fly.add_actuators(dofs[::2], "velocity", kv=2e-3, forcerange=(-0.5, 0.5))
+        fly.add_actuators(dofs[::3], "motor", gear=0.5)
+        fly.add_leg_adhesion()
+        world = FlatGroundWorld()
+        world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+        model = world.compile_model()
+        ids = [i for i, a in enumerate(fly.actuators) if a["kind"] != "adhesion"]
+        assert model["act_general"][:, 0].astype(bool).sum() == len(dofs[::2]) + len(dofs[::3])
+    n = 1024
+    sim = HIPSimulation(world, n_worlds=n, device=0)
+    assert sim.batch_info()["chunked"] == 0            # activations advance in place: whole-launch work items
+    nu = sim.model.nu
+    g = torch.Generator(device=sim.device); g.manual_seed(11)
+    sim.field("qvel")[:, 6:] = (torch.rand((n, sim.model.nv - 6), device=sim.device, generator=g) - 0.5) * 60.0
+    phase = torch.rand((n, len(ids)), device=sim.device, generator=g) * 6.2832
+    idt = torch.as_tensor(ids, device=sim.device)
+    blob = sim.model.to_blob()
+    compared, worst_f, worst_a, worst_q = 0, 0.0, 0.0, 0.0
+    for tick in range(12):
+        amp = 3.0 if kind in ("intvelocity",) else 1.5
+        off = 1.0 if kind in ("damper", "muscle") else 0.0
+        c = amp * torch.sin(phase + 0.9 * tick) + off
+        ctrl = sim.field("ctrl"); ctrl[:, idt] = c
+        sim.step(19)
+        torch.cuda.synchronize()
+        state = {k: sim.field(k).cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "ctrl", "qacc_warmstart", "act")}
+        sim.step(1)
+        torch.cuda.synchronize()
+        qacc, frc, act = sim.field("qacc").cpu().numpy(), sim.field("actuator_force").cpu().numpy(), sim.field("act").cpu().numpy()
+        stats, geom = sim.field("stats").cpu().numpy(), sim.field("contact_geom").cpu().numpy()
+        for w in (0, 17 + 83 * tick, n - 1):
+            o = oracle_lib.Oracle(blob, "f64")
+            o.qpos[:] = state["qpos"][w]; o.qvel[:] = state["qvel"][w]; o.ctrl[:] = state["ctrl"][w]
+            o.arr("qacc_warmstart")[:] = state["qacc_warmstart"][w]; o.arr("act")[:] = state["act"][w]
+            o.step(1)
+            ref_f, ref_a = o.arr("actuator_force"), o.arr("act")
+            fs = max(np.abs(ref_f).max(), 1e-6)
+            worst_f = max(worst_f, np.abs(frc[w] - ref_f).max() / fs)
+            worst_a = max(worst_a, np.abs(act[w] - ref_a).max() / max(np.abs(ref_a).max(), 1e-6))
+            nc = int(stats[w, 0])
+            if nc == o.ints()["ncon"] and geom[w, :nc].astype(int).tolist() == o.ints()["con_geom"]:
+                compared += 1
+                worst_q = max(worst_q, np.abs(qacc[w] - o.arr("qacc")).max() / max(np.abs(o.arr("qacc")).max(), 1e4))
+    report("general_actuators_1024", kind=kind, compared=compared, worst_force=worst_f, worst_activation=worst_a, worst_qacc=worst_q,
+           mean_contacts=float(stats[:, 0].mean()))
+    assert compared >= 30 and worst_f < 1e-4 and worst_a < 1e-5 and worst_q < 2e-3
+    # (flies without a position servo slump onto the ground; the servoed ones of the last case stand on a few claws)
+    assert float(stats[:, 0].mean()) > (3 if kind in at.KW else 0.5) and bool(torch.isfinite(sim.field("qpos")).all())
+    if kind in ("intvelocity", "cylinder", "muscle"):
+        assert float(np.abs(act[:, ids]).max()) > 1e-3 and float(np.abs(act[:, [i for i in range(nu) if i not in ids]]).max()) == 0.0
+
+
+def test_a_world_with_two_flies_steps_each_like_its_own_world(torch_mod):
+    """``BaseWorld.add_fly`` takes several flies (reference ``compose/world.py:95-149``; refused until round 6).  The reference's
+    flies never collide with each other (``contype = conaffinity = 0``, fly-ground pairs only: ``compose/fly.py:609-610``,
+    ``compose/world.py:300-309``), so a fly of a two-fly world must move exactly as in a world of its own: every per-fly query of
+    ``HIPSimulation(two_fly_world, n)`` — and of the CPU-style ``Simulation`` — is bit-equal to the single-fly simulation's, with
+    different skeletons, spawn poses, actuator sets and controls per fly."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation, Simulation
+    from flygym_amd.anatomy import ActuatedDOFPreset, AxisOrder, JointPreset, Skeleton
+    from flygym_amd.compose import ActuatorType, FlatGroundWorld, Fly, KinematicPosePreset
+    from flygym_amd.utils.math import Rotation3D
+
+    def fly_a(name="alice"):
+        f = Fly(name=name)
+        f.add_joints(Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.LEGS_ONLY), neutral_pose=KinematicPosePreset.NEUTRAL)
+        f.add_actuators(f.skeleton.get_actuated_dofs_from_preset(ActuatedDOFPreset.LEGS_ACTIVE_ONLY), "position", kp=50.0, neutral_input=KinematicPosePreset.NEUTRAL)
+        f.add_leg_adhesion()
+        return f
+
+    def fly_b(name="bob"):
+        f = Fly(name=name)
+        f.add_joints(Skeleton(axis_order=AxisOrder.YAW_PITCH_ROLL, joint_preset=JointPreset.LEGS_ACTIVE_ONLY), neutral_pose=KinematicPosePreset.NEUTRAL)
+        f.add_actuators(f.skeleton.get_actuated_dofs_from_preset(ActuatedDOFPreset.LEGS_ACTIVE_ONLY), "position", kp=20.0, neutral_input=KinematicPosePreset.NEUTRAL)
+        return f
+
+    spawn = {"alice": ((0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0))), "bob": ((6.0, -3.0, 1.1), Rotation3D("quat", (0.9238795, 0, 0, 0.3826834)))}
+    both = FlatGroundWorld()
+    both.add_fly(fly_a(), *spawn["alice"])
+    both.add_fly(fly_b(), *spawn["bob"], add_ground_contact_sensors=False)
+    with pytest.raises(ValueError, match="already exists"):
+        both.add_fly(fly_b(), *spawn["bob"])
+    with pytest.raises(ValueError, match="holds 2 flies"):
+        both.compile_model()
+    assert both.compile_model("bob").nv == 48 and both.compile_model("alice").nv == 72
+    n = 32
+    sim = HIPSimulation(both, n_worlds=n, device=0)
+    assert set(sim.sims) == {"alice", "bob"} and sim.for_fly("bob").model.nv == 48
+    alone = {}
+    for name, make in (("alice", fly_a), ("bob", fly_b)):
+        w = FlatGroundWorld()
+        if name == "bob": w.add_fly(make(), *spawn[name], add_ground_contact_sensors=False)
+        else: w.add_fly(make(), *spawn[name])
+        alone[name] = HIPSimulation(w, n_worlds=n, device=0)
+    g = torch.Generator(device=sim.device); g.manual_seed(5)
+    for tick in range(6):
+        for name in ("alice", "bob"):
+            fly = both.fly_lookup[name]
+            k = len(fly.get_actuated_jointdofs_order("position"))
+            target = sim.get_joint_angles(name)[:, :0].new_zeros((n, k)) + 0.3 * torch.rand((n, k), device=sim.device, generator=g)
+            sim.set_actuator_inputs(name, ActuatorType.POSITION, target)
+            alone[name].set_actuator_inputs(name, ActuatorType.POSITION, target)
+        adh = torch.ones((n, 6), device=sim.device) * (tick % 2)
+        sim.set_leg_adhesion_states("alice", adh); alone["alice"].set_leg_adhesion_states("alice", adh)
+        sim.step(25)
+        for s in alone.values(): s.step(25)
+        torch.cuda.synchronize()
+        for name in ("alice", "bob"):
+            for q in ("get_joint_angles", "get_joint_velocities", "get_body_positions", "get_body_rotations"):
+                assert torch.equal(getattr(sim, q)(name), getattr(alone[name], q)(name)), (tick, name, q)
+            assert torch.equal(sim.get_actuator_forces(name, "position"), alone[name].get_actuator_forces(name, "position"))
+        for a, b in zip(sim.get_ground_contact_info("alice"), alone["alice"].get_ground_contact_info("alice")):
+            assert torch.equal(a, b)
+    assert float(sim.get_body_positions("bob")[:, 0, 0].mean()) > 4.0 > float(sim.get_body_positions("alice")[:, 0, 0].mean())
+    assert sim.time == pytest.approx(150 * 1e-4, rel=1e-3)
+    with pytest.raises(AttributeError, match="for_fly"):
+        sim.field("qpos")
+    sim.reset()
+    assert float(sim.get_joint_velocities("bob").abs().max()) == 0.0
+    # the single-world CPU-style class on the same world
+    one = Simulation(both, device=0)
+    one.warmup(0.005)
+    ja = one.get_joint_angles("alice"); jb = one.get_joint_angles("bob")
+    assert ja.shape == (66,) and jb.shape == (42,) and np.isfinite(ja).all() and np.isfinite(jb).all()
