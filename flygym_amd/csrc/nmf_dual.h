@@ -111,6 +111,9 @@ __device__ __forceinline__ void dual_eliminate(unsigned long long rem, const Dua
   auto first_of = [](unsigned long long r) { return __builtin_amdgcn_readfirstlane(max(__ffsll((long long)r) - 1, 0)); };      // (0 for an empty set: a harmless fetch)
   int kk_next = first_of(rem);
   DualCol::Raw an = dc.fetch(kk_next);
+  // (Round 6, measured and dropped: the two rows of a pyramid pair read the same four entries of G and differ in the sign of mu
+  // only — skipping the reads and their address arithmetic when the next pivot is this one's pair mate costs a scalar branch per
+  // pivot in front of the reads that are meant to be in flight early: 59.9 -> 59.0 M.)
 #define NMF_DUAL_PIVOT(P)                                                                                   \
   if constexpr (P < PMAX) {                                                                                 \
     if (rem == 0ull) return;                                                                                \

@@ -3,12 +3,12 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v Warn | tail -40 ) > gpurun_out/r5_pytest.log
-( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > gpurun_out/r5_smoke.log
-python bench.py --no-cpu-baseline --no-live-counters --steps 20 --warmup 5 > gpurun_out/r5_bench_driver.log 2>&1
-python bench.py --no-cpu-baseline --no-live-counters --no-other-configs > gpurun_out/r5_bench_default.log 2>&1
-tail -30 gpurun_out/r5_pytest.log; cat gpurun_out/r5_smoke.log
-for f in gpurun_out/r5_bench_driver.log gpurun_out/r5_bench_default.log; do grep '^{"metric"' $f | python -c "
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v Warn | tail -40 ) > gpurun_out/r6_pytest.log
+( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > gpurun_out/r6_smoke.log
+python bench.py --no-cpu-baseline --no-live-counters --steps 20 --warmup 5 > gpurun_out/r6_bench_driver.log 2>&1
+python bench.py --no-cpu-baseline --no-live-counters --no-other-configs > gpurun_out/r6_bench_default.log 2>&1
+tail -30 gpurun_out/r6_pytest.log; cat gpurun_out/r6_smoke.log
+for f in gpurun_out/r6_bench_driver.log gpurun_out/r6_bench_default.log; do grep '^{"metric"' $f | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); c = d['config']

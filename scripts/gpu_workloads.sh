@@ -11,6 +11,8 @@ for l in sys.stdin:
 " "$1"; }
 {
 for n in 16 64 256 1024 2048 4096 8192 16384; do timeout 300 $B --workload replay --worlds-per-gpu $n 2>/dev/null | line "replay worlds $n"; done
+# the reference benchmark's second series: every collision geom a capsule (run_gpu_benchmark.py:15-24 sweeps simplify_geom in [False, True])
+for n in 16 64 256 1024 2048 4096 8192 16384; do timeout 300 $B --workload replay --simplify-geom --worlds-per-gpu $n 2>/dev/null | line "replay, all-capsule geoms, worlds $n"; done
 for t in gapped blocks mixed; do timeout 300 $B --terrain $t 2>/dev/null | line "cpg terrain $t"; done
 timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 2>/dev/null | line "config5 mixed+odor+adhesion 4096"
 timeout 300 $B --terrain mixed --odor --cpg-adhesion 20 --worlds-per-gpu 128 2>/dev/null | line "config5 mixed+odor+adhesion 128"

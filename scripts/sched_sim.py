@@ -1,5 +1,5 @@
 """Offline model of a chunked launch (diagnostic): list scheduling of (world, steps) tickets on 2048 persistent workgroups with
-the precedence of a world's items, on per-world costs recorded by scripts/cost_pairing.py (gpurun_out/costpair_chunks.npy).
+the precedence of a world's items, on per-world costs recorded by scripts/archive/cost_pairing.py (gpurun_out/costpair_chunks.npy).
 Reproduces the measured failure of whole-launch items for the costliest worlds (2275 vs 1894 us modelled, 38.1 vs 44.7 M measured)."""
 import numpy as np, heapq, sys
 c = np.load("gpurun_out/costpair_chunks.npy")[0]

@@ -621,7 +621,7 @@ def test_full_size_batches_step_like_the_oracle_from_their_own_states(torch_mod,
                 # force-weighted centroid: where two contacts of a leg share a load the split is as uncertain as the solve —
                 # no further from the float64 oracle than twice the float32 oracle is.  (Floor 2e-4 mm: over 192 walking
                 # ALL_BIOLOGICAL states the centroid is off by 7e-7 mm in the median, 1e-6 at the 90 % quantile and 2.5e-5 at
-                # most with the contact-space solve, 6.3e-5 with the primal loop — scripts/r4/gpu_qacc_err.py; the tail is
+                # most with the contact-space solve, 6.3e-5 with the primal loop — scripts/archive/r4/gpu_qacc_err.py; the tail is
                 # that near-degenerate split, met here once in 72 x 6 legs at 1.35e-4.)
                 so32 = ref["f32"].arr("sensordata").reshape(6, 16) if mine == ref["f32"].ints()["con_geom"] else so
                 np.testing.assert_allclose(sh[:, 7:10], so[:, 7:10], atol=max(2e-4, 2.0 * np.abs(so32[:, 7:10] - so[:, 7:10]).max()))
