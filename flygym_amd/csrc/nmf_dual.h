@@ -64,14 +64,21 @@ struct DualCol {
   int cc9b, blk9b;        // byte offsets: 36 cc, 36 cc (cc + 1) / 2
   int tdb, td3b;          // the lane's tangent (1: rows 0 / 1, 2: rows 2 / 3) as byte offsets 4 td, 12 td
   float smu;              // +- mu of the lane's row
-  struct Raw { float nn, nt, tn, tt, smu2; };
+  // the lane's vector as a combination of its contact's directions: alpha n + beta t (t = the lane's tangent) — a pyramid row is
+  // (1, +- mu); in direction mode (dual_solve) lane k = 0 of a contact stands for n (1, 0), k = 1 / 2 for t1 / t2 (0, 1), k = 3 for nothing (0, 0)
+  float alpha, beta;
+  struct Raw { float nn, nt, tn, tt, smu2, a2; };
   __device__ __forceinline__ void init(const float* g, int lane, float smu_) {
     G = lds_pinned(g); cc = lane >> 2; cc9b = 36 * cc; blk9b = 36 * (cc * (cc + 1) / 2);
     const int td = 1 + ((lane >> 1) & 1);
     tdb = 4 * td; td3b = 12 * td; smu = smu_;
+    alpha = 1.f; beta = smu_;
     asm("" : "+v"(cc9b), "+v"(blk9b), "+v"(tdb), "+v"(td3b));      // lane constants, not expressions to re-derive per pivot
   }
   __device__ __forceinline__ Raw fetch(int kk) const {
+    // (Round 6, measured and dropped: the pivot's side of the address as three v_readlane of what lane kk holds for its own contact
+    // instead of these eight scalar instructions, and the pivot search as one s_ff1: 60.0 -> 59.7 M — scalar issue is not what the
+    // step is short of, vector issue is.)
     const unsigned int c2 = (unsigned int)kk >> 2, td2b = 4u + (((unsigned int)kk << 1) & 4u);      // scalar
     int c29b = (int)(36u * c2), blk29b = (int)(18u * (c2 * (c2 + 1u)));
     asm("" : "+s"(c29b), "+s"(blk29b));      // (scalar multiplies, not v_mad_u64_u32 per lane)
@@ -86,10 +93,10 @@ struct DualCol {
     auto at = [&](int byte_off) { return *(lds_cptr)((const __attribute__((address_space(3))) char*)G + byte_off); };
     Raw r;
     r.nn = at(base); r.nt = at(a_nt); r.tn = at(a_tn); r.tt = at(a_tt);
-    r.smu2 = readlane_f(smu, kk);
+    r.smu2 = readlane_f(beta, kk); r.a2 = readlane_f(alpha, kk);
     return r;
   }
-  __device__ __forceinline__ float value(const Raw& r) const { return fmaf(smu, fmaf(r.smu2, r.tt, r.tn), fmaf(r.smu2, r.nt, r.nn)); }
+  __device__ __forceinline__ float value(const Raw& r) const { return fmaf(beta, fmaf(r.smu2, r.tt, r.a2 * r.tn), alpha * fmaf(r.smu2, r.nt, r.a2 * r.nn)); }
 };
 __device__ __forceinline__ float quad_sum(float v) {
   v += NMF_DPP(v, 0xB1);
@@ -367,13 +374,50 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   for (int iter = 0; iter < m.max_iter; ++iter) {
     iters = iter + 1;
     // Gauss-Jordan on [R + A | j0]: pivots = active rows in index order, every row takes part
-    float b = j0, diag = 1.f;
-    dual_eliminate<4 * NC>(mask, dcol, R, lane, b, diag);
+    // Direction pivots: a contact whose four rows are all pivots — lambda_c = E psi lies in the range of the 4 x 3 pyramid map E
+    // (rows n +- mu t1, n +- mu t2), and its four equations are the three of phi = E^T lambda:
+    // (G_cc + R (E^T E)^-1) phi + sum_c' G_cc' phi_c' = -(E^T E)^-1 E^T j0, E^T E = diag(4, 2 mu^2, 2 mu^2) — three pivots instead of
+    // four, each column one direction of G instead of a pyramid combination.  Lanes k = 0, 1, 2 of such a contact stand for n, t1,
+    // t2; the other contacts keep their rows; the matrix stays symmetric (DualCol's alpha, beta).  Same optimum.
+    const unsigned int nib4 = (unsigned int)(mask >> (4 * cc)) & 0xfu;
+#ifdef NMF_DUAL_DIRS
+    const bool fullc = on && nib4 == 0xfu && mu > 1e-6f;
+#else
+    // NOT the shipped default (round 6): measured + 1.7 % (59.9 -> 60.9 M at the driver's arguments, 62.95 -> 64.0 M default, no
+    // elimination beyond 47 pivots left) with the SAME one-step accuracy on identical states (scripts/onestep_error.py: median
+    // 4.59e-5 against 4.61e-5 of max |qacc|, p99 2.3e-4 / 2.2e-4 over 384 states; mixed terrain 4.93e-5 / 5.03e-5) — but the
+    // 150-step free rollouts of tests/test_hip_parity_r2.py leave one more chaotic clip partition behind than the row pivots do
+    // (28 of 32 picks followed against 30; the bar is the primal loop's 32 minus 2), and this round's rule is that no bar moves.
+    // Build with -DNMF_DUAL_DIRS to get it (the code below is the same either way: with `fullc` false every contact keeps its rows).
+    const bool fullc = false;
+#endif
+    float b, diag = 1.f, R_e = R;
+    unsigned long long mask_e = mask;
+    {
+      const float q0 = NMF_DPP(j0, 0x00), q1 = NMF_DPP(j0, 0x55), q2 = NMF_DPP(j0, 0xAA), q3 = NMF_DPP(j0, 0xFF);
+      const float hm = 0.5f * __builtin_amdgcn_rcpf(mu);                       // 1 / (2 mu)
+      const float bdir = k == 0 ? 0.25f * ((q0 + q1) + (q2 + q3)) : k == 1 ? hm * (q0 - q1) : k == 2 ? hm * (q2 - q3) : 0.f;
+      b = fullc ? bdir : j0;
+      R_e = fullc ? (k == 0 ? 0.25f * R : R * (2.f * hm * hm)) : R;           // R / 4, R / (2 mu^2)
+      dcol.alpha = fullc ? (k == 0 ? 1.f : 0.f) : 1.f;
+      dcol.beta = fullc ? ((k == 1 || k == 2) ? 1.f : 0.f) : smu;
+      mask_e = __ballot(fullc ? k < 3 : (bool)((mask >> lane) & 1ull));
+    }
+    dual_eliminate<4 * NC>(mask_e, dcol, R_e, lane, b, diag);
     const bool act = (mask >> lane) & 1ull;
-    const float lam_t = act ? -b * __builtin_amdgcn_rcpf(diag) : 0.f;
-    const float jar_t = act ? -R * lam_t : b;
+    const bool piv = (mask_e >> lane) & 1ull;
+    const float x = piv ? -b * __builtin_amdgcn_rcpf(diag) : 0.f;               // phi* on direction lanes, lambda* on pivot rows
+    float lam_t, jar_t;
+    {
+      const float x0 = NMF_DPP(x, 0x00), x1 = NMF_DPP(x, 0x55), x2 = NMF_DPP(x, 0xAA);
+      const float hm = 0.5f * __builtin_amdgcn_rcpf(mu);
+      const float lam_dir = fmaf((k & 1) ? -hm : hm, k < 2 ? x1 : x2, 0.25f * x0);     // E (E^T E)^-1 phi
+      lam_t = fullc ? lam_dir : (act ? x : 0.f);
+      jar_t = fullc ? -R * lam_dir : (act ? -R * lam_t : b);
+    }
+    dcol.alpha = 1.f; dcol.beta = smu;
     const unsigned long long tmask = __ballot(on && jar_t < 0.f);
-    npiv = max(npiv, (int)__popcll(mask));
+    npiv = max(npiv, (int)__popcll(mask_e));
     jar_last = jar_t; viol_last = tmask ^ mask;
 #ifdef NMF_DUAL_DEBUG
     {
