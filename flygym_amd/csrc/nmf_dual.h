@@ -165,6 +165,42 @@ __device__ __noinline__ void dual_restore(FlyLds<TP>& s, const GModel& m, int la
   sweep_twists(s, s.qacc_smooth, s.T, m, lane);
 }
 
+// The CPU flavour's noslip post-pass on the rows of a contact-space solve (see dual_solve): Gauss-Seidel over the pairs of opposing
+// pyramid edges with the regulariser removed; returns the rows' forces after it.  Not inlined: the batched flavour never runs it.
+template <class TP>
+__device__ __noinline__ float dual_noslip(FlyLds<TP>& s, const GModel& m, int lane, int ncon, float frow, float j0, float R, float smu) {
+  lane = opaque(lane);
+  ncon = __builtin_amdgcn_readfirstlane(ncon);
+  const bool on = lane < 4 * ncon;
+  const float scale = 1.0f / (m.meaninertia * (float)TP::NV);
+  DualCol dcol;
+  dcol.init(dual_g(s), lane, smu);
+    for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
+      float improvement = sweep == 0 ? wave_sum(0.5f * frow * frow * R) : 0.f;       // the regulariser's share of the cost drops out
+      for (int c2 = 0; c2 < ncon; ++c2) {
+        for (int pp = 0; pp < 2; ++pp) {
+          const int r0 = 4 * c2 + 2 * pp, r1 = r0 + 1;
+          const float col0 = dcol.value(dcol.fetch(r0)), col1 = dcol.value(dcol.fetch(r1));
+          const float res0 = wave_sum(on ? col0 * frow : 0.f) + readlane_f(j0, r0), res1 = wave_sum(on ? col1 * frow : 0.f) + readlane_f(j0, r1);
+          const float a00 = readlane_f(col0, r0), a01 = readlane_f(col0, r1), a11 = readlane_f(col1, r1);
+          const float old0 = readlane_f(frow, r0), old1 = readlane_f(frow, r1);
+          const float bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
+          const float mid = 0.5f * (old0 + old1);
+          const float K1 = a00 + a11 - 2.f * a01, K0 = mid * (a00 - a11) + bc0 - bc1;
+          float n0 = mid, n1 = mid;
+          if (!(K1 < kMinVal)) { const float y = fminf(fmaxf(-K0 / K1, -mid), mid); n0 = mid + y; n1 = mid - y; }
+          const float d0 = n0 - old0, d1 = n1 - old1;
+          float change = 0.5f * (d0 * (a00 * d0 + a01 * d1) + d1 * (a01 * d0 + a11 * d1)) + d0 * res0 + d1 * res1;
+          if (change > 1e-10f) { n0 = old0; n1 = old1; change = 0.f; }
+          frow = lane == r0 ? n0 : lane == r1 ? n1 : frow;
+          improvement -= change;
+        }
+      }
+      if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
+    }
+  return frow;
+}
+
 // How a solve ended (SolveReport bits, nmf_step.hip) and what the elimination it ended on violates: for every end but the
 // exact one the rows in (target's sign pattern) xor (pivot set) are the target's KKT violations — the largest |residual| among
 // them relative to the largest |residual| of all rows goes out as `resid` (0 = exact).
@@ -546,30 +582,8 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // the pairs of opposing pyramid edges with the regulariser removed — a pair (mid + y, mid - y) keeps its sum, y in
   // [-mid, mid] minimises 1/2 f^T A f + f^T j0; an update that raises the cost is undone; up to noslip_iter sweeps.
   // A's columns come out of G (DualCol), a pair's residual is two wave sums.  Not a throughput path: the batched class strips the option.
-  if (two_pass) {
-    for (int sweep = 0; sweep < m.noslip_iter; ++sweep) {
-      float improvement = sweep == 0 ? wave_sum(0.5f * frow * frow * R) : 0.f;       // the regulariser's share of the cost drops out
-      for (int c2 = 0; c2 < ncon; ++c2) {
-        for (int pp = 0; pp < 2; ++pp) {
-          const int r0 = 4 * c2 + 2 * pp, r1 = r0 + 1;
-          const float col0 = dcol.value(dcol.fetch(r0)), col1 = dcol.value(dcol.fetch(r1));
-          const float res0 = wave_sum(on ? col0 * frow : 0.f) + readlane_f(j0, r0), res1 = wave_sum(on ? col1 * frow : 0.f) + readlane_f(j0, r1);
-          const float a00 = readlane_f(col0, r0), a01 = readlane_f(col0, r1), a11 = readlane_f(col1, r1);
-          const float old0 = readlane_f(frow, r0), old1 = readlane_f(frow, r1);
-          const float bc0 = res0 - a00 * old0 - a01 * old1, bc1 = res1 - a01 * old0 - a11 * old1;
-          const float mid = 0.5f * (old0 + old1);
-          const float K1 = a00 + a11 - 2.f * a01, K0 = mid * (a00 - a11) + bc0 - bc1;
-          float n0 = mid, n1 = mid;
-          if (!(K1 < kMinVal)) { const float y = fminf(fmaxf(-K0 / K1, -mid), mid); n0 = mid + y; n1 = mid - y; }
-          const float d0 = n0 - old0, d1 = n1 - old1;
-          float change = 0.5f * (d0 * (a00 * d0 + a01 * d1) + d1 * (a01 * d0 + a11 * d1)) + d0 * res0 + d1 * res1;
-          if (change > 1e-10f) { n0 = old0; n1 = old1; change = 0.f; }
-          frow = lane == r0 ? n0 : lane == r1 ? n1 : frow;
-          improvement -= change;
-        }
-      }
-      if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
-    }
+  if (two_pass) {       // (its own function: inlined, the pass's code sat in every batched step's way — 1.0 % of the headline, round 6)
+    frow = dual_noslip<TP>(s, m, lane, ncon, frow, j0, R, smu);
     lam = frow; c_ws = 0.f;       // qacc = M^-1 (qfrc_smooth + J^T f): first pass of the expansion below
   }
   // the final active set, for the next step
@@ -598,8 +612,9 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // One pass on the batched flavour.  CPU flavour (noslip on): two — first the noslip forces' acceleration, which is the step's
   // qacc (an output: straight to HBM on a launch's last step, qacc_out), then the main solver's, which stays in s.qacc as the
   // next step's warm start.
-  for (int pass = 0, npass = two_pass ? 2 : 1; pass < npass; ++pass) {
-  const float lam_x = pass ? lam_main : lam, c_x = pass ? c_main : c_ws;
+  // (The batched flavour's single pass is straight-line code of its own: as one trip of the CPU flavour's two-trip loop it cost the
+  // headline 1.0 % — 60.5 -> 59.9 M at the driver's arguments, measured in round 6 — for a pass only the one-world flavour runs.)
+  auto expand_pass = [&](const float lam_x, const float c_x, const bool first_of_two) {
   if constexpr (!kProdInG) {
     for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
     WSYNC();
@@ -688,11 +703,17 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     }
   }
   WSYNC();
-  if (two_pass && pass == 0) {
+  if (first_of_two) {
     if (qacc_out) { for (int j = lane; j < TP::NV; j += kWave) qacc_out[opaque(j)] = s.qacc[j]; }
     WSYNC();
   }
-  }             // the factors are dead: c_w takes the contact wrenches again
+  };
+  if (!two_pass) expand_pass(lam, c_ws, false);
+  else {
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < 2; ++pass) expand_pass(pass ? lam_main : lam, pass ? c_main : c_ws, pass == 0);
+  }
+  // the factors are dead: c_w takes the contact wrenches again
   STAGE(14);
   // ---- contact wrenches and J^T f
   {
