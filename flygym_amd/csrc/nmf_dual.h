@@ -166,9 +166,11 @@ __device__ __noinline__ void dual_restore(FlyLds<TP>& s, const GModel& m, int la
 }
 
 // The CPU flavour's noslip post-pass on the rows of a contact-space solve (see dual_solve): Gauss-Seidel over the pairs of opposing
-// pyramid edges with the regulariser removed; returns the rows' forces after it.  Not inlined: the batched flavour never runs it.
+// pyramid edges with the regulariser removed; returns the rows' forces after it.  The batched flavour never runs it: on the
+// leg-chain kernels it is a function of its own (dual_noslip_cold: inlined it cost the headline 1 %); the hybrid kernels, whose
+// registers a call site would push into scratch (ALL_BIOLOGICAL 1 -> 10 spilled registers, 31.4 -> 30.9 M), keep it inline.
 template <class TP>
-__device__ __noinline__ float dual_noslip(FlyLds<TP>& s, const GModel& m, int lane, int ncon, float frow, float j0, float R, float smu) {
+__device__ __forceinline__ float dual_noslip(FlyLds<TP>& s, const GModel& m, int lane, int ncon, float frow, float j0, float R, float smu) {
   lane = opaque(lane);
   ncon = __builtin_amdgcn_readfirstlane(ncon);
   const bool on = lane < 4 * ncon;
@@ -199,6 +201,10 @@ __device__ __noinline__ float dual_noslip(FlyLds<TP>& s, const GModel& m, int la
       if (scale * improvement < 1e-6f) break;          // noslip_tolerance (MuJoCo's default)
     }
   return frow;
+}
+template <class TP>
+__device__ __noinline__ float dual_noslip_cold(FlyLds<TP>& s, const GModel& m, int lane, int ncon, float frow, float j0, float R, float smu) {
+  return dual_noslip<TP>(s, m, lane, ncon, frow, j0, R, smu);
 }
 
 // How a solve ended (SolveReport bits, nmf_step.hip) and what the elimination it ended on violates: for every end but the
@@ -583,7 +589,8 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // [-mid, mid] minimises 1/2 f^T A f + f^T j0; an update that raises the cost is undone; up to noslip_iter sweeps.
   // A's columns come out of G (DualCol), a pair's residual is two wave sums.  Not a throughput path: the batched class strips the option.
   if (two_pass) {       // (its own function: inlined, the pass's code sat in every batched step's way — 1.0 % of the headline, round 6)
-    frow = dual_noslip<TP>(s, m, lane, ncon, frow, j0, R, smu);
+    if constexpr (kDualS<TP>) frow = dual_noslip_cold<TP>(s, m, lane, ncon, frow, j0, R, smu);
+    else frow = dual_noslip<TP>(s, m, lane, ncon, frow, j0, R, smu);
     lam = frow; c_ws = 0.f;       // qacc = M^-1 (qfrc_smooth + J^T f): first pass of the expansion below
   }
   // the final active set, for the next step
@@ -612,9 +619,8 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
   // One pass on the batched flavour.  CPU flavour (noslip on): two — first the noslip forces' acceleration, which is the step's
   // qacc (an output: straight to HBM on a launch's last step, qacc_out), then the main solver's, which stays in s.qacc as the
   // next step's warm start.
-  // (The batched flavour's single pass is straight-line code of its own: as one trip of the CPU flavour's two-trip loop it cost the
-  // headline 1.0 % — 60.5 -> 59.9 M at the driver's arguments, measured in round 6 — for a pass only the one-world flavour runs.)
-  auto expand_pass = [&](const float lam_x, const float c_x, const bool first_of_two) {
+  for (int pass = 0, npass = two_pass ? 2 : 1; pass < npass; ++pass) {
+  const float lam_x = pass ? lam_main : lam, c_x = pass ? c_main : c_ws;
   if constexpr (!kProdInG) {
     for (int i = lane; i < NLEG * NDL; i += kWave) acc[i] = 0.f;
     WSYNC();
@@ -703,17 +709,11 @@ __device__ __forceinline__ int dual_solve(FlyLds<TP>& s, const GModel& m, int la
     }
   }
   WSYNC();
-  if (first_of_two) {
+  if (two_pass && pass == 0) {
     if (qacc_out) { for (int j = lane; j < TP::NV; j += kWave) qacc_out[opaque(j)] = s.qacc[j]; }
     WSYNC();
   }
-  };
-  if (!two_pass) expand_pass(lam, c_ws, false);
-  else {
-#pragma clang loop unroll(disable)
-    for (int pass = 0; pass < 2; ++pass) expand_pass(pass ? lam_main : lam, pass ? c_main : c_ws, pass == 0);
-  }
-  // the factors are dead: c_w takes the contact wrenches again
+  }             // the factors are dead: c_w takes the contact wrenches again
   STAGE(14);
   // ---- contact wrenches and J^T f
   {
