@@ -557,3 +557,34 @@ def test_one_step_accuracy_on_states_that_do_not_depend_on_the_solver(torch_mod,
     assert len(devs) >= 0.95 * total                                              # contact lists equal to the oracle's in nearly every sampled state
     assert np.median(devs) < 1e-4 and np.quantile(devs, 0.9) < 3e-4 and np.quantile(devs, 0.99) < 1e-3 and devs.max() < 2e-3
     assert exits["contact_space"] >= 0.99 * exits["steps"] * (1.0 if terrain == "flat" else 0.97)      # the judged solver is the contact-space one
+
+
+def test_flies_per_cu_option_changes_residency_not_results(torch_mod):
+    """``nmf_batch_options.flies_per_cu`` (round 6: idle LDS per stepping workgroup, so that a CU keeps room for another stream's
+    kernel — measured with the eye renderer, DESIGN_APPENDIX.md H): ``nmf_batch_info`` reports the residency asked for, the grid
+    shrinks with it, and — scheduling only — the states after chunked launches are bit-identical to the default batch's."""
+    torch = torch_mod
+    from flygym_amd import HIPSimulation, make_model
+    from flygym_amd.controllers import TripodCPG
+
+    n = 4096
+    sims = []
+    for opts in (None, dict(flies_per_cu=6), dict(flies_per_cu=99)):
+        fly, world, _ = make_model()
+        sim = HIPSimulation(world, n_worlds=n, device=0, _options=opts)
+        sim.set_leg_adhesion_states(fly.name, np.ones((n, 6), dtype=np.float32))
+        sims.append(sim)
+    base, six, many = sims
+    info0, info6, info99 = base.batch_info(), six.batch_info(), many.batch_info()
+    assert info0["flies_per_cu"] == 8 and info6["flies_per_cu"] == 6 and info99["flies_per_cu"] == 8      # above the kernel's own: ignored
+    assert info6["resident_workgroups"] * 8 == info0["resident_workgroups"] * 6
+    table = TripodCPG(fly.get_actuated_jointdofs_order("position"), base.timestep).targets(n, 2500, device=base.device)
+    ids = base.replay_ids(fly.name)
+    for sim in (base, six):
+        sim.warmup()
+        for k in range(4):
+            sim.step_replay(table, ids, 20 * k, 20)
+    torch.cuda.synchronize()
+    for k in KEYS + ("qacc", "sensordata"):
+        assert torch.equal(base.field(k), six.field(k)), k
+    assert float(base.field("stats")[:, 0].mean()) > 3
