@@ -223,6 +223,25 @@ class Fly:
         self.joint_params.update(out)
         return out
 
+    def set_joint_params(self, jointdofs: Iterable[JointDOF], *, stiffness: float | None = None, damping: float | None = None,
+                         armature: float | None = None, springref: float | None = None) -> None:
+        """Change the passive parameters of SOME joints after :meth:`add_joints` (which sets one value for all).  The reference does
+        this by editing the MJCF tree — ``for joint in fly.mjcf_root.worldbody.find_all("joint"): joint.stiffness = 5``
+        (tutorial 1bis, "change the stiffness of all tarsal joints"); this engine has no MJCF document, the recorded joint
+        parameters (``fly.joint_params[dof]``: name, axis, stiffness, damping, armature, springref) are what the compiler reads.
+        Global options are ``fly.mujoco_globals`` (``["option"]["timestep"]``, ``["option"]["gravity"]``, ...: the reference's
+        ``fly.mjcf_root.option``)."""
+        for dof in jointdofs:
+            if dof not in self.joint_params:
+                raise ValueError(f"joint {dof.name} does not exist")
+            for key, val in (("stiffness", stiffness), ("damping", damping), ("armature", armature), ("springref", springref)):
+                if val is not None:
+                    if key != "springref" and float(val) < 0:
+                        raise ValueError(f"{key} cannot be negative")
+                    self.joint_params[dof][key] = float(val)
+            if springref is not None:
+                self.jointdof_to_neutralangle[dof] = float(springref)
+
     # ---- actuators ---------------------------------------------------------------
     def add_actuators(
         self,

@@ -312,3 +312,34 @@ def test_a_world_takes_several_flies():
     assert alone.compile_model().digest() == ma.digest()
     with pytest.raises(KeyError):
         w.compile_model("c")
+
+
+def test_per_joint_parameters_and_global_options_reach_the_model(oracle_lib):
+    """What the reference's tutorial 1bis does through ``fly.mjcf_root`` (dm_control): a different stiffness for the tarsal joints
+    only, another timestep.  Here: ``Fly.set_joint_params`` / ``fly.joint_params`` and ``fly.mujoco_globals`` — the compiled model
+    carries them and the oracle's passive force follows."""
+    fly = Fly(name="t")
+    sk = A.Skeleton(axis_order=A.AxisOrder.YAW_PITCH_ROLL, joint_preset=A.JointPreset.LEGS_ONLY)
+    fly.add_joints(sk, neutral_pose=KinematicPosePreset.NEUTRAL)
+    tarsal = [d for d in fly.get_jointdofs_order() if d.child.link.startswith("tarsus") and d.child.link != "tarsus1"]
+    assert len(tarsal) == 24
+    fly.set_joint_params(tarsal, stiffness=5.0, damping=0.25)
+    with pytest.raises(ValueError, match="negative"):
+        fly.set_joint_params(tarsal[:1], damping=-1.0)
+    fly.mujoco_globals["option"]["timestep"] = 2e-4
+    world = FlatGroundWorld()
+    world.add_fly(fly, (0, 0, 0.8), Rotation3D("quat", (1, 0, 0, 0)))
+    m = world.compile_model()
+    order = fly.get_jointdofs_order()
+    is_t = np.array([d in tarsal for d in order])
+    np.testing.assert_array_equal(m["dof_stiffness"][6:][is_t], 5.0)
+    np.testing.assert_array_equal(m["dof_stiffness"][6:][~is_t], 10.0)
+    np.testing.assert_array_equal(m["dof_damping"][6:][is_t], 0.25)
+    assert float(m["opt_timestep"][0]) == 2e-4
+    o = oracle_lib.Oracle(m.to_blob(), "f64")
+    o.qpos[7:] += 0.1                      # every hinge 0.1 rad off its spring reference
+    o.forward()
+    qp = o.arr("qfrc_passive")[6:]
+    np.testing.assert_allclose(qp[is_t], -0.5, rtol=1e-12); np.testing.assert_allclose(qp[~is_t], -1.0, rtol=1e-12)
+    o.step(1)
+    assert o.arr("time")[0] == pytest.approx(2e-4)
