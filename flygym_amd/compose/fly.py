@@ -120,6 +120,18 @@ class Fly:
             seg.is_leg() and seg.link == "tarsus5"
         )
 
+    # ---- MJCF surface of the reference (compose/base.py): this engine has no MJCF document; said so, not silently absent ----------
+    @property
+    def mjcf_root(self):
+        raise AttributeError(
+            "flygym_amd has no MJCF document (the reference's fly.mjcf_root is a dm_control element tree): the recorded choices are "
+            "fly.joint_params / fly.set_joint_params(), fly.actuators, fly.mujoco_globals; world.compile_model() gives the compiled model")
+
+    def save_xml_with_assets(self, *args, **kwargs):
+        raise NotImplementedError(
+            "flygym_amd compiles the recorded choices to its own flat model, not to MJCF: use world.compile_model().save(path) "
+            "(CompiledModel.load(path) reads it back) — there is no XML to export")
+
     def compile(self):
         """``(model, data)`` of the fly on its own, as the reference's ``Fly.compile`` (``compose/base.py:21-27``): the
         fly floating in empty space.  The reference's standalone fly has no free joint, so the summary counts only the
