@@ -136,6 +136,8 @@ class OdorSensors:
     def __init__(self, sim, fly_name: str, source_positions, peak_intensities):
         import torch
 
+        if hasattr(sim, "for_fly"):          # a world with several flies: this fly's batch
+            sim = sim.for_fly(fly_name)
         self.sim = sim
         fly = sim.world.fly_lookup[fly_name]
         names = [s.name for s in fly.get_bodysegs_order()]

@@ -123,6 +123,8 @@ class EyeRenderer:
         if rays_per_ommatidium not in (0, 16):
             raise ValueError("rays_per_ommatidium must be 0 (every pixel) or 16")
 
+        if hasattr(sim, "for_fly"):          # a world with several flies: this fly's batch
+            sim = sim.for_fly(fly_name)
         self.sim, self.scene, self.retina = sim, scene or Scene(), retina or Retina()
         fly = sim.world.fly_lookup[fly_name]
         names = [s.name for s in fly.get_bodysegs_order()]

@@ -487,6 +487,13 @@ def test_a_world_with_two_flies_steps_each_like_its_own_world(torch_mod):
         sim.field("qpos")
     sim.reset()
     assert float(sim.get_joint_velocities("bob").abs().max()) == 0.0
+    # the sensors take the multi-fly simulation and find their fly's batch
+    from flygym_amd.sensors import OdorSensors
+    from flygym_amd.vision import EyeRenderer
+    odor = OdorSensors(sim, "bob", [(10.0, 0.0, 1.0)], [(1.0,)])
+    assert odor.sim is sim.for_fly("bob") and tuple(odor.get_odor_intensities().shape)[0] == n
+    eyes = EyeRenderer(sim, "alice")
+    assert eyes.sim is sim.for_fly("alice") and tuple(eyes.render().shape) == (n, 2, eyes.retina.num_ommatidia, 2)
     # the single-world CPU-style class on the same world
     one = Simulation(both, device=0)
     one.warmup(0.005)
