@@ -300,7 +300,11 @@ int launch(nmf_batch* b, const nmf::ReplayArgs& rp, int n_steps, hipStream_t str
   if (oversub && b->chunking && b->csched_buf && b->handoff_buf && n_steps >= 2 * b->min_chunk_steps) {
     int start = 0, c = 0;
     while (start < n_steps && c < b->max_chunks) {
-      int len = (int)std::ceil((n_steps - start) / (b->chunk_div_short && n_steps > 64 ? 2.0 : b->chunk_div));
+      // (the library's own plan — no chunk_div option given: launches of more than 64 steps halve; on flat ground with a leg-chain
+      // skeleton launches of up to 30 steps take 1.6 instead of 1.7 — 20 steps = 13 + 5 + 2, three chunks instead of 12 + 5 + 2 + 1:
+      // 60.05 -> 60.6 M at the driver's arguments, round 6; 30 steps tie, 40 and 50 steps keep 1.7: 63.0 against 62.5 M)
+      const double div = !b->chunk_div_short ? b->chunk_div : n_steps > 64 ? 2.0 : (b->chunk_div < 1.75 && n_steps <= 30 ? 1.6 : b->chunk_div);
+      int len = (int)std::ceil((n_steps - start) / div);
       len = std::max(len, b->min_chunk_steps);
       if (c == b->max_chunks - 1 || n_steps - start - len < b->min_chunk_steps) len = n_steps - start;
       b->st.chunk_start[c++] = start;
